@@ -127,6 +127,15 @@ class _Physics:
     self._b.n_forward += 1
 
 
+class _GeomUser(dict):
+  """physics.named.model.geom_user with nuser_geom=1: every entry is a float array
+  of shape (1,), and assignment writes into it (so `= [GROUP_GOAL]` works and
+  `entry == GROUP_GOAL` is truthy), as in MuJoCo's named indexer."""
+
+  def __setitem__(self, k, v):
+    dict.__setitem__(self, k, np.asarray(v, float).reshape(1))
+
+
 class PoseProvider:
   """Serves exactly the calls listed in SURVEY 8b from scripted data."""
 
@@ -136,7 +145,7 @@ class PoseProvider:
     self.nu = robot.nu
     self.actuator_ctrlrange = np.stack(
         [-np.ones(robot.nu), np.ones(robot.nu)], -1)
-    self.user_groups = {}
+    self.user_groups = _GeomUser()
     self.geom_rgba = {}
     self.site_rgba = {}
     self.pos = {}
@@ -158,7 +167,8 @@ class PoseProvider:
     self.time = 0.
     self.pos = {}
     # geom 'robot' carries the default user value 0 (= GROUP_INACTIVE)
-    self.user_groups = {'robot': consts.GROUP_INACTIVE}
+    self.user_groups = _GeomUser()
+    self.user_groups['robot'] = consts.GROUP_INACTIVE
     self.pos['robot'] = np.r_[np.asarray(config['robot_xy'], float),
                               config['robot_z_height']]
     th = config['robot_rot']
@@ -355,6 +365,16 @@ def _quat2mat(q):
 
 
 ref_utils.quat2mat = _quat2mat
+
+
+def rs_dump(rs):
+  st = rs.get_state()
+  return {
+      'key': [int(x) for x in st[1]],
+      'pos': int(st[2]),
+      'has_gauss': int(st[3]),
+      'cached_gaussian': float(st[4])
+  }
 
 
 def rs_probe(rs):
@@ -599,8 +619,17 @@ def run_episode(robot, task_name, seed, n_steps, script_seed):
     rp[:2] += stepv
     yaw[0] = np.arctan2(stepv[1], stepv[0]) + srs.normal(0, 0.05)
     bridge.mat = rotz(yaw[0])
-    bridge.vel = np.r_[stepv / (n * bridge.dt), 0.]
-    bridge.com = rp + bridge.mat @ np.array([0.019, 0., 0.])
+    # kinematically consistent rigid-body data for the Point robot: origin
+    # velocity v0, yaw rate wz, subtree COM at R (off,0,0), COM velocity
+    # v0 + wz x (R off)  (point.xml:18-19 masses: sphere 4/3 pi r^3, box 1e-3)
+    wz = srs.normal(0, 1)
+    off = 1e-4 / (4. / 3. * np.pi * 1e-3 + 1e-3)
+    v0 = np.r_[stepv / (n * bridge.dt), 0.]
+    lever = bridge.mat @ np.array([off, 0., 0.])
+    bridge.com = rp + lever
+    bridge.vel = v0 + np.cross([0., 0., wz], lever)
+    bridge.v0 = v0
+    bridge.wz = wz
     if 'box' in bridge.pos:
       bp = bridge.pos['box']
       g = bridge.pos['goal'][:2] - bp[:2]
@@ -631,8 +660,8 @@ def run_episode(robot, task_name, seed, n_steps, script_seed):
     bridge.contact_names = contacts
     s = bridge.sensors
     s['accelerometer'] = np.r_[srs.normal(0, 1, 2), 9.81]
-    s['velocimeter'] = bridge.mat.T @ bridge.vel
-    s['gyro'] = np.r_[0., 0., srs.normal(0, 1)]
+    s['velocimeter'] = bridge.mat.T @ bridge.v0
+    s['gyro'] = np.r_[0., 0., bridge.wz]
     s['magnetometer'] = bridge.mat.T @ np.array([0., -0.5, 0.])
 
   b.script = script
@@ -646,6 +675,9 @@ def run_episode(robot, task_name, seed, n_steps, script_seed):
       'init': snapshot(env),
       'init_obs': [float(x) for x in env.observation],
       'init_robot_rot': float(b.rot0),
+      'rs_state': rs_dump(env.rs),
+      'keepouts': {k: float(v[1]) for k, v in w._placements.items()},
+      'obstacles': [int(x) for x in task.obstacles],
   }
   names = [k for k in b.pos.keys()]
   rec['names'] = names
@@ -664,6 +696,8 @@ def run_episode(robot, task_name, seed, n_steps, script_seed):
         'groups': [snap['groups'][k] for k in names],
         'robot_mat': [float(x) for x in b.mat.ravel()],
         'robot_vel': [float(x) for x in b.vel],
+        'robot_v0': [float(x) for x in b.v0],
+        'robot_yaw': float(yaw[0]),
         'robot_com': [float(x) for x in b.com],
         'contacts': [list(c) for c in b.contact_names],
         'sensors': {

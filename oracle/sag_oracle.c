@@ -1,0 +1,1026 @@
+/*
+ * sag_oracle.c - CPU restatement of the hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library; the product (safe_adaptation_gym_amd + libsag.so) never does.
+ *
+ * Scalar, one env at a time, IEEE double (build with -DSAGO_F32 for a float
+ * variant used to separate precision effects from logic differences).
+ *
+ * Parity status
+ *   PINNED by fixtures generated from the reference's own NumPy code
+ *   (oracle/gen_golden.py -> tests/golden/): lidar, lidar grouping, hazard cost,
+ *   contact-count cost rule, every task's compute_reward / reset / set_mocaps,
+ *   goal resampling and its RNG draw order, button state machine.
+ *   UNPINNED ("parity unpinned"): the rigid-body dynamics.  The reference
+ *   delegates them to the MuJoCo C library (dm_control>=0.0.403778684, no pinned
+ *   version, not vendored, not installable here), so sago_substep() is a
+ *   specification written from the MJCF (assets/xmls/point.xml) and MuJoCo's
+ *   documented semantics, pinned only by analytic known answers
+ *   (tests/test_oracle_physics.py).
+ *
+ * Reference lines followed are cited at each function as file:line relative to
+ * /root/reference/safe_adaptation_gym/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/sag.h"
+
+#ifdef SAGO_F32
+typedef float real;
+#define R_SQRT sqrtf
+#define R_SIN sinf
+#define R_COS cosf
+#define R_FABS fabsf
+#else
+typedef double real;
+#define R_SQRT sqrt
+#define R_SIN sin
+#define R_COS cos
+#define R_FABS fabs
+#endif
+
+#define PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------------ */
+/* constants from the MJCF / primitive_objects.py                           */
+/* ------------------------------------------------------------------------ */
+/* point.xml:3 timestep, safe_adaptation_gym.py:15-19 substeps */
+static const double DT[3] = {0.004, 0.008, 0.012};
+static const int NSTEP[3] = {5, 10, 12};
+static const int NU[3] = {2, 2, 12};
+static const int OBS_DIM[3] = {60, 72, 104};
+
+/* point.xml:18-19, density 1 (:5): sphere r .1 + box half .05 at (.1,0,0) */
+#define PT_M_SPHERE (4.0 / 3.0 * PI * 0.001)
+#define PT_M_BOX 0.001
+#define PT_MASS (PT_M_SPHERE + PT_M_BOX)
+#define PT_MC (PT_M_BOX * 0.1) /* mass * com offset along local +x */
+#define PT_IO (0.4 * PT_M_SPHERE * 0.01 + PT_M_BOX * (0.01 + 0.01) / 12.0 + PT_M_BOX * 0.01)
+#define PT_DAMP_Z 0.005      /* point.xml:17 */
+#define PT_FORCE_LIM 0.05    /* point.xml:7-8 forcerange */
+#define PT_GEAR_Z 0.3        /* point.xml:37 */
+#define PT_KV 1.0            /* MuJoCo velocity actuator default kv */
+#define PT_Z 0.1             /* point.xml:13 body height (no z DoF) */
+#define GOAL_Z (0.3 / 2.0 + 1e-2) /* primitive_objects.py:141 size/2 + 1e-2 */
+#define GOAL_SIZE 0.3        /* tasks/go_to_goal.py:12 */
+#define GOAL_KEEPOUT 0.4     /* tasks/go_to_goal.py:13 */
+#define GOAL_RECT 1.5        /* tasks/go_to_goal.py:9 */
+#define BUTTON_R 0.1         /* tasks/press_buttons.py:16 */
+#define GRAVITY 9.81
+#define LIDAR_MAX 5.0        /* safe_adaptation_gym.py:23 */
+
+/* MuJoCo default contact softness: solref (0.02, 1), solimp (0.9, 0.95, 0.001, 0.5, 2);
+ * time constant clamped to >= 2*dt (refsafe). */
+#define SOL_TC 0.02
+#define SOL_D0 0.9
+#define SOL_D1 0.95
+#define SOL_WIDTH 0.001
+#define FRICTION_MU 1.0 /* max(geom frictions) = 1 for every default pair */
+
+/* vases: free box, density .001 (consts.py:20-21, primitive_objects.py:39-54) */
+#define VASE_DENSITY 0.001
+
+#define MAX_RESAMPLE_TRIES 10000 /* inner loop of tasks/go_to_goal.py:63-64 */
+
+/* ------------------------------------------------------------------------ */
+/* env state: the sag.h record, widened to `real`                           */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  real f[SAG_REC_FLOATS];
+  int32_t i[SAG_REC_INTS];
+} OEnv;
+
+typedef struct {
+  real obs[104];
+  real reward[2];
+  int cost, done, goal_met, tape_used;
+  /* diagnostics for parity tests */
+  real qacc[3];
+  real cost_margin; /* smallest |distance to a flag threshold| seen */
+  uint32_t btn_contact_mask;
+} OOut;
+
+int sago_sizeof_env(void) { return (int)sizeof(OEnv); }
+int sago_sizeof_out(void) { return (int)sizeof(OOut); }
+int sago_real_bytes(void) { return (int)sizeof(real); }
+
+void sago_load(OEnv* e, const float* rf, const int32_t* ri) {
+  for (int k = 0; k < SAG_REC_FLOATS; k++) e->f[k] = (real)rf[k];
+  memcpy(e->i, ri, sizeof(e->i));
+}
+void sago_load_f64(OEnv* e, const double* rf, const int32_t* ri) {
+  for (int k = 0; k < SAG_REC_FLOATS; k++) e->f[k] = (real)rf[k];
+  memcpy(e->i, ri, sizeof(e->i));
+}
+void sago_store(const OEnv* e, float* rf, int32_t* ri) {
+  for (int k = 0; k < SAG_REC_FLOATS; k++) rf[k] = (float)e->f[k];
+  memcpy(ri, e->i, sizeof(e->i));
+}
+void sago_store_f64(const OEnv* e, double* rf, int32_t* ri) {
+  for (int k = 0; k < SAG_REC_FLOATS; k++) rf[k] = (double)e->f[k];
+  memcpy(ri, e->i, sizeof(e->i));
+}
+
+/* ------------------------------------------------------------------------ */
+/* random words: tape (parity mode) or Philox4x32-10 (throughput mode)       */
+/* ------------------------------------------------------------------------ */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+void sago_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  memcpy(out, ctr, 16);
+  philox4x32_10(out, key[0], key[1]);
+}
+
+typedef struct {
+  const uint32_t* tape;
+  int len, pos;
+  int exhausted;
+  uint32_t key0, key1, env_id, step;
+} Rng;
+
+/* stream 0: in-step draws (words indexed by pos); stream 1: action noise;
+ * stream 2: synthetic actions (sag_dev_fill_actions). */
+static uint32_t rng_word(Rng* g) {
+  if (g->tape) {
+    if (g->pos >= g->len) { g->exhausted = 1; g->pos++; return 0; }
+    return g->tape[g->pos++];
+  }
+  uint32_t c[4] = {g->env_id, g->step, (uint32_t)(g->pos >> 2), 0u};
+  philox4x32_10(c, g->key0, g->key1);
+  return c[g->pos++ & 3];
+}
+/* numpy legacy random_sample(): 53-bit double from two 32-bit words */
+static double rng_double(Rng* g) {
+  uint32_t a = rng_word(g) >> 5, b = rng_word(g) >> 6;
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+/* rs.uniform(lo, hi) = lo + (hi - lo) * random_sample() */
+static double rng_uniform(Rng* g, double lo, double hi) { return lo + (hi - lo) * rng_double(g); }
+
+/* counter-based standard normals for action noise (throughput mode only; the
+ * reference draws rs.normal(size=nu), safe_adaptation_gym.py:63-65). */
+void sago_noise(uint32_t key0, uint32_t key1, uint32_t env_id, uint32_t step, int nu, float* out) {
+  for (int j = 0; j < nu; j += 2) {
+    uint32_t c[4] = {env_id, step, (uint32_t)(j >> 1), 1u};
+    philox4x32_10(c, key0, key1);
+    float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float r = sqrtf(-2.0f * logf(u1));
+    float a = 6.28318530717958647692f * u2;
+    out[j] = r * cosf(a);
+    if (j + 1 < nu) out[j + 1] = r * sinf(a);
+  }
+}
+/* synthetic policy: U(-1,1) (stream 2) */
+void sago_actions(uint32_t key0, uint32_t key1, uint32_t env_id, uint32_t step, int nu, float* out) {
+  for (int j = 0; j < nu; j += 4) {
+    uint32_t c[4] = {env_id, step, (uint32_t)(j >> 2), 2u};
+    philox4x32_10(c, key0, key1);
+    for (int k = 0; k < 4 && j + k < nu; k++)
+      out[j + k] = ((float)(c[k] >> 8) + 0.5f) * (2.0f / 16777216.0f) - 1.0f;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* lidar: safe_adaptation_gym.py:174-223, fp64 exactly as NumPy evaluates it  */
+/* ------------------------------------------------------------------------ */
+/* Python float % : fmod, then shift into the divisor's sign (npy_divmod). */
+static double py_mod(double a, double b) {
+  double m = fmod(a, b);
+  if (m != 0.0 && ((b < 0) != (m < 0))) m += b;
+  return m;
+}
+
+/* One object into a 16-bin reading. ex, ey = ego_xy (:197-202). Returns bin. */
+static int lidar_accumulate(double ex, double ey, double* obs) {
+  const double two_pi = PI * 2;
+  double dist = hypot(ex, ey);              /* np.abs(complex) :209            */
+  double angle = py_mod(atan2(ey, ex), two_pi); /* np.angle(z) % (2 pi) :210   */
+  double bin_size = two_pi / SAG_LIDAR_BINS;    /* :211                         */
+  int bin = (int)(angle / bin_size);            /* :212                         */
+  /* Reference quirk: angle % 2pi can round to exactly 2pi for a
+   * tiny negative angle -> bin 16 -> IndexError in the reference.  Documented
+   * deviation: wrap to bin 0. */
+  if (bin >= SAG_LIDAR_BINS) bin -= SAG_LIDAR_BINS;
+  double bin_angle = bin_size * bin;            /* :213 */
+  double sensor = (LIDAR_MAX - dist > 0 ? LIDAR_MAX - dist : 0.0) / LIDAR_MAX; /* :214 */
+  if (sensor > obs[bin]) obs[bin] = sensor;     /* :215 */
+  double alias = (angle - bin_angle) / bin_size; /* :216 */
+  int bp = (bin + 1) % SAG_LIDAR_BINS, bm = (bin + SAG_LIDAR_BINS - 1) % SAG_LIDAR_BINS;
+  if (alias * sensor > obs[bp]) obs[bp] = alias * sensor;             /* :221 */
+  if ((1 - alias) * sensor > obs[bm]) obs[bm] = (1 - alias) * sensor; /* :222 */
+  return bin;
+}
+
+/* General form (tilted base: car/doggo): robot_pos[3], row-major robot_mat[9],
+ * pts [n][2]; obs16 zero-initialised here; bins may be NULL.
+ * ego = ([p,0] - robot_pos) @ R  -> first two components (:200-202). */
+void sago_lidar(const double* robot_pos, const double* mat, const double* pts, int n,
+                double* obs16, int* bins) {
+  for (int k = 0; k < SAG_LIDAR_BINS; k++) obs16[k] = 0.0;
+  for (int j = 0; j < n; j++) {
+    double w0 = pts[2 * j] - robot_pos[0], w1 = pts[2 * j + 1] - robot_pos[1],
+           w2 = 0.0 - robot_pos[2];
+    /* np.matmul(world_3vec, robot_mat)[:2]: column k = sum_i w_i * R[i][k] */
+    double ex = w0 * mat[0] + w1 * mat[3] + w2 * mat[6];
+    double ey = w0 * mat[1] + w1 * mat[4] + w2 * mat[7];
+    int b = lidar_accumulate(ex, ey, obs16);
+    if (bins) bins[j] = b;
+  }
+}
+
+/* Planar robot (Point): R = Rz(yaw), so the z term vanishes exactly. */
+static int lidar_planar(double rx, double ry, double c, double s, double px, double py,
+                        double* obs) {
+  double w0 = px - rx, w1 = py - ry;
+  double ex = w0 * c + w1 * s;  /* w0*R[0][0] + w1*R[1][0] */
+  double ey = w0 * -s + w1 * c; /* w0*R[0][1] + w1*R[1][1] */
+  return lidar_accumulate(ex, ey, obs);
+}
+
+/* The stand-alone lidar + hazard-cost path of the C ABI (sag_lidar_cost):
+ * float inputs promoted to double, same arithmetic. */
+void sago_lidar_cost(int K, const float* robot3, const float* points, const uint8_t* group,
+                     float hazard_size, float* lidar48, int32_t* bins, uint8_t* cost) {
+  double obs[48];
+  for (int k = 0; k < 48; k++) obs[k] = 0;
+  double rx = robot3[0], ry = robot3[1], yaw = robot3[2];
+  double c = cos(yaw), s = sin(yaw);
+  int cst = 0;
+  for (int j = 0; j < K; j++) {
+    int g = group[j] & 127;
+    double px = points[2 * j], py = points[2 * j + 1];
+    if (group[j] & 128) { /* world.py:148-153 */
+      double dx = rx - px, dy = ry - py;
+      if (sqrt(dx * dx + dy * dy) <= (double)hazard_size) cst = 1;
+    }
+    int b = -1;
+    /* output order [obstacles, objects, goal] (safe_adaptation_gym.py:136-139) */
+    if (g == 1) b = lidar_planar(rx, ry, c, s, px, py, obs);
+    else if (g == 3) b = lidar_planar(rx, ry, c, s, px, py, obs + 16);
+    else if (g == 2) b = lidar_planar(rx, ry, c, s, px, py, obs + 32);
+    if (bins) bins[j] = b;
+  }
+  for (int k = 0; k < 48; k++) lidar48[k] = (float)obs[k];
+  *cost = (uint8_t)cst;
+}
+
+/* ------------------------------------------------------------------------ */
+/* planar geometry                                                           */
+/* ------------------------------------------------------------------------ */
+typedef struct { int type; real ox, oy, a, b; } Geom; /* type 0 circle (a=r), 1 box (a=hx,b=hy) */
+
+typedef struct {
+  real x, y, yaw, vx, vy, w;   /* state */
+  real ax, ay, aw;             /* accumulated acceleration this substep */
+  real minv[6];                /* symmetric inverse inertia: xx, xy, xw, yy, yw, ww (0 for static) */
+  int ngeom;
+  Geom g[5];
+  int dynamic;
+} Body;
+
+typedef struct { real nx, ny, px, py, depth; } Contact;
+
+static real clampr(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* world centre + rotation of a geom */
+static void geom_world(const Body* b, const Geom* g, real* cx, real* cy, real* c, real* s) {
+  *c = R_COS(b->yaw); *s = R_SIN(b->yaw);
+  *cx = b->x + *c * g->ox - *s * g->oy;
+  *cy = b->y + *s * g->ox + *c * g->oy;
+}
+
+/* Each narrowphase returns contacts with normal pointing from A to B.  Touching
+ * (depth == 0) is not a contact (MuJoCo: dist < margin = 0). */
+static int circle_circle(real ax, real ay, real ra, real bx, real by, real rb, Contact* out) {
+  real dx = bx - ax, dy = by - ay;
+  real d2 = dx * dx + dy * dy, rs = ra + rb;
+  if (d2 >= rs * rs) return 0;
+  real d = R_SQRT(d2);
+  real nx = 1, ny = 0;
+  if (d > (real)1e-12) { nx = dx / d; ny = dy / d; }
+  out->nx = nx; out->ny = ny; out->depth = rs - d;
+  out->px = ax + nx * (ra - (real)0.5 * out->depth);
+  out->py = ay + ny * (ra - (real)0.5 * out->depth);
+  return 1;
+}
+
+/* circle A vs oriented box B (centre bx,by; cos/sin cb,sb; half hx,hy) */
+static int circle_box(real ax, real ay, real ra, real bx, real by, real cb, real sb, real hx,
+                      real hy, Contact* out) {
+  real wx = ax - bx, wy = ay - by;
+  real lx = cb * wx + sb * wy, ly = -sb * wx + cb * wy; /* circle centre in box frame */
+  real qx = clampr(lx, -hx, hx), qy = clampr(ly, -hy, hy);
+  real ddx = lx - qx, ddy = ly - qy;
+  real onx, ony, depth; /* outward normal of the box in its frame */
+  if (ddx == 0 && ddy == 0) { /* centre inside the box */
+    real px = hx - R_FABS(lx), py = hy - R_FABS(ly);
+    if (px < py) { onx = lx >= 0 ? 1 : -1; ony = 0; depth = ra + px; qx = onx * hx; }
+    else { onx = 0; ony = ly >= 0 ? 1 : -1; depth = ra + py; qy = ony * hy; }
+  } else {
+    real d2 = ddx * ddx + ddy * ddy;
+    if (d2 >= ra * ra) return 0;
+    real d = R_SQRT(d2);
+    onx = ddx / d; ony = ddy / d; depth = ra - d;
+  }
+  /* to world; normal from A (circle) to B (box) = -outward */
+  out->nx = -(cb * onx - sb * ony);
+  out->ny = -(sb * onx + cb * ony);
+  out->px = bx + cb * qx - sb * qy;
+  out->py = by + sb * qx + cb * qy;
+  out->depth = depth;
+  return 1;
+}
+
+/* vertices of box P strictly inside box Q -> contacts with the outward normal
+ * of Q's least-penetrated face.  sign = +1 if Q is body A (normal A->B is Q's
+ * outward), -1 if Q is body B. Vertex order (+,+), (-,+), (-,-), (+,-). */
+static int verts_in_box(real pxc, real pyc, real cp, real sp, real phx, real phy, real qxc,
+                        real qyc, real cq, real sq, real qhx, real qhy, real sign, Contact* out) {
+  static const int SX[4] = {1, -1, -1, 1}, SY[4] = {1, 1, -1, -1};
+  int n = 0;
+  for (int k = 0; k < 4; k++) {
+    real vx = pxc + cp * (SX[k] * phx) - sp * (SY[k] * phy);
+    real vy = pyc + sp * (SX[k] * phx) + cp * (SY[k] * phy);
+    real wx = vx - qxc, wy = vy - qyc;
+    real lx = cq * wx + sq * wy, ly = -sq * wx + cq * wy;
+    real dx = qhx - R_FABS(lx), dy = qhy - R_FABS(ly);
+    if (dx <= 0 || dy <= 0) continue;
+    real onx, ony, depth;
+    if (dx < dy) { onx = lx >= 0 ? 1 : -1; ony = 0; depth = dx; }
+    else { onx = 0; ony = ly >= 0 ? 1 : -1; depth = dy; }
+    out[n].nx = sign * (cq * onx - sq * ony);
+    out[n].ny = sign * (sq * onx + cq * ony);
+    out[n].px = vx; out[n].py = vy; out[n].depth = depth;
+    n++;
+  }
+  return n;
+}
+
+static int geom_pair(const Body* A, const Geom* ga, const Body* B, const Geom* gb, Contact* out) {
+  real ax, ay, ca, sa, bx, by, cb, sb;
+  geom_world(A, ga, &ax, &ay, &ca, &sa);
+  geom_world(B, gb, &bx, &by, &cb, &sb);
+  if (ga->type == 0 && gb->type == 0) return circle_circle(ax, ay, ga->a, bx, by, gb->a, out);
+  if (ga->type == 0 && gb->type == 1) return circle_box(ax, ay, ga->a, bx, by, cb, sb, gb->a, gb->b, out);
+  if (ga->type == 1 && gb->type == 0) {
+    int n = circle_box(bx, by, gb->a, ax, ay, ca, sa, ga->a, ga->b, out);
+    if (n) { out->nx = -out->nx; out->ny = -out->ny; }
+    return n;
+  }
+  int n = verts_in_box(ax, ay, ca, sa, ga->a, ga->b, bx, by, cb, sb, gb->a, gb->b, (real)-1, out);
+  n += verts_in_box(bx, by, cb, sb, gb->a, gb->b, ax, ay, ca, sa, ga->a, ga->b, (real)1, out + n);
+  return n;
+}
+
+static real bound_radius(const Body* b) {
+  real r = 0;
+  for (int k = 0; k < b->ngeom; k++) {
+    const Geom* g = &b->g[k];
+    real off = R_SQRT(g->ox * g->ox + g->oy * g->oy);
+    real e = g->type == 0 ? g->a : R_SQRT(g->a * g->a + g->b * g->b);
+    if (off + e > r) r = off + e;
+  }
+  return r;
+}
+
+/* ------------------------------------------------------------------------ */
+/* soft contact (MuJoCo-style reference acceleration, one Gauss-Seidel sweep) */
+/* ------------------------------------------------------------------------ */
+typedef struct { real kcoef, bcoef, h; } Sol;
+
+static Sol make_sol(double h) {
+  double tc = SOL_TC < 2 * h ? 2 * h : SOL_TC; /* refsafe */
+  Sol s;
+  s.bcoef = (real)(2.0 / (SOL_D1 * tc));
+  s.kcoef = (real)(1.0 / (SOL_D1 * SOL_D1 * tc * tc)); /* dampratio 1 */
+  s.h = (real)h;
+  return s;
+}
+
+static real impedance(real depth) {
+  real x = depth / (real)SOL_WIDTH;
+  if (x > 1) x = 1;
+  real y = x < (real)0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x); /* power 2, midpoint .5 */
+  return (real)SOL_D0 + ((real)SOL_D1 - (real)SOL_D0) * y;
+}
+
+/* u = Minv * J^T for J = [dx, dy, r x d]; returns J u */
+static real minv_apply(const Body* b, real dx, real dy, real rxd, real u[3]) {
+  const real* m = b->minv;
+  u[0] = m[0] * dx + m[1] * dy + m[2] * rxd;
+  u[1] = m[1] * dx + m[3] * dy + m[4] * rxd;
+  u[2] = m[2] * dx + m[4] * dy + m[5] * rxd;
+  return dx * u[0] + dy * u[1] + rxd * u[2];
+}
+
+static void rel_at(const Body* A, const Body* B, real rax, real ray, real rbx, real rby,
+                   real* vx, real* vy, real* ax, real* ay) {
+  /* point velocity v + w x r, point acceleration a + alpha x r (centripetal
+   * term omitted by specification) */
+  *vx = (B->vx - B->w * rby) - (A->vx - A->w * ray);
+  *vy = (B->vy + B->w * rbx) - (A->vy + A->w * rax);
+  *ax = (B->ax - B->aw * rby) - (A->ax - A->aw * ray);
+  *ay = (B->ay + B->aw * rbx) - (A->ay + A->aw * rax);
+}
+
+static void apply_dir(Body* A, Body* B, real dx, real dy, real rax, real ray, real rbx,
+                      real rby, real f, const real ua[3], const real ub[3]) {
+  (void)dx; (void)dy; (void)rax; (void)ray; (void)rbx; (void)rby;
+  if (A->dynamic) { A->ax -= ua[0] * f; A->ay -= ua[1] * f; A->aw -= ua[2] * f; }
+  if (B->dynamic) { B->ax += ub[0] * f; B->ay += ub[1] * f; B->aw += ub[2] * f; }
+}
+
+static void solve_contact(Body* A, Body* B, const Contact* c, const Sol* sol) {
+  real rax = c->px - A->x, ray = c->py - A->y, rbx = c->px - B->x, rby = c->py - B->y;
+  real nx = c->nx, ny = c->ny;
+  real vx, vy, ax, ay;
+  real ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
+  /* normal */
+  rel_at(A, B, rax, ray, rbx, rby, &vx, &vy, &ax, &ay);
+  real vn = vx * nx + vy * ny, an = ax * nx + ay * ny;
+  real An = 0;
+  if (A->dynamic) An += minv_apply(A, nx, ny, rax * ny - ray * nx, ua);
+  if (B->dynamic) An += minv_apply(B, nx, ny, rbx * ny - rby * nx, ub);
+  if (An <= 0) return;
+  real d = impedance(c->depth);
+  /* separating acceleration wanted: aref = -b*vn + k*depth (vn<0 approaching) */
+  real aref = -sol->bcoef * vn + sol->kcoef * c->depth;
+  real fn = d * (aref - an) / An;
+  if (fn <= 0) return;
+  apply_dir(A, B, nx, ny, rax, ray, rbx, rby, fn, ua, ub);
+  /* friction along t = (-ny, nx), regularised Coulomb */
+  real tx = -ny, ty = nx;
+  rel_at(A, B, rax, ray, rbx, rby, &vx, &vy, &ax, &ay);
+  real vt = vx * tx + vy * ty, at = ax * tx + ay * ty;
+  real At = 0;
+  if (A->dynamic) At += minv_apply(A, tx, ty, rax * ty - ray * tx, ua);
+  if (B->dynamic) At += minv_apply(B, tx, ty, rbx * ty - rby * tx, ub);
+  if (At <= 0) return;
+  real ft = d * (-sol->bcoef * vt - at) / At;
+  ft = clampr(ft, -(real)FRICTION_MU * fn, (real)FRICTION_MU * fn);
+  apply_dir(A, B, tx, ty, rax, ray, rbx, rby, ft, ua, ub);
+}
+
+/* all contacts of one body pair; returns number of contacts (penetrations) */
+static int collide_pair(Body* A, Body* B, real ra, real rb, const Sol* sol, int solve) {
+  real dx = B->x - A->x, dy = B->y - A->y, rs = ra + rb;
+  if (dx * dx + dy * dy > rs * rs) return 0; /* broadphase */
+  int total = 0;
+  Contact c[8];
+  for (int i = 0; i < A->ngeom; i++)
+    for (int j = 0; j < B->ngeom; j++) {
+      int n = geom_pair(A, &A->g[i], B, &B->g[j], c);
+      total += n;
+      if (solve)
+        for (int k = 0; k < n; k++) solve_contact(A, B, &c[k], sol);
+    }
+  return total;
+}
+
+/* floor friction of a free body resting on the plane (condim-6 floor contact
+ * reduced to translation + torsion about the vertical, decoupled):
+ *   f = clamp_norm(-d0 m (b v + a), mu m g),  tau = clamp(-d0 I (b w + alpha), mu m g r_eff) */
+static void floor_friction(Body* b, real mass, real inertia, real reff, const Sol* sol) {
+  real d0 = (real)SOL_D0;
+  real fx = -d0 * mass * (sol->bcoef * b->vx + b->ax);
+  real fy = -d0 * mass * (sol->bcoef * b->vy + b->ay);
+  real fmax = (real)(FRICTION_MU * GRAVITY) * mass;
+  real fn2 = fx * fx + fy * fy;
+  if (fn2 > fmax * fmax) { real sc = fmax / R_SQRT(fn2); fx *= sc; fy *= sc; }
+  b->ax += fx / mass; b->ay += fy / mass;
+  real t = -d0 * inertia * (sol->bcoef * b->w + b->aw);
+  t = clampr(t, -fmax * reff, fmax * reff);
+  b->aw += t / inertia;
+}
+
+/* ------------------------------------------------------------------------ */
+/* world assembly from the record                                            */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  Body robot, vase[SAG_MAX_VASES], pillar[SAG_MAX_PILLARS], button[SAG_MAX_BUTTONS];
+  real r_robot, r_vase, r_pillar, r_button;
+  real vase_m, vase_I, vase_reff;
+  int nV, nP, nB;
+} World;
+
+static void body_static_circle(Body* b, real x, real y, real r) {
+  memset(b, 0, sizeof(*b));
+  b->x = x; b->y = y; b->ngeom = 1; b->g[0].type = 0; b->g[0].a = r; b->dynamic = 0;
+}
+
+static void point_minv(Body* b, real damp, real h) {
+  /* (M + h D)^-1 for M(yaw) of the Point robot about the body origin */
+  real c = R_COS(b->yaw), s = R_SIN(b->yaw);
+  real m = (real)PT_MASS + h * damp, I = (real)PT_IO + h * (real)PT_DAMP_Z;
+  real a = -(real)PT_MC * s, bb = (real)PT_MC * c;
+  /* M = [[m,0,a],[0,m,bb],[a,bb,I]] ; det = m (m I - a^2 - bb^2) */
+  real det = m * (m * I - a * a - bb * bb);
+  real id = 1 / det;
+  b->minv[0] = (m * I - bb * bb) * id; /* xx */
+  b->minv[1] = (a * bb) * id;          /* xy */
+  b->minv[2] = (-a * m) * id;          /* xw */
+  b->minv[3] = (m * I - a * a) * id;   /* yy */
+  b->minv[4] = (-bb * m) * id;         /* yw */
+  b->minv[5] = (m * m) * id;           /* ww */
+}
+
+static void world_from_env(const OEnv* e, World* w) {
+  memset(w, 0, sizeof(*w));
+  const real* f = e->f;
+  Body* r = &w->robot;
+  r->x = f[SAG_F_ROBOT]; r->y = f[SAG_F_ROBOT + 1]; r->yaw = f[SAG_F_ROBOT + 2];
+  r->vx = f[SAG_F_ROBOT + 3]; r->vy = f[SAG_F_ROBOT + 4]; r->w = f[SAG_F_ROBOT + 5];
+  r->dynamic = 1; r->ngeom = 2;
+  r->g[0].type = 0; r->g[0].a = (real)0.1;                       /* point.xml:18 */
+  r->g[1].type = 1; r->g[1].ox = (real)0.1; r->g[1].a = (real)0.05; r->g[1].b = (real)0.05; /* :19 */
+  w->r_robot = bound_radius(r);
+  w->nV = e->i[SAG_I_NV]; w->nP = e->i[SAG_I_NP]; w->nB = e->i[SAG_I_NB];
+  real vs = f[SAG_F_VASE_SIZE];
+  for (int k = 0; k < w->nV; k++) {
+    Body* b = &w->vase[k];
+    const real* v = f + SAG_F_VASES + 6 * k;
+    b->x = v[0]; b->y = v[1]; b->yaw = v[2]; b->vx = v[3]; b->vy = v[4]; b->w = v[5];
+    b->dynamic = 1; b->ngeom = 1; b->g[0].type = 1; b->g[0].a = vs; b->g[0].b = vs;
+  }
+  /* vase mass properties: box of half extent vs, density .001 */
+  w->vase_m = (real)VASE_DENSITY * 8 * vs * vs * vs;
+  w->vase_I = w->vase_m * (4 * vs * vs + 4 * vs * vs) / 12;
+  w->vase_reff = vs * (real)1.41421356237309504880;
+  for (int k = 0; k < w->nV; k++) {
+    Body* b = &w->vase[k];
+    b->minv[0] = 1 / w->vase_m; b->minv[3] = 1 / w->vase_m; b->minv[5] = 1 / w->vase_I;
+  }
+  w->r_vase = vs * (real)1.41421356237309504880;
+  for (int k = 0; k < w->nP; k++)
+    body_static_circle(&w->pillar[k], f[SAG_F_PILLARS + 2 * k], f[SAG_F_PILLARS + 2 * k + 1],
+                       f[SAG_F_PILLAR_SIZE]);
+  w->r_pillar = f[SAG_F_PILLAR_SIZE];
+  for (int k = 0; k < w->nB; k++)
+    body_static_circle(&w->button[k], f[SAG_F_BUTTONS + 2 * k], f[SAG_F_BUTTONS + 2 * k + 1],
+                       (real)BUTTON_R);
+  w->r_button = (real)BUTTON_R;
+}
+
+static void world_to_env(const World* w, OEnv* e) {
+  real* f = e->f;
+  const Body* r = &w->robot;
+  f[SAG_F_ROBOT] = r->x; f[SAG_F_ROBOT + 1] = r->y; f[SAG_F_ROBOT + 2] = r->yaw;
+  f[SAG_F_ROBOT + 3] = r->vx; f[SAG_F_ROBOT + 4] = r->vy; f[SAG_F_ROBOT + 5] = r->w;
+  for (int k = 0; k < w->nV; k++) {
+    const Body* b = &w->vase[k];
+    real* v = f + SAG_F_VASES + 6 * k;
+    v[0] = b->x; v[1] = b->y; v[2] = b->yaw; v[3] = b->vx; v[4] = b->vy; v[5] = b->w;
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Point robot forward dynamics (point.xml)                  */
+/* ------------------------------------------------------------------------ */
+/* ctrl: already noised + clipped to ctrlrange (safe_adaptation_gym.py:63-67).
+ * Generalised coordinates (x, y, yaw) of the body origin in the world frame:
+ * slide x, slide y precede the hinge, so their axes stay fixed (rotated by the
+ * constant rot0), and isotropic damping makes the world frame equivalent.
+ *   M(q) qacc + bias = tau_act - D qvel + J^T f_contact, integrated with MuJoCo's
+ *   Euler: damping implicit ((M + h D) qacc = ...), velocity then position. */
+static void point_smooth(Body* r, const real ctrl[2], real gear, real damp, real h) {
+  real c = R_COS(r->yaw), s = R_SIN(r->yaw);
+  /* motor on site "robot": force gear*clip(ctrl, forcerange) along body +x (point.xml:36) */
+  real f0 = gear * clampr(ctrl[0], -(real)PT_FORCE_LIM, (real)PT_FORCE_LIM);
+  /* velocity servo on hinge z: kv (ctrl - gear*w), clipped, times gear (point.xml:37) */
+  real f1 = (real)PT_GEAR_Z *
+            clampr((real)PT_KV * (ctrl[1] - (real)PT_GEAR_Z * r->w), -(real)PT_FORCE_LIM,
+                   (real)PT_FORCE_LIM);
+  /* tau - bias - D v;  bias = (-mc c w^2, -mc s w^2, 0) */
+  real Fx = f0 * c - damp * r->vx + (real)PT_MC * c * r->w * r->w;
+  real Fy = f0 * s - damp * r->vy + (real)PT_MC * s * r->w * r->w;
+  real Tz = f1 - (real)PT_DAMP_Z * r->w;
+  point_minv(r, damp, h);
+  const real* m = r->minv;
+  r->ax = m[0] * Fx + m[1] * Fy + m[2] * Tz;
+  r->ay = m[1] * Fx + m[3] * Fy + m[4] * Tz;
+  r->aw = m[2] * Fx + m[4] * Fy + m[5] * Tz;
+}
+
+/* One forward-dynamics evaluation: accelerations of every body at the current
+ * state.  Fixed pair order (specification):
+ *   robot-pillars, robot-buttons, robot-vases, vase-pillars, vase-buttons,
+ *   vase-vase (i<j), then floor friction of each vase.
+ * Returns robot/obstacle penetration count (cost rule, mujoco_bridge.py:177-191
+ * with prefixes consts.OBSTACLES) and the button contact mask. */
+static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol* sol,
+                         uint32_t* btn_mask) {
+  point_smooth(&w->robot, ctrl, e->f[SAG_F_GEAR], e->f[SAG_F_DAMP], sol->h);
+  for (int k = 0; k < w->nV; k++) { w->vase[k].ax = w->vase[k].ay = w->vase[k].aw = 0; }
+  int cost_contacts = 0;
+  uint32_t mask = 0;
+  for (int p = 0; p < w->nP; p++)
+    cost_contacts += collide_pair(&w->robot, &w->pillar[p], w->r_robot, w->r_pillar, sol, 1);
+  for (int b = 0; b < w->nB; b++)
+    if (collide_pair(&w->robot, &w->button[b], w->r_robot, w->r_button, sol, 1)) mask |= 1u << b;
+  for (int k = 0; k < w->nV; k++)
+    cost_contacts += collide_pair(&w->robot, &w->vase[k], w->r_robot, w->r_vase, sol, 1);
+  for (int k = 0; k < w->nV; k++) {
+    for (int p = 0; p < w->nP; p++)
+      collide_pair(&w->vase[k], &w->pillar[p], w->r_vase, w->r_pillar, sol, 1);
+    for (int b = 0; b < w->nB; b++)
+      collide_pair(&w->vase[k], &w->button[b], w->r_vase, w->r_button, sol, 1);
+  }
+  for (int i = 0; i < w->nV; i++)
+    for (int j = i + 1; j < w->nV; j++)
+      collide_pair(&w->vase[i], &w->vase[j], w->r_vase, w->r_vase, sol, 1);
+  for (int k = 0; k < w->nV; k++) floor_friction(&w->vase[k], w->vase_m, w->vase_I, w->vase_reff, sol);
+  if (btn_mask) *btn_mask = mask;
+  return cost_contacts;
+}
+
+static void integrate(Body* b, real h) {
+  b->vx += h * b->ax; b->vy += h * b->ay; b->w += h * b->aw;
+  b->x += h * b->vx; b->y += h * b->vy; b->yaw += h * b->w;
+}
+
+/* nstep x mj_step (safe_adaptation_gym.py:72) */
+void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) {
+  World w;
+  world_from_env(e, &w);
+  Sol sol = make_sol(h);
+  for (int s = 0; s < nstep; s++) {
+    world_forward(&w, e, ctrl, &sol, NULL);
+    integrate(&w.robot, sol.h);
+    for (int k = 0; k < w.nV; k++) integrate(&w.vase[k], sol.h);
+  }
+  world_to_env(&w, e);
+}
+
+/* ------------------------------------------------------------------------ */
+/* goal resampling: tasks/go_to_goal.py:59-80 + utils.py:22-70                */
+/* ------------------------------------------------------------------------ */
+static real kind_keepout(const OEnv* e, int which) { return e->f[SAG_F_KEEPOUT + which]; }
+
+/* returns 1 and writes goal if a valid placement was drawn */
+static int resample_goal(OEnv* e, Rng* g) {
+  const real* f = e->f;
+  double xmin = -GOAL_RECT, ymin = -GOAL_RECT, xmax = GOAL_RECT, ymax = GOAL_RECT;
+  int nH = e->i[SAG_I_NH], nV = e->i[SAG_I_NV], nP = e->i[SAG_I_NP], nB = e->i[SAG_I_NB];
+  for (int t = 0; t < MAX_RESAMPLE_TRIES; t++) {
+    /* utils.draw_placement: constrain by keepout, then two uniforms (:51-70) */
+    double cx0 = xmin + GOAL_KEEPOUT, cy0 = ymin + GOAL_KEEPOUT, cx1 = xmax - GOAL_KEEPOUT,
+           cy1 = ymax - GOAL_KEEPOUT;
+    double gx = rng_uniform(g, cx0, cx1);
+    double gy = rng_uniform(g, cy0, cy1);
+    if (g->exhausted) return 0;
+    int ok = 1;
+    /* every other layout entry, dist < keepout_other + GOAL_KEEPOUT rejects (:68-73) */
+#define CHECK(px, py, ko)                                                  \
+  do {                                                                     \
+    double ddx = gx - (double)(px), ddy = gy - (double)(py);               \
+    if (sqrt(ddx * ddx + ddy * ddy) < (double)(ko) + GOAL_KEEPOUT) ok = 0; \
+  } while (0)
+    CHECK(f[SAG_F_ROBOT], f[SAG_F_ROBOT + 1], kind_keepout(e, 0));
+    for (int k = 0; k < nH && ok; k++) CHECK(f[SAG_F_HAZARDS + 2 * k], f[SAG_F_HAZARDS + 2 * k + 1], kind_keepout(e, 1));
+    for (int k = 0; k < nV && ok; k++) CHECK(f[SAG_F_VASES + 6 * k], f[SAG_F_VASES + 6 * k + 1], kind_keepout(e, 2));
+    for (int k = 0; k < nP && ok; k++) CHECK(f[SAG_F_PILLARS + 2 * k], f[SAG_F_PILLARS + 2 * k + 1], kind_keepout(e, 3));
+    if (e->i[SAG_I_BOX_KIND] != SAG_BOX_NONE && ok) CHECK(f[SAG_F_BOX], f[SAG_F_BOX + 1], kind_keepout(e, 4));
+    (void)nB; /* no task has both a goal body and buttons */
+#undef CHECK
+    if (ok) {
+      e->f[SAG_F_GOAL] = (real)gx;
+      e->f[SAG_F_GOAL + 1] = (real)gy;
+      return 1;
+    }
+    /* every rejected draw enlarges the rectangle by 1 % (:76-79, utils.py:118-119) */
+    xmin *= 1.01; ymin *= 1.01; xmax *= 1.01; ymax *= 1.01;
+  }
+  return 0;
+}
+
+static double dist2d(double ax, double ay, double bx, double by) {
+  double dx = ax - bx, dy = ay - by;
+  return sqrt(dx * dx + dy * dy);
+}
+static double dist3d(double ax, double ay, double az, double bx, double by, double bz) {
+  double dx = ax - bx, dy = ay - by, dz = az - bz;
+  return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+/* GoToGoal.reset (tasks/go_to_goal.py:50-57): resample, last <- 2-D distance */
+static void goal_reset(OEnv* e, Rng* g) {
+  if (!resample_goal(e, g)) e->i[SAG_I_FLAGS] |= g->exhausted ? 2 : 1;
+  e->f[SAG_F_LAST] = (real)dist2d(e->f[SAG_F_ROBOT], e->f[SAG_F_ROBOT + 1], e->f[SAG_F_GOAL],
+                                  e->f[SAG_F_GOAL + 1]);
+}
+
+/* PressButtons._sample_goal_button (tasks/press_buttons.py:71-77) */
+static void sample_goal_button(OEnv* e, Rng* g) {
+  /* legacy rs.choice(4) -> randint(0,4): masked rejection on a 32-bit word, mask 3 */
+  int b = (int)(rng_word(g) & 3u);
+  if (g->exhausted) { e->i[SAG_I_FLAGS] |= 2; return; }
+  e->i[SAG_I_GOAL_BUTTON] = b;
+  e->i[SAG_I_BTN_TIMER] = 5; /* BUTTON_TICKING_DELAY */
+  e->f[SAG_F_LAST] = (real)dist2d(e->f[SAG_F_ROBOT], e->f[SAG_F_ROBOT + 1],
+                                  e->f[SAG_F_BUTTONS + 2 * b], e->f[SAG_F_BUTTONS + 2 * b + 1]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* CatchGoal.set_mocaps (tasks/catch_goal.py:20-31), before physics           */
+/* ------------------------------------------------------------------------ */
+static void catch_goal_mocap(OEnv* e, Rng* g, double time) {
+  int t = e->i[SAG_I_CATCH_TIMER];
+  t = t - 1 > 0 ? t - 1 : 0; /* Timer.tick */
+  if (t == 0) {
+    e->f[SAG_F_CATCH + 2] = e->f[SAG_F_CATCH + 3];
+    e->f[SAG_F_CATCH + 3] = (real)rng_uniform(g, 0.2, 1.0);
+    if (g->exhausted) e->i[SAG_I_FLAGS] |= 2;
+    t = 10; /* SAMPLE_POINTS */
+  }
+  e->i[SAG_I_CATCH_TIMER] = t;
+  double progress = (10 - t) / 10.0;
+  double cur = e->f[SAG_F_CATCH + 2], nxt = e->f[SAG_F_CATCH + 3];
+  double radius = progress * (nxt - cur) + cur;
+  e->f[SAG_F_GOAL] = (real)(e->f[SAG_F_CATCH] + sin(time) * radius);
+  e->f[SAG_F_GOAL + 1] = (real)(e->f[SAG_F_CATCH + 1] + cos(time) * radius);
+}
+
+/* ------------------------------------------------------------------------ */
+/* per-task reward (tasks/*.py compute_reward)                                */
+/* ------------------------------------------------------------------------ */
+static void task_reward(OEnv* e, Rng* g, uint32_t btn_mask, OOut* out) {
+  real* f = e->f;
+  int task = e->i[SAG_I_TASK];
+  double rx = f[SAG_F_ROBOT], ry = f[SAG_F_ROBOT + 1];
+  out->reward[0] = out->reward[1] = 0;
+  out->goal_met = 0;
+  switch (task) {
+    case SAG_TASK_GO_TO_GOAL:
+    case SAG_TASK_GO_TO_GOAL_DAMPING:
+    case SAG_TASK_GO_TO_GOAL_MOTOR:
+    case SAG_TASK_CATCH_GOAL:
+    case SAG_TASK_GO_TO_GOAL_SCARCE:
+    case SAG_TASK_UNSUPERVISED: {
+      /* tasks/go_to_goal.py:31-45: 3-D distance robot xpos - goal xpos */
+      double dist = dist3d(rx, ry, PT_Z, f[SAG_F_GOAL], f[SAG_F_GOAL + 1], GOAL_Z);
+      double r = (double)f[SAG_F_LAST] - dist;
+      if (task == SAG_TASK_GO_TO_GOAL_SCARCE) /* go_to_goal_scarce.py:26-32: indicator(0<=d<=.45) */
+        r *= (0 <= dist && dist <= GOAL_SIZE * 1.5) ? 1.0 : 0.0;
+      f[SAG_F_LAST] = (real)dist;
+      if (dist <= GOAL_SIZE) {
+        out->goal_met = 1;
+        goal_reset(e, g); /* update_layout is implicit: the record holds current poses */
+        if (task == SAG_TASK_CATCH_GOAL) { /* catch_goal.py:36-40: origin <- new goal */
+          f[SAG_F_CATCH] = f[SAG_F_GOAL];
+          f[SAG_F_CATCH + 1] = f[SAG_F_GOAL + 1];
+        }
+        r += 1.0;
+      }
+      if (task == SAG_TASK_UNSUPERVISED) { /* tasks/unsupervised.py:48-67 */
+        double c = cos((double)f[SAG_F_ROBOT + 2]), s = sin((double)f[SAG_F_ROBOT + 2]);
+        double off = PT_MC / PT_MASS; /* subtree COM offset along local +x */
+        double x = rx + c * off, y = ry + s * off;
+        double w = f[SAG_F_ROBOT + 5];
+        double u = f[SAG_F_ROBOT + 3] - w * (s * off), v = f[SAG_F_ROBOT + 4] + w * (c * off);
+        double radius = sqrt(x * x + y * y);
+        out->reward[0] = (real)((((-u * y + v * x) / radius) / (1 + fabs(radius - 1.5))) * 1e-1);
+        out->reward[1] = (real)r;
+      } else {
+        out->reward[0] = (real)r;
+      }
+      break;
+    }
+    case SAG_TASK_PRESS_BUTTONS:
+    case SAG_TASK_PRESS_BUTTONS_SCARCE: {
+      /* tasks/press_buttons.py:42-64, press_buttons_scarce.py:22-55 */
+      int gb = e->i[SAG_I_GOAL_BUTTON];
+      double gd = dist2d(rx, ry, f[SAG_F_BUTTONS + 2 * gb], f[SAG_F_BUTTONS + 2 * gb + 1]);
+      double r = task == SAG_TASK_PRESS_BUTTONS ? (double)f[SAG_F_LAST] - gd : 0.0;
+      f[SAG_F_LAST] = (real)gd;
+      if (btn_mask & (1u << gb)) {
+        r += 1.0;
+        out->goal_met = 1;
+        sample_goal_button(e, g);
+        e->i[SAG_I_BTN_STATE] = 0; /* BUTTON_CHANGE */
+      }
+      /* (scarce: the wrong-button branch tests names that never match - App. C) */
+      if (e->i[SAG_I_BTN_STATE] == 0) {
+        if (e->i[SAG_I_BTN_TIMER] != 0) e->i[SAG_I_BTN_TIMER] -= 1; /* tick */
+        else { e->i[SAG_I_BTN_STATE] = 1; e->i[SAG_I_BTN_TIMER] = 5; }
+      }
+      out->reward[0] = (real)r;
+      break;
+    }
+    case SAG_TASK_COLLECT: {
+      /* tasks/collect.py:24-47 */
+      int nB = e->i[SAG_I_NB];
+      if (e->i[SAG_I_ACTIVE_MASK] == 0) e->i[SAG_I_ACTIVE_MASK] = (1 << nB) - 1; /* reset */
+      double r = 0;
+      /* the reference iterates a Python set of names; which touched button is taken
+       * first when two are touched in one step is hash-order dependent.  Specified
+       * here as lowest index first. */
+      for (int b = 0; b < nB; b++)
+        if ((e->i[SAG_I_ACTIVE_MASK] >> b & 1) && (btn_mask >> b & 1)) {
+          r += 1.0;
+          out->goal_met = 1;
+          e->i[SAG_I_ACTIVE_MASK] &= ~(1 << b);
+          break;
+        }
+      out->reward[0] = (real)r;
+      break;
+    }
+    default:
+      break; /* box tasks: not in this build of the oracle */
+  }
+}
+
+/* lidar group of button b after the task's _update_goal_button / collect logic
+ * (press_buttons.py:78-91, collect.py:35-36,43-46) */
+static int button_group(const OEnv* e, int b) {
+  int task = e->i[SAG_I_TASK];
+  if (task == SAG_TASK_COLLECT) return (e->i[SAG_I_ACTIVE_MASK] >> b & 1) ? 2 : 0;
+  if (e->i[SAG_I_BTN_STATE] == 0) return 0;
+  return b == e->i[SAG_I_GOAL_BUTTON] ? 2 : 3;
+}
+
+static int has_goal_body(int task) {
+  return !(task == SAG_TASK_PRESS_BUTTONS || task == SAG_TASK_PRESS_BUTTONS_SCARCE ||
+           task == SAG_TASK_COLLECT);
+}
+
+/* ------------------------------------------------------------------------ */
+/* observation: safe_adaptation_gym.py:120-139,225-237 (Point: 48 + 12)       */
+/* ------------------------------------------------------------------------ */
+static void observe(const OEnv* e, const real qacc[3], real* obs) {
+  const real* f = e->f;
+  double lid[48];
+  for (int k = 0; k < 48; k++) lid[k] = 0;
+  double rx = f[SAG_F_ROBOT], ry = f[SAG_F_ROBOT + 1], yaw = f[SAG_F_ROBOT + 2];
+  double c = cos(yaw), s = sin(yaw);
+  int nH = e->i[SAG_I_NH], nV = e->i[SAG_I_NV], nP = e->i[SAG_I_NP], nB = e->i[SAG_I_NB];
+  for (int k = 0; k < nH; k++) lidar_planar(rx, ry, c, s, f[SAG_F_HAZARDS + 2 * k], f[SAG_F_HAZARDS + 2 * k + 1], lid);
+  for (int k = 0; k < nV; k++) lidar_planar(rx, ry, c, s, f[SAG_F_VASES + 6 * k], f[SAG_F_VASES + 6 * k + 1], lid);
+  for (int k = 0; k < nP; k++) lidar_planar(rx, ry, c, s, f[SAG_F_PILLARS + 2 * k], f[SAG_F_PILLARS + 2 * k + 1], lid);
+  if (e->i[SAG_I_BOX_KIND] != SAG_BOX_NONE) lidar_planar(rx, ry, c, s, f[SAG_F_BOX], f[SAG_F_BOX + 1], lid + 16);
+  for (int b = 0; b < nB; b++) {
+    int g = button_group(e, b);
+    if (g == 3) lidar_planar(rx, ry, c, s, f[SAG_F_BUTTONS + 2 * b], f[SAG_F_BUTTONS + 2 * b + 1], lid + 16);
+    if (g == 2) lidar_planar(rx, ry, c, s, f[SAG_F_BUTTONS + 2 * b], f[SAG_F_BUTTONS + 2 * b + 1], lid + 32);
+  }
+  if (has_goal_body(e->i[SAG_I_TASK])) lidar_planar(rx, ry, c, s, f[SAG_F_GOAL], f[SAG_F_GOAL + 1], lid + 32);
+  for (int k = 0; k < 48; k++) obs[k] = (real)lid[k];
+  /* sensors (point.xml:23-28) in the site frame = body frame, R = Rz(yaw):
+   * accelerometer = R^T (a_origin - g), velocimeter = R^T v, gyro = (0,0,w),
+   * magnetometer = R^T (0,-0.5,0). */
+  double ax = qacc[0], ay = qacc[1];
+  obs[48] = (real)(c * ax + s * ay);
+  obs[49] = (real)(-s * ax + c * ay);
+  obs[50] = (real)GRAVITY;
+  double vx = f[SAG_F_ROBOT + 3], vy = f[SAG_F_ROBOT + 4];
+  obs[51] = (real)(c * vx + s * vy);
+  obs[52] = (real)(-s * vx + c * vy);
+  obs[53] = 0;
+  obs[54] = 0; obs[55] = 0; obs[56] = f[SAG_F_ROBOT + 5];
+  obs[57] = (real)(-0.5 * s);
+  obs[58] = (real)(-0.5 * c);
+  obs[59] = 0;
+}
+
+/* hazard part of World.compute_cost (world.py:147-153), fp64 on the stored poses */
+static int hazard_cost(const OEnv* e, double* margin) {
+  const real* f = e->f;
+  int n = 0;
+  double hs = f[SAG_F_HAZARD_SIZE];
+  for (int k = 0; k < e->i[SAG_I_NH]; k++) {
+    double d = dist2d(f[SAG_F_ROBOT], f[SAG_F_ROBOT + 1], f[SAG_F_HAZARDS + 2 * k], f[SAG_F_HAZARDS + 2 * k + 1]);
+    if (d <= hs) n++;
+    if (fabs(d - hs) < *margin) *margin = fabs(d - hs);
+  }
+  return n;
+}
+
+static int state_bad(const OEnv* e) {
+  for (int k = 0; k < 6; k++) {
+    real v = e->f[SAG_F_ROBOT + k];
+    if (!(v == v) || R_FABS(v) > (real)1e10) return 1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* SafeAdaptationGym.step (safe_adaptation_gym.py:56-83)                      */
+/* ------------------------------------------------------------------------ */
+/* action[nu]; noise[nu] standard normals or NULL (-> Philox stream 1);
+ * tape or NULL (-> Philox stream 0); nstep<0 -> table; ext_contacts >= 0
+ * overrides the geometric contact results (golden episodes script contacts):
+ * ext_cost_contacts = robot/obstacle contact count, ext_btn_mask = touched buttons. */
+void sago_step(OEnv* e, int robot, const float* action, const float* noise, const uint32_t* tape,
+               int tape_len, uint32_t key0, uint32_t key1, int nstep, int ext_cost_contacts,
+               uint32_t ext_btn_mask, OOut* out) {
+  int nu = NU[robot];
+  double h = DT[robot];
+  if (nstep < 0) nstep = NSTEP[robot];
+  Rng g = {tape, tape_len, 0, 0, key0, key1, (uint32_t)e->i[SAG_I_ENV_ID], (uint32_t)e->i[SAG_I_STEP]};
+  float nz[SAG_MAX_NU];
+  if (!noise) { sago_noise(key0, key1, g.env_id, g.step, nu, nz); noise = nz; }
+  real ctrl[SAG_MAX_NU];
+  for (int j = 0; j < nu; j++) {
+    /* action + action_noise * normal, clipped to ctrlrange * scale (:63-67, mujoco_bridge.py:164-166) */
+    real a = (real)action[j] + e->f[SAG_F_ACTION_NOISE] * (real)noise[j];
+    real lim = e->f[SAG_F_CTRL_SCALE + j];
+    ctrl[j] = clampr(a, -lim, lim);
+  }
+  memset(out, 0, sizeof(*out));
+  out->cost_margin = 1e30;
+  /* World.set_mocaps (:71): only CatchGoal acts; uses time BEFORE the step */
+  double time = (double)e->i[SAG_I_STEP] * NSTEP[robot] * h;
+  if (e->i[SAG_I_TASK] == SAG_TASK_CATCH_GOAL) catch_goal_mocap(e, &g, time);
+  sago_substeps(e, ctrl, nstep, h);
+  e->i[SAG_I_STEP] += 1;
+  if (state_bad(e)) { /* PhysicsError branch (:73-75) */
+    real z[3] = {0, 0, 0};
+    observe(e, z, out->obs);
+    out->reward[0] = -10; out->done = 1; out->cost = 0;
+    out->tape_used = g.pos;
+    return;
+  }
+  /* mj_forward at the final state (:76): contacts + qacc */
+  World w;
+  world_from_env(e, &w);
+  Sol sol = make_sol(h);
+  uint32_t mask = 0;
+  int cc = world_forward(&w, e, ctrl, &sol, &mask);
+  if (ext_cost_contacts >= 0) { cc = ext_cost_contacts; mask = ext_btn_mask; }
+  out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
+  out->btn_contact_mask = mask;
+  task_reward(e, &g, mask, out);                /* :77 */
+  double margin = 1e30;
+  int cost = cc + hazard_cost(e, &margin);      /* :78, world.py:144-155 */
+  out->cost = cost > 0;
+  out->cost_margin = (real)margin;
+  observe(e, out->qacc, out->obs);              /* :80 */
+  out->tape_used = g.pos;
+}
+
+/* observation after reset (safe_adaptation_gym.py:104,107): forward + observe, ctrl = 0 */
+void sago_observe(OEnv* e, int robot, OOut* out) {
+  memset(out, 0, sizeof(*out));
+  World w;
+  world_from_env(e, &w);
+  Sol sol = make_sol(DT[robot]);
+  real ctrl[SAG_MAX_NU] = {0};
+  world_forward(&w, e, ctrl, &sol, &out->btn_contact_mask);
+  out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
+  observe(e, out->qacc, out->obs);
+}
+
+/* task.reset as run by World.reset right after rebuild (world.py:167-170):
+ * installs the `last` distances from the positions in the record.  (The goal
+ * resample / button choice of reset is drawn host-side, App. B.5.) */
+void sago_task_reset(OEnv* e) {
+  real* f = e->f;
+  int task = e->i[SAG_I_TASK];
+  if (has_goal_body(task))
+    f[SAG_F_LAST] = (real)dist2d(f[SAG_F_ROBOT], f[SAG_F_ROBOT + 1], f[SAG_F_GOAL], f[SAG_F_GOAL + 1]);
+  else if (task != SAG_TASK_COLLECT) {
+    int b = e->i[SAG_I_GOAL_BUTTON];
+    f[SAG_F_LAST] = (real)dist2d(f[SAG_F_ROBOT], f[SAG_F_ROBOT + 1], f[SAG_F_BUTTONS + 2 * b], f[SAG_F_BUTTONS + 2 * b + 1]);
+  }
+}
+
+/* ------------------------------------------------------------------------ */
+/* batch driver (cpu_baseline leg of bench.py; OpenMP over envs)              */
+/* ------------------------------------------------------------------------ */
+/* envs: n contiguous OEnv; actions [n][nu]; outputs per env.  Philox mode. */
+void sago_step_batch(OEnv* envs, int n, int robot, const float* actions, uint32_t key0,
+                     uint32_t key1, float* obs, float* reward, uint8_t* cost, uint8_t* done,
+                     uint8_t* goal_met, int nthreads) {
+  int nu = NU[robot], od = OBS_DIM[robot];
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int i = 0; i < n; i++) {
+    OOut o;
+    sago_step(&envs[i], robot, actions + (size_t)i * nu, NULL, NULL, 0, key0, key1, -1, -1, 0, &o);
+    if (obs) for (int k = 0; k < od; k++) obs[(size_t)i * od + k] = (float)o.obs[k];
+    if (reward) { reward[2 * i] = (float)o.reward[0]; reward[2 * i + 1] = (float)o.reward[1]; }
+    if (cost) cost[i] = (uint8_t)o.cost;
+    if (done) done[i] = (uint8_t)o.done;
+    if (goal_met) goal_met[i] = (uint8_t)o.goal_met;
+  }
+}
+
+void sago_robot_info(int robot, int out[5], double* dt) {
+  static const int NQ[3] = {3, 13, 20}, NV[3] = {3, 11, 19};
+  out[0] = NU[robot]; out[1] = OBS_DIM[robot]; out[2] = NSTEP[robot]; out[3] = NQ[robot]; out[4] = NV[robot];
+  *dt = DT[robot];
+}

@@ -1,0 +1,100 @@
+"""Pin the CPU oracle (oracle/sag_oracle.c) against fixtures generated from the
+reference's own NumPy code (oracle/gen_golden.py -> tests/golden/)."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle_lib import (F_GOAL, F_LAST, I_FLAGS, Oracle)
+
+
+@pytest.fixture(scope='module')
+def oracle():
+  return Oracle()
+
+
+def test_lidar_matches_reference(oracle):
+  """safe_adaptation_gym.py:174-223 on 260 cases incl. exact-axis, tilted base, empty."""
+  z = np.load(gu.GOLDEN + '/lidar.npz')
+  n = len(z['count'])
+  for i in range(n):
+    k = int(z['count'][i])
+    obs, bins = oracle.lidar(z['robot_pos'][i], z['robot_mat'][i], z['points'][i, :k])
+    # values: NumPy's matmul/BLAS may round the 3-term dot products differently by an
+    # ulp; the bin indices (below) are what must be bit-exact.
+    np.testing.assert_allclose(obs, z['obs'][i], rtol=0, atol=1e-14, err_msg=f'case {i}')
+    assert np.array_equal(obs > 0, z['obs'][i] > 0)
+    for j in range(k):
+      if z['bins'][i, j] >= 0:
+        assert bins[j] == z['bins'][i, j], (i, j)
+
+
+EPISODES = None
+
+
+def episodes():
+  global EPISODES
+  if EPISODES is None:
+    EPISODES = gu.load_json_gz('episodes.json.gz')
+  return EPISODES
+
+
+NO_BOX_TASKS = [
+    'catch_goal', 'collect', 'go_to_goal', 'go_to_goal_damping', 'go_to_goal_motor',
+    'go_to_goal_scarce', 'press_buttons', 'press_buttons_scarce', 'unsupervised'
+]
+
+
+@pytest.mark.parametrize('task', NO_BOX_TASKS)
+def test_episode_matches_reference(oracle, task):
+  """Replay the reference's step() (scripted poses) through the oracle with physics
+  off: noise draw order, reward, cost, lidar grouping, goal resample, button / catch
+  state machines and RNG consumption must all match."""
+  ep = [e for e in episodes() if e['robot'] == 'point' and e['task'] == task][0]
+  names = ep['names']
+  rf, ri = gu.episode_init_record(ep)
+  e = oracle.env(rf, ri)
+  rs = gu.rs_from_dump(ep['rs_state'])
+  # first observation (reset): lidar + non-acceleration sensors
+  out = oracle.observe(e, 0)
+  obs0 = np.array(out.obs[:60])
+  np.testing.assert_allclose(obs0[:48], ep['init_obs'][:48], rtol=0, atol=1e-12)
+  n_met = 0
+  for t, st in enumerate(ep['steps']):
+    noise = rs.normal(size=2)  # safe_adaptation_gym.py:63-65
+    ctrl = np.clip(np.array(st['action']) + 0.01 * noise, -1, 1)
+    np.testing.assert_allclose(ctrl, st['ctrl'], rtol=0, atol=1e-15)
+    tape = gu.rs_words(gu.rs_copy(rs), 512)
+    rf, ri = oracle.record(e)
+    gu.set_poses(rf, names, st['pos'], yaw=st['robot_yaw'], v0=st['robot_v0'],
+                 wz=st['sensors']['gyro'][2])
+    e = oracle.env(rf, ri)
+    cc, mask = gu.contact_inputs('point', st['contacts'])
+    out = oracle.step(e, 0, st['action'], noise=noise, tape=tape, nstep=0,
+                      ext_contacts=cc, ext_btn_mask=mask)
+    gu.rs_words(rs, out.tape_used)
+    rf, ri = oracle.record(e)
+    assert ri[I_FLAGS] == 0
+    # outputs
+    nr = len(st['reward'])
+    np.testing.assert_allclose(np.array(out.reward[:nr]), st['reward'], rtol=0, atol=1e-12,
+                               err_msg=f'step {t}')
+    assert out.cost == int(st['cost']), t
+    assert out.done == int(st['done'])
+    obs = np.array(out.obs[:60])
+    np.testing.assert_allclose(obs[:48], st['obs'][:48], rtol=0, atol=1e-12, err_msg=f'step {t}')
+    # sensors: accelerometer xy is physics-derived (not pinned); the rest is kinematics
+    np.testing.assert_allclose(obs[50:60], st['obs'][50:60], rtol=0, atol=1e-12)
+    # state after
+    assert gu.rs_probe(rs) == st['rs_probe'], f'RNG position diverged at step {t}'
+    ts = st['task_state']
+    if ts.get('_last_goal_distance') is not None:
+      assert abs(rf[F_LAST] - ts['_last_goal_distance']) < 1e-12
+    if 'goal' in names:
+      g = st['pos'][names.index('goal')]
+      np.testing.assert_allclose(rf[F_GOAL:F_GOAL + 2], g[:2], rtol=0, atol=1e-12)
+    rf2, ri2 = rf.copy(), ri.copy()
+    gu.set_task_state(rf2, ri2, ts)
+    np.testing.assert_array_equal(ri2, ri)
+    np.testing.assert_allclose(rf2, rf, rtol=0, atol=1e-12)
+    n_met += out.goal_met
+  assert n_met > 3, 'fixture should exercise goal-met events'
