@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""bench.py - env-steps/s of the batched SafeAdaptationGym.step() on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W            (N = 1: run directly)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU.  Environments are independent, so the batch is sharded by env
+index with NO collective on the data path (weak scaling: --envs per GPU is fixed);
+torch.distributed (gloo, CPU tensors) is used only for the barrier and the
+max-over-ranks of the timed region.  The step itself never touches torch.
+
+A "step" = one sag_step_device() over the whole shard: action noise + clip, nstep=5
+physics substeps with contact, reward (+ goal resampling), cost, 3x16 lidar, sensors,
+observation write.  Inputs (layouts, actions) are resident in HBM before timing.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+# algorithmic bytes of one Point/GoToGoal env-step (fp32 SoA state):
+# action 8 + robot qpos,qvel r/w 48 + 10 vases x 6 floats r/w 480 + 9 hazards, pillar,
+# goal xy 88 + task scalars r/w 16 + obs 240 + reward 4 + cost 4 + done 4
+ALG_BYTES_PER_ENV_STEP = 892
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+N_LAYOUTS = 4096       # distinct sampled layouts, tiled over the batch
+N_ACTION_BUFS = 8
+
+
+def build_records(task, envs_per_gpu, rank, seed=666):
+  """Layouts with the reference sampler semantics: global env g uses the layout drawn
+  with RandomState(seed + g % N_LAYOUTS); env ids (RNG streams) are globally unique."""
+  import batch_util as bu
+  from safe_adaptation_gym_amd import _native as nat
+  cache = os.path.join(ROOT, 'gpurun_out', f'layouts_{task}_{seed}_{N_LAYOUTS}.npz')
+  n = min(N_LAYOUTS, envs_per_gpu * max(1, int(os.environ.get('WORLD_SIZE', '1'))))
+  if os.path.exists(cache):
+    z = np.load(cache)
+    rf, ri = z['rf'], z['ri']
+  else:
+    rf, ri = bu.sample_records('point', task, n, seed=seed)
+    try:
+      os.makedirs(os.path.dirname(cache), exist_ok=True)
+      np.savez(cache + f'.{os.getpid()}.tmp.npz', rf=rf, ri=ri)
+      os.replace(cache + f'.{os.getpid()}.tmp.npz', cache)
+    except OSError:
+      pass
+  g = rank * envs_per_gpu + np.arange(envs_per_gpu)
+  idx = g % len(rf)
+  out_f, out_i = rf[idx].copy(), ri[idx].copy()
+  out_i[:, nat.I_ENV_ID] = g
+  return out_f, out_i
+
+
+class DeviceRun:
+  """Everything resident on the GPU: world, action buffers, output buffers."""
+
+  def __init__(self, task, envs, device, rank, seed=666):
+    from safe_adaptation_gym_amd import _native as nat
+    self.nat = nat
+    rf, ri = build_records(task, envs, rank, seed)
+    has_btn = int(ri[:, nat.I_NB].max()) > 0
+    self.ctx = nat.Context('point', envs, device=device, seed=seed,
+                           max_buttons=nat.MAX_BUTTONS if has_btn else 0, has_box=False)
+    self.ctx.set_layout(rf, ri)
+    self.envs = envs
+    od = self.ctx.info['obs_dim']
+    self.d_act = [self.ctx.dev_alloc(envs * 2 * 4) for _ in range(N_ACTION_BUFS)]
+    for k, b in enumerate(self.d_act):
+      self.ctx.dev_fill_actions(b, k)
+    self.d_obs = self.ctx.dev_alloc(envs * od * 4)
+    self.d_rew = self.ctx.dev_alloc(envs * 2 * 4)
+    self.d_cost = self.ctx.dev_alloc(envs)
+    self.d_done = self.ctx.dev_alloc(envs)
+    self.d_met = self.ctx.dev_alloc(envs)
+    self.ctx.wait()
+    self.t = 0
+
+  def step(self):
+    c = self.ctx
+    c.step_device(self.d_act[self.t % N_ACTION_BUFS], None, -1, self.d_obs, self.d_rew, self.d_cost,
+                  self.d_done, self.d_met)
+    self.t += 1
+
+  def run(self, steps):
+    for _ in range(steps):
+      self.step()
+
+  def stats(self):
+    cost = self.ctx.dev_download(self.d_cost, (self.envs,), np.uint8)
+    done = self.ctx.dev_download(self.d_done, (self.envs,), np.uint8)
+    obs = self.ctx.dev_download(self.d_obs, (min(self.envs, 4096) * 60,), np.float32)
+    return float(cost.mean()), int(done.sum()), bool(np.isfinite(obs).all())
+
+  def close(self):
+    self.ctx.close()
+
+
+def timed(run, steps, warmup, barrier):
+  run.run(warmup)
+  run.ctx.wait()
+  barrier()
+  t0 = time.perf_counter()
+  run.run(steps)
+  run.ctx.wait()
+  barrier()
+  return time.perf_counter() - t0
+
+
+def cpu_baseline(task, seconds=12.0):
+  """The CPU oracle (oracle/sag_oracle.c, fp64, OpenMP over envs) on this host: same
+  layouts, same counter-based actions/noise.  A reported baseline, not the target."""
+  from oracle_lib import Oracle
+  o = Oracle()
+  n = 4096
+  rf, ri = build_records(task, n, 0)
+  arr = o.make_batch(rf, ri)
+  acts = np.stack([[o.actions((666, 0), int(ri[i, 12]), s, 2) for i in range(n)] for s in range(4)])
+  cores = os.cpu_count() or 1
+  out = {}
+  for label, nt in (('1', 1), ('all', cores)):
+    o.step_batch(arr, 0, acts[0], key=(666, 0), nthreads=nt)  # warm
+    t0 = time.perf_counter()
+    done_steps = 0
+    budget = seconds * (0.35 if nt == 1 else 0.65)
+    while time.perf_counter() - t0 < budget:
+      o.step_batch(arr, 0, acts[done_steps % 4], key=(666, 0), nthreads=nt)
+      done_steps += 1
+    dt = time.perf_counter() - t0
+    out[label] = (n * done_steps / dt, done_steps, dt)
+  v, k, dt = out['all']
+  return {
+      'value': v,
+      'unit': 'env-steps/s',
+      'cores': cores,
+      'kind': 'port',
+      'sample': f'point/{task}, {n} envs x {k} steps in {dt:.1f}s, oracle/sag_oracle.c fp64 -O2 OpenMP '
+                f'{cores} threads (1 thread: {out["1"][0]:.0f} env-steps/s); CPU restatement, not MuJoCo',
+      'single_core_value': out['1'][0],
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=200)
+  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--envs', type=int, default=1 << 20, help='environments per GPU (weak scaling)')
+  ap.add_argument('--task', default='go_to_goal')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line')
+  args = ap.parse_args()
+
+  rank = int(os.environ.get('RANK', '0'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if world != args.gpus:
+    if world == 1 and args.gpus > 1:
+      sys.exit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
+               '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    sys.exit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+  dist = None
+  if world > 1:
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    # the data path has no collective; gloo on CPU tensors carries the barrier and the max
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+  def barrier():
+    if dist is not None:
+      dist.barrier()
+
+  def max_over_ranks(x):
+    if dist is None:
+      return x
+    import torch
+    t = torch.tensor([x], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+  from safe_adaptation_gym_amd import _native as nat
+  ndev = nat.device_count()
+  if ndev < 1:
+    sys.exit('no HIP device visible (there is no CPU fallback)')
+  device = local % ndev
+
+  run = DeviceRun(args.task, args.envs, device, rank)
+  # timed region with per-launch HIP events on the context stream (kernel time for the roofline)
+  run.ctx.enable_timing(True)
+  run.ctx.kernel_time_ms(reset=True)
+  elapsed = max_over_ranks(timed(run, args.steps, args.warmup, barrier))
+  k_ms, k_n = run.ctx.kernel_time_ms(reset=True)
+  # kernel_time covers warmup + timed launches; both are the same kernel on the same data
+  run.ctx.enable_timing(False)
+  cost_rate, n_done, finite = run.stats()
+  total_env_steps = world * args.envs * args.steps
+  value = total_env_steps / elapsed
+  achieved = ALG_BYTES_PER_ENV_STEP * args.envs / (k_ms * 1e-3) / 1e9
+  res = {
+      'metric': 'env-steps/sec (batched) Point/GoToGoal',
+      'value': value,
+      'unit': 'env-steps/s',
+      'n_gpus': world,
+      'steps': args.steps,
+      'warmup': args.warmup,
+      'ms_per_step': elapsed / args.steps * 1e3,
+      'higher_is_better': True,
+      'scaling': 'weak',
+      'vs_baseline': None,
+      'dtype': 'f32',
+      'data': 'synthetic',
+      'config': {
+          'workload': f'point/{args.task} full step() (5 substeps + contact + reward + cost + lidar + obs), '
+                      f'fixed layouts sampled with the reference sampler (seeds 666+i, {N_LAYOUTS} distinct, tiled), '
+                      f'{args.envs} envs per GPU, counter-based actions U(-1,1) and noise 0.01 on device',
+          'envs_per_gpu': args.envs,
+          'global_envs': world * args.envs,
+          'parallelism': f'env-sharded x{world}, no collective',
+      },
+      'roofline': {
+          'bound': 'hbm',
+          'achieved': achieved,
+          'peak': HBM_PEAK_GBS,
+          'unit': 'GB/s',
+          'frac': achieved / HBM_PEAK_GBS,
+          'traffic': None,
+          'kernel': 'sag::k_step_point',
+          'kernel_ms': k_ms,
+          'launches_timed': k_n,
+          'alg_bytes_per_env_step': ALG_BYTES_PER_ENV_STEP,
+      },
+      'checks': {'cost_rate_last_step': cost_rate, 'done_envs': n_done, 'obs_finite': finite},
+  }
+  run.close()
+
+  if rank == 0 and world == 1:
+    if not args.no_c2:
+      c2 = DeviceRun(args.task, 4096, device, 0)
+      c2.ctx.enable_timing(True)
+      t = timed(c2, max(args.steps, 200), args.warmup, lambda: None)
+      ms, _ = c2.ctx.kernel_time_ms(reset=True)
+      res['c2_4096_envs'] = {
+          'value': 4096 * max(args.steps, 200) / t,
+          'unit': 'env-steps/s',
+          'ms_per_step': t / max(args.steps, 200) * 1e3,
+          'kernel_ms': ms,
+          'note': 'BASELINE config-2 batch size (4096 envs on one GPU): launch/latency bound, 64 wavefronts'
+      }
+      c2.close()
+    if not args.no_cpu_baseline:
+      res['cpu_baseline'] = cpu_baseline(args.task)
+  if rank == 0:
+    print(json.dumps(res))
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

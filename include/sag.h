@@ -5,7 +5,7 @@
  * seam is the Python object MujocoBridge (reference safe_adaptation_gym/
  * mujoco_bridge.py:15-280) as consumed by SafeAdaptationGym.step/reset/observation
  * (safe_adaptation_gym.py:56-139), World (world.py:139-165,219-231) and the tasks'
- * compute_reward/reset/set_mocaps (tasks/*.py).  Each entry point below names the
+ * compute_reward/reset/set_mocaps (tasks/<task>.py).  Each entry point below names the
  * reference calls it replaces.  Plain pointers and sizes only; no exceptions cross
  * the ABI; every function returns 0 on success and a negative sag_status on error,
  * with a message available from sag_last_error().
@@ -221,6 +221,8 @@ int sag_dev_fill_actions(sag_ctx* ctx, float* d_actions, uint32_t step_index);
  * stream: mean milliseconds per launch over the launches since the last call
  * with reset != 0.  Feeds bench.py's roofline.achieved. */
 int sag_kernel_time_ms(sag_ctx* ctx, int32_t reset, double* mean_ms, int64_t* launches);
+/* Per-launch HIP-event bracketing of the step kernel is off by default. */
+int sag_enable_timing(sag_ctx* ctx, int32_t on);
 
 int sag_device_count(void);
 

@@ -602,16 +602,26 @@ static void point_smooth(Body* r, const real ctrl[2], real gear, real damp, real
   real c = R_COS(r->yaw), s = R_SIN(r->yaw);
   /* motor on site "robot": force gear*clip(ctrl, forcerange) along body +x (point.xml:36) */
   real f0 = gear * clampr(ctrl[0], -(real)PT_FORCE_LIM, (real)PT_FORCE_LIM);
-  /* velocity servo on hinge z: kv (ctrl - gear*w), clipped, times gear (point.xml:37) */
-  real f1 = (real)PT_GEAR_Z *
-            clampr((real)PT_KV * (ctrl[1] - (real)PT_GEAR_Z * r->w), -(real)PT_FORCE_LIM,
-                   (real)PT_FORCE_LIM);
   /* tau - bias - D v;  bias = (-mc c w^2, -mc s w^2, 0) */
   real Fx = f0 * c - damp * r->vx + (real)PT_MC * c * r->w * r->w;
   real Fy = f0 * s - damp * r->vy + (real)PT_MC * s * r->w * r->w;
-  real Tz = f1 - (real)PT_DAMP_Z * r->w;
+  real Tz0 = -(real)PT_DAMP_Z * r->w;
   point_minv(r, damp, h);
   const real* m = r->minv;
+  /* velocity servo on hinge z (point.xml:37): torque gear*clip(kv*(ctrl - gear*w), forcerange).
+   * Its velocity feedback is stiff: h*kv*gear^2/Izz = 12.7 per substep, far outside the
+   * stability region of an explicit update (MuJoCo's Euler treats only joint damping
+   * implicitly and would limit-cycle at +-1 rad/s here).  SPECIFICATION: the servo is
+   * evaluated at the end-of-substep yaw rate, solved exactly for the clipped-linear law:
+   * w_lin = implicit linear prediction; the clip of its error gives the torque, which is the
+   * exact root in the linear zone and the correctly signed limit outside it (the map is
+   * monotone). */
+  real A = r->w + h * (m[2] * Fx + m[4] * Fy + m[5] * Tz0);
+  real g = h * m[5];
+  real w_lin = (A + g * (real)(PT_GEAR_Z * PT_KV) * ctrl[1]) / (1 + g * (real)(PT_GEAR_Z * PT_GEAR_Z * PT_KV));
+  real f1 = (real)PT_GEAR_Z *
+            clampr((real)PT_KV * (ctrl[1] - (real)PT_GEAR_Z * w_lin), -(real)PT_FORCE_LIM, (real)PT_FORCE_LIM);
+  real Tz = f1 + Tz0;
   r->ax = m[0] * Fx + m[1] * Fy + m[2] * Tz;
   r->ay = m[1] * Fx + m[3] * Fy + m[4] * Tz;
   r->aw = m[2] * Fx + m[4] * Fy + m[5] * Tz;
@@ -757,7 +767,7 @@ static void catch_goal_mocap(OEnv* e, Rng* g, double time) {
 }
 
 /* ------------------------------------------------------------------------ */
-/* per-task reward (tasks/*.py compute_reward)                                */
+/* per-task reward (tasks/<task>.py compute_reward)                                */
 /* ------------------------------------------------------------------------ */
 static void task_reward(OEnv* e, Rng* g, uint32_t btn_mask, OOut* out) {
   real* f = e->f;
@@ -1016,6 +1026,34 @@ void sago_step_batch(OEnv* envs, int n, int robot, const float* actions, uint32_
     if (cost) cost[i] = (uint8_t)o.cost;
     if (done) done[i] = (uint8_t)o.done;
     if (goal_met) goal_met[i] = (uint8_t)o.goal_met;
+  }
+}
+
+/* lockstep parity driver: explicit noise / tape per env (either may be NULL), all
+ * outputs incl. diagnostics.  Serial. */
+void sago_step_batch_full(OEnv* envs, int n, int robot, const float* actions, const float* noise,
+                          const uint32_t* tape, int tape_len, uint32_t key0, uint32_t key1,
+                          int nstep, float* obs, float* reward, uint8_t* cost, uint8_t* done,
+                          uint8_t* goal_met, int32_t* tape_used, double* cost_margin) {
+  int nu = NU[robot], od = OBS_DIM[robot];
+  for (int i = 0; i < n; i++) {
+    OOut o;
+    sago_step(&envs[i], robot, actions + (size_t)i * nu, noise ? noise + (size_t)i * nu : NULL,
+              tape ? tape + (size_t)i * tape_len : NULL, tape_len, key0, key1, nstep, -1, 0, &o);
+    for (int k = 0; k < od; k++) obs[(size_t)i * od + k] = (float)o.obs[k];
+    reward[2 * i] = (float)o.reward[0]; reward[2 * i + 1] = (float)o.reward[1];
+    cost[i] = (uint8_t)o.cost; done[i] = (uint8_t)o.done; goal_met[i] = (uint8_t)o.goal_met;
+    tape_used[i] = o.tape_used;
+    if (cost_margin) cost_margin[i] = (double)o.cost_margin;
+  }
+}
+
+void sago_observe_batch(OEnv* envs, int n, int robot, float* obs) {
+  int od = OBS_DIM[robot];
+  for (int i = 0; i < n; i++) {
+    OOut o;
+    sago_observe(&envs[i], robot, &o);
+    for (int k = 0; k < od; k++) obs[(size_t)i * od + k] = (float)o.obs[k];
   }
 }
 

@@ -1,0 +1,258 @@
+"""ctypes binding of libsag.so (include/sag.h).  NumPy only - no torch on the path.
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible,
+every entry point raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsag.so')
+
+ABI_VERSION = 1
+MAX_HAZARDS, MAX_VASES, MAX_PILLARS, MAX_BUTTONS, MAX_NU = 9, 10, 2, 6, 12
+REC_FLOATS, REC_INTS = 144, 16
+
+# record field offsets (enum sag_rec_float / sag_rec_int)
+F_ROBOT, F_ROBOT0, F_GEAR, F_DAMP, F_ACTION_NOISE, F_CTRL_SCALE = 0, 6, 9, 10, 11, 12
+F_HAZARD_SIZE, F_VASE_SIZE, F_PILLAR_SIZE, F_KEEPOUT = 24, 25, 26, 27
+F_GOAL, F_CATCH, F_LAST, F_BOX = 32, 34, 38, 41
+F_HAZARDS, F_PILLARS, F_BUTTONS, F_VASES = 47, 65, 69, 81
+(I_TASK, I_NH, I_NV, I_NP, I_NB, I_BOX_KIND, I_GOAL_BUTTON, I_BTN_STATE, I_BTN_TIMER,
+ I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS) = range(14)
+
+ROBOT_IDS = {'point': 0, 'car': 1, 'doggo': 2}
+
+EXPORTS = [
+    'sag_robot_info', 'sag_create', 'sag_destroy', 'sag_last_error', 'sag_set_layout',
+    'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
+    'sag_observe', 'sag_lidar_cost', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
+    'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing',
+    'sag_device_count'
+]
+
+
+class SagError(RuntimeError):
+  pass
+
+
+class _Config(C.Structure):
+  _fields_ = [('abi_version', C.c_int32), ('robot', C.c_int32), ('n_envs', C.c_int32),
+              ('device', C.c_int32), ('max_hazards', C.c_int32), ('max_vases', C.c_int32),
+              ('max_pillars', C.c_int32), ('max_buttons', C.c_int32), ('has_box', C.c_int32),
+              ('reserved0', C.c_int32), ('seed', C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+  """Load libsag.so; raises SagError (never falls back) if it is not there."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise SagError(
+        f'{LIB_PATH} not found: build it with `python -m safe_adaptation_gym_amd.build` '
+        '(hipcc, --offload-arch=gfx950). There is no CPU fallback.')
+  lib = C.CDLL(LIB_PATH)
+  vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+  up, bp = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+  lib.sag_last_error.restype = C.c_char_p
+  lib.sag_last_error.argtypes = [vp]
+  lib.sag_robot_info.argtypes = [C.c_int32, ip, C.POINTER(C.c_double)]
+  lib.sag_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+  lib.sag_destroy.argtypes = [vp]
+  lib.sag_set_layout.argtypes = [vp, ip, C.c_int32, fp, ip]
+  lib.sag_set_state.argtypes = [vp, ip, C.c_int32, fp, ip]
+  lib.sag_get_state.argtypes = [vp, ip, C.c_int32, fp, ip]
+  lib.sag_reset.argtypes = [vp, ip, C.c_int32]
+  lib.sag_step.argtypes = [vp, fp, fp, up, C.c_int32, C.c_int32, fp, fp, bp, bp, bp, ip]
+  lib.sag_step_device.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+  lib.sag_wait.argtypes = [vp]
+  lib.sag_observe.argtypes = [vp, fp]
+  lib.sag_lidar_cost.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, bp, C.c_float, fp, ip, bp]
+  lib.sag_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+  lib.sag_dev_free.argtypes = [vp, vp]
+  lib.sag_dev_upload.argtypes = [vp, vp, vp, C.c_uint64]
+  lib.sag_dev_download.argtypes = [vp, vp, vp, C.c_uint64]
+  lib.sag_dev_fill_actions.argtypes = [vp, vp, C.c_uint32]
+  lib.sag_kernel_time_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+  lib.sag_enable_timing.argtypes = [vp, C.c_int32]
+  _lib = lib
+  return lib
+
+
+def robot_info(robot):
+  lib = load()
+  out = (C.c_int32 * 5)()
+  dt = C.c_double()
+  rc = lib.sag_robot_info(ROBOT_IDS[robot] if isinstance(robot, str) else robot, out, C.byref(dt))
+  if rc:
+    raise SagError(f'sag_robot_info failed ({rc})')
+  return dict(nu=out[0], obs_dim=out[1], nstep=out[2], nq=out[3], nv=out[4], dt=dt.value)
+
+
+def device_count():
+  return load().sag_device_count()
+
+
+def _ptr(a, ctype):
+  return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Context:
+  """One GPU shard: owns the SoA world of n_envs environments on `device`."""
+
+  def __init__(self, robot, n_envs, device=0, seed=0, max_hazards=MAX_HAZARDS,
+               max_vases=MAX_VASES, max_pillars=MAX_PILLARS, max_buttons=MAX_BUTTONS,
+               has_box=True):
+    self.lib = load()
+    self.robot = robot
+    self.info = robot_info(robot)
+    self.n_envs = int(n_envs)
+    cfg = _Config(ABI_VERSION, ROBOT_IDS[robot], self.n_envs, device, max_hazards, max_vases,
+                  max_pillars, max_buttons, int(has_box), 0, seed & (2**64 - 1))
+    h = C.c_void_p()
+    rc = self.lib.sag_create(C.byref(cfg), C.byref(h))
+    if rc:
+      raise SagError(f'sag_create failed ({rc}): {self.lib.sag_last_error(None).decode()}')
+    self.h = h
+    nu, od, n = self.info['nu'], self.info['obs_dim'], self.n_envs
+    self._obs = np.zeros((n, od), np.float32)
+    self._rew = np.zeros((n, 2), np.float32)
+    self._cost = np.zeros(n, np.uint8)
+    self._done = np.zeros(n, np.uint8)
+    self._met = np.zeros(n, np.uint8)
+    self._used = np.zeros(n, np.int32)
+
+  def _check(self, rc, what):
+    if rc:
+      raise SagError(f'{what} failed ({rc}): {self.lib.sag_last_error(self.h).decode()}')
+
+  def close(self):
+    if getattr(self, 'h', None):
+      self.lib.sag_destroy(self.h)
+      self.h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # interpreter shutdown
+      pass
+
+  # -- records ---------------------------------------------------------------
+  def _recs(self, env_ids, rec_f, rec_i):
+    rec_f = np.ascontiguousarray(rec_f, np.float32).reshape(-1, REC_FLOATS)
+    rec_i = np.ascontiguousarray(rec_i, np.int32).reshape(-1, REC_INTS)
+    n = len(rec_f)
+    assert len(rec_i) == n
+    ids = None
+    if env_ids is not None:
+      ids = np.ascontiguousarray(env_ids, np.int32)
+      assert len(ids) == n
+    return ids, n, rec_f, rec_i
+
+  def set_layout(self, rec_f, rec_i, env_ids=None):
+    ids, n, rf, ri = self._recs(env_ids, rec_f, rec_i)
+    self._check(self.lib.sag_set_layout(self.h, _ptr(ids, C.c_int32), n, _ptr(rf, C.c_float),
+                                        _ptr(ri, C.c_int32)), 'sag_set_layout')
+
+  def set_state(self, rec_f, rec_i, env_ids=None):
+    ids, n, rf, ri = self._recs(env_ids, rec_f, rec_i)
+    self._check(self.lib.sag_set_state(self.h, _ptr(ids, C.c_int32), n, _ptr(rf, C.c_float),
+                                       _ptr(ri, C.c_int32)), 'sag_set_state')
+
+  def get_state(self, env_ids=None):
+    ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int32)
+    n = self.n_envs if ids is None else len(ids)
+    rf = np.zeros((n, REC_FLOATS), np.float32)
+    ri = np.zeros((n, REC_INTS), np.int32)
+    self._check(self.lib.sag_get_state(self.h, _ptr(ids, C.c_int32), n, _ptr(rf, C.c_float),
+                                       _ptr(ri, C.c_int32)), 'sag_get_state')
+    return rf, ri
+
+  def reset(self, env_ids=None):
+    ids = None if env_ids is None else np.ascontiguousarray(env_ids, np.int32)
+    n = self.n_envs if ids is None else len(ids)
+    self._check(self.lib.sag_reset(self.h, _ptr(ids, C.c_int32), n), 'sag_reset')
+
+  # -- stepping --------------------------------------------------------------
+  def step(self, actions, noise=None, tape=None, nstep=-1, want_tape_used=False):
+    n, nu = self.n_envs, self.info['nu']
+    a = np.ascontiguousarray(actions, np.float32).reshape(n, nu)
+    nz = None if noise is None else np.ascontiguousarray(noise, np.float32).reshape(n, nu)
+    tp, tl = None, 0
+    if tape is not None:
+      tp = np.ascontiguousarray(tape, np.uint32).reshape(n, -1)
+      tl = tp.shape[1]
+    self._check(
+        self.lib.sag_step(self.h, _ptr(a, C.c_float), _ptr(nz, C.c_float), _ptr(tp, C.c_uint32), tl,
+                          nstep, _ptr(self._obs, C.c_float), _ptr(self._rew, C.c_float),
+                          _ptr(self._cost, C.c_uint8), _ptr(self._done, C.c_uint8),
+                          _ptr(self._met, C.c_uint8),
+                          _ptr(self._used, C.c_int32) if want_tape_used or tp is not None else None),
+        'sag_step')
+    return (self._obs.copy(), self._rew.copy(), self._cost.copy(), self._done.copy(),
+            self._met.copy(), self._used.copy())
+
+  def observe(self):
+    self._check(self.lib.sag_observe(self.h, _ptr(self._obs, C.c_float)), 'sag_observe')
+    return self._obs.copy()
+
+  def lidar_cost(self, robot, points, group, hazard_size=0.2, want_bins=True):
+    robot = np.ascontiguousarray(robot, np.float32).reshape(-1, 3)
+    n = len(robot)
+    group = np.ascontiguousarray(group, np.uint8).reshape(n, -1)
+    K = group.shape[1]
+    points = np.ascontiguousarray(points, np.float32).reshape(n, K, 2)
+    lidar = np.zeros((n, 48), np.float32)
+    bins = np.full((n, K), -1, np.int32) if want_bins else None
+    cost = np.zeros(n, np.uint8)
+    self._check(
+        self.lib.sag_lidar_cost(self.h, n, K, _ptr(robot, C.c_float), _ptr(points, C.c_float),
+                                _ptr(group, C.c_uint8), hazard_size, _ptr(lidar, C.c_float),
+                                _ptr(bins, C.c_int32), _ptr(cost, C.c_uint8)), 'sag_lidar_cost')
+    return lidar, bins, cost
+
+  # -- device-resident stepping (bench harness / GPU learners) -----------------
+  def dev_alloc(self, nbytes):
+    p = C.c_void_p()
+    self._check(self.lib.sag_dev_alloc(self.h, nbytes, C.byref(p)), 'sag_dev_alloc')
+    return p
+
+  def dev_free(self, p):
+    self._check(self.lib.sag_dev_free(self.h, p), 'sag_dev_free')
+
+  def dev_upload(self, dst, arr):
+    arr = np.ascontiguousarray(arr)
+    self._check(self.lib.sag_dev_upload(self.h, dst, arr.ctypes.data_as(C.c_void_p), arr.nbytes),
+                'sag_dev_upload')
+
+  def dev_download(self, src, shape, dtype):
+    out = np.zeros(shape, dtype)
+    self._check(self.lib.sag_dev_download(self.h, out.ctypes.data_as(C.c_void_p), src, out.nbytes),
+                'sag_dev_download')
+    return out
+
+  def dev_fill_actions(self, d_actions, step_index):
+    self._check(self.lib.sag_dev_fill_actions(self.h, d_actions, step_index), 'sag_dev_fill_actions')
+
+  def step_device(self, d_actions, d_noise=None, nstep=-1, d_obs=None, d_reward=None, d_cost=None,
+                  d_done=None, d_goal_met=None):
+    self._check(
+        self.lib.sag_step_device(self.h, d_actions, d_noise, nstep, d_obs, d_reward, d_cost, d_done,
+                                 d_goal_met), 'sag_step_device')
+
+  def wait(self):
+    self._check(self.lib.sag_wait(self.h), 'sag_wait')
+
+  def enable_timing(self, on=True):
+    self._check(self.lib.sag_enable_timing(self.h, int(on)), 'sag_enable_timing')
+
+  def kernel_time_ms(self, reset=False):
+    ms, n = C.c_double(), C.c_int64()
+    self._check(self.lib.sag_kernel_time_ms(self.h, int(reset), C.byref(ms), C.byref(n)),
+                'sag_kernel_time_ms')
+    return ms.value, n.value

@@ -1,0 +1,493 @@
+// sag_api.hip - host side of the C ABI declared in include/sag.h.
+//
+// One context = one GPU = one HIP stream.  Device memory: the SoA world
+// (S: [SAG_REC_FLOATS][N] f32, I: [DI_COUNT][N] i32), AoS staging for records,
+// pinned host + device staging for the host-pointer step.  No allocation, no
+// synchronisation and no host<->device copy happens inside sag_step_device(),
+// so callers may capture it into a hipGraph.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sag_device.hpp"
+
+using namespace sag;
+
+namespace {
+
+struct RobotInfo { int nu, obs_dim, nstep, nq, nv; double dt; };
+const RobotInfo ROBOTS[3] = {
+    {2, 60, 5, 3, 3, 0.004},      // point.xml:3, safe_adaptation_gym.py:15-19
+    {2, 72, 10, 13, 11, 0.008},   // car.xml:3
+    {12, 104, 12, 20, 19, 0.012}  // doggo.xml:2
+};
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct sag_ctx {
+  sag_config cfg;
+  RobotInfo rb;
+  int N;
+  hipStream_t stream = nullptr;
+  float* S = nullptr;
+  int32_t* I = nullptr;
+  // last installed layout (sag_reset)
+  float* L_f = nullptr;   // [N][SAG_REC_FLOATS] AoS, device
+  int32_t* L_i = nullptr; // [N][SAG_REC_INTS]
+  // staging
+  float* st_f = nullptr; int32_t* st_i = nullptr; int32_t* st_ids = nullptr;  // device, N records
+  void* pin = nullptr; size_t pin_bytes = 0;  // pinned host
+  // step staging (device)
+  float* d_act = nullptr; float* d_noise = nullptr; uint32_t* d_tape = nullptr; size_t tape_cap = 0;
+  float* d_obs = nullptr; float* d_rew = nullptr; uint8_t* d_cost = nullptr; uint8_t* d_done = nullptr;
+  uint8_t* d_met = nullptr; int32_t* d_used = nullptr;
+  // generic buffers for sag_lidar_cost
+  void* scratch = nullptr; size_t scratch_bytes = 0;
+  bool have_layout = false;
+  // kernel timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double ev_ms = 0; int64_t ev_n = 0;
+  bool timing = false;
+  std::string err;
+};
+
+namespace {
+
+int fail(sag_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(ctx, SAG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+int ensure_pin(sag_ctx* c, size_t bytes) {
+  if (c->pin_bytes >= bytes) return 0;
+  if (c->pin) (void)hipHostFree(c->pin);
+  c->pin = nullptr; c->pin_bytes = 0;
+  HIPCHK(c, hipHostMalloc(&c->pin, bytes, hipHostMallocDefault));
+  c->pin_bytes = bytes;
+  return 0;
+}
+
+int ensure_scratch(sag_ctx* c, size_t bytes) {
+  if (c->scratch_bytes >= bytes) return 0;
+  if (c->scratch) (void)hipFree(c->scratch);
+  c->scratch = nullptr; c->scratch_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->scratch, bytes));
+  c->scratch_bytes = bytes;
+  return 0;
+}
+
+// drain finished timing events into the running mean
+void drain_events(sag_ctx* c) {
+  for (size_t k = 0; k < c->ev_used; k++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev_pool[k].first, c->ev_pool[k].second) == hipSuccess) {
+      c->ev_ms += ms; c->ev_n += 1;
+    }
+  }
+  c->ev_used = 0;
+}
+
+int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint32_t* d_tape,
+                int tape_len, int nstep, float* d_obs, float* d_rew, uint8_t* d_cost,
+                uint8_t* d_done, uint8_t* d_met, int32_t* d_used, int observe_only) {
+  if (c->cfg.robot != SAG_ROBOT_POINT)
+    return fail(c, SAG_ERR_UNSUPPORTED, "only the Point robot has a device integrator in this build");
+  StepArgs a;
+  a.S = c->S; a.I = c->I; a.N = c->N;
+  a.actions = d_act; a.noise = d_noise; a.tape = d_tape; a.tape_len = tape_len;
+  a.nstep = nstep < 0 ? c->rb.nstep : nstep;
+  a.nstep_table = c->rb.nstep;
+  a.h = (float)c->rb.dt;
+  a.key0 = (uint32_t)(c->cfg.seed & 0xffffffffu); a.key1 = (uint32_t)(c->cfg.seed >> 32);
+  a.obs = d_obs; a.reward = d_rew; a.cost = d_cost; a.done = d_done; a.goal_met = d_met;
+  a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.observe_only = observe_only;
+  const int blocks = (c->N + WAVE - 1) / WAVE;
+  const size_t lds = (size_t)(c->cfg.max_vases > 0 ? c->cfg.max_vases : 1) * VCOMP * WAVE * sizeof(float);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->timing && !observe_only) {
+    if (c->ev_used == c->ev_pool.size()) {
+      if (c->ev_pool.size() >= 4096) {  // bounded pool: fold what has finished
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        drain_events(c);
+      } else {
+        hipEvent_t a0, a1;
+        HIPCHK(c, hipEventCreate(&a0));
+        HIPCHK(c, hipEventCreate(&a1));
+        c->ev_pool.emplace_back(a0, a1);
+      }
+    }
+    e0 = c->ev_pool[c->ev_used].first; e1 = c->ev_pool[c->ev_used].second;
+    c->ev_used++;
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+  }
+  hipLaunchKernelGGL(k_step_point, dim3(blocks), dim3(WAVE), lds, c->stream, a);
+  if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sag_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sag_robot_info(int32_t robot, int32_t out[5], double* dt) {
+  if (robot < 0 || robot > 2 || !out || !dt) return SAG_ERR_ARG;
+  const RobotInfo& r = ROBOTS[robot];
+  out[0] = r.nu; out[1] = r.obs_dim; out[2] = r.nstep; out[3] = r.nq; out[4] = r.nv;
+  *dt = r.dt;
+  return SAG_OK;
+}
+
+const char* sag_last_error(const sag_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sag_create(const sag_config* cfg, sag_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, SAG_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != SAG_ABI_VERSION)
+    return fail(nullptr, SAG_ERR_ARG, "ABI version %d, library is %d", cfg->abi_version, SAG_ABI_VERSION);
+  if (cfg->robot < 0 || cfg->robot > 2) return fail(nullptr, SAG_ERR_ARG, "bad robot %d", cfg->robot);
+  if (cfg->n_envs <= 0) return fail(nullptr, SAG_ERR_ARG, "n_envs must be positive");
+  if (cfg->max_hazards < 0 || cfg->max_hazards > SAG_MAX_HAZARDS || cfg->max_vases < 0 ||
+      cfg->max_vases > SAG_MAX_VASES || cfg->max_pillars < 0 || cfg->max_pillars > SAG_MAX_PILLARS ||
+      cfg->max_buttons < 0 || cfg->max_buttons > SAG_MAX_BUTTONS)
+    return fail(nullptr, SAG_ERR_ARG, "capacity out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, SAG_ERR_NODEVICE, "no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, SAG_ERR_NODEVICE, "device %d out of range (%d visible)", cfg->device, ndev);
+  sag_ctx* c = new sag_ctx();
+  c->cfg = *cfg; c->rb = ROBOTS[cfg->robot]; c->N = cfg->n_envs;
+  const size_t N = (size_t)c->N;
+#define CREATE_CHK(call)                                                                         \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      int rc_ = fail(nullptr, SAG_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));       \
+      sag_destroy(c);                                                                            \
+      return rc_;                                                                                \
+    }                                                                                            \
+  } while (0)
+  CREATE_CHK(hipSetDevice(cfg->device));
+  CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipMalloc(&c->S, N * SAG_REC_FLOATS * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->I, N * DI_COUNT * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->L_f, N * SAG_REC_FLOATS * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->L_i, N * SAG_REC_INTS * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->st_f, N * SAG_REC_FLOATS * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->st_i, N * SAG_REC_INTS * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->st_ids, N * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->d_act, N * c->rb.nu * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->d_noise, N * c->rb.nu * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->d_obs, N * c->rb.obs_dim * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->d_rew, N * 2 * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->d_cost, N));
+  CREATE_CHK(hipMalloc(&c->d_done, N));
+  CREATE_CHK(hipMalloc(&c->d_met, N));
+  CREATE_CHK(hipMalloc(&c->d_used, N * sizeof(int32_t)));
+  CREATE_CHK(hipMemsetAsync(c->S, 0, N * SAG_REC_FLOATS * sizeof(float), c->stream));
+  CREATE_CHK(hipMemsetAsync(c->I, 0, N * DI_COUNT * sizeof(int32_t), c->stream));
+  CREATE_CHK(hipStreamSynchronize(c->stream));
+#undef CREATE_CHK
+  *out = c;
+  return SAG_OK;
+}
+
+int sag_destroy(sag_ctx* c) {
+  if (!c) return SAG_OK;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  void* bufs[] = {c->S, c->I, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
+                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (c->pin) (void)hipHostFree(c->pin);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return SAG_OK;
+}
+
+static int upload_records(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* rec_f,
+                          const int32_t* rec_i) {
+  if (n <= 0 || n > c->N || !rec_f || !rec_i) return fail(c, SAG_ERR_ARG, "bad record batch (n=%d)", n);
+  if (env_ids)
+    for (int k = 0; k < n; k++)
+      if (env_ids[k] < 0 || env_ids[k] >= c->N) return fail(c, SAG_ERR_ARG, "env id %d out of range", env_ids[k]);
+  for (int k = 0; k < n; k++) {
+    const int32_t* ri = rec_i + (size_t)k * SAG_REC_INTS;
+    if (ri[SAG_I_TASK] < 0 || ri[SAG_I_TASK] >= SAG_NUM_TASKS || ri[SAG_I_NH] < 0 ||
+        ri[SAG_I_NH] > c->cfg.max_hazards || ri[SAG_I_NV] < 0 || ri[SAG_I_NV] > c->cfg.max_vases ||
+        ri[SAG_I_NP] < 0 || ri[SAG_I_NP] > c->cfg.max_pillars || ri[SAG_I_NB] < 0 ||
+        ri[SAG_I_NB] > c->cfg.max_buttons || ri[SAG_I_BOX_KIND] < 0 || ri[SAG_I_BOX_KIND] > 3 ||
+        (ri[SAG_I_BOX_KIND] != 0 && !c->cfg.has_box) || ri[SAG_I_GOAL_BUTTON] < 0 ||
+        ri[SAG_I_GOAL_BUTTON] >= SAG_MAX_BUTTONS || ri[SAG_I_BTN_TIMER] < 0 || ri[SAG_I_BTN_TIMER] > 5 ||
+        ri[SAG_I_CATCH_TIMER] < 0 || ri[SAG_I_CATCH_TIMER] > 10)
+      return fail(c, SAG_ERR_ARG, "record %d exceeds the context's capacities or has a bad field", k);
+  }
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMemcpyAsync(c->st_f, rec_f, (size_t)n * SAG_REC_FLOATS * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->st_i, rec_i, (size_t)n * SAG_REC_INTS * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  if (env_ids)
+    HIPCHK(c, hipMemcpyAsync(c->st_ids, env_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int sag_set_layout(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* rec_f, const int32_t* rec_i) {
+  if (!c) return SAG_ERR_ARG;
+  int rc = upload_records(c, env_ids, n, rec_f, rec_i);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
+                     env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 1);
+  // keep a copy for sag_reset: read the installed state back into the AoS layout store
+  hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
+                     env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i);
+  HIPCHK(c, hipGetLastError());
+  // scatter the staged records into L_f/L_i rows by env id (host loop of async copies would be
+  // slow; records are contiguous when env_ids == NULL, the common case)
+  if (!env_ids) {
+    HIPCHK(c, hipMemcpyAsync(c->L_f, c->st_f, (size_t)n * SAG_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->L_i, c->st_i, (size_t)n * SAG_REC_INTS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    for (int k = 0; k < n; k++) {
+      HIPCHK(c, hipMemcpyAsync(c->L_f + (size_t)env_ids[k] * SAG_REC_FLOATS, c->st_f + (size_t)k * SAG_REC_FLOATS,
+                               SAG_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->L_i + (size_t)env_ids[k] * SAG_REC_INTS, c->st_i + (size_t)k * SAG_REC_INTS,
+                               SAG_REC_INTS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_layout = true;
+  return SAG_OK;
+}
+
+int sag_set_state(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* rec_f, const int32_t* rec_i) {
+  if (!c) return SAG_ERR_ARG;
+  int rc = upload_records(c, env_ids, n, rec_f, rec_i);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
+                     env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 0);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->have_layout = true;
+  return SAG_OK;
+}
+
+int sag_get_state(sag_ctx* c, const int32_t* env_ids, int32_t n, float* rec_f, int32_t* rec_i) {
+  if (!c) return SAG_ERR_ARG;
+  if (n <= 0 || n > c->N || !rec_f || !rec_i) return fail(c, SAG_ERR_ARG, "bad record batch (n=%d)", n);
+  if (env_ids)
+    for (int k = 0; k < n; k++)
+      if (env_ids[k] < 0 || env_ids[k] >= c->N) return fail(c, SAG_ERR_ARG, "env id %d out of range", env_ids[k]);
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  if (env_ids)
+    HIPCHK(c, hipMemcpyAsync(c->st_ids, env_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
+                     env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(rec_f, c->st_f, (size_t)n * SAG_REC_FLOATS * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(rec_i, c->st_i, (size_t)n * SAG_REC_INTS * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
+  if (!c) return SAG_ERR_ARG;
+  if (!c->have_layout) return fail(c, SAG_ERR_STATE, "sag_reset before sag_set_layout");
+  if (n <= 0 || n > c->N) return fail(c, SAG_ERR_ARG, "bad n=%d", n);
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  if (!env_ids) {
+    hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
+                       (const int32_t*)nullptr, n, c->L_f, c->L_i, 0);
+  } else {
+    for (int k = 0; k < n; k++)
+      if (env_ids[k] < 0 || env_ids[k] >= c->N) return fail(c, SAG_ERR_ARG, "env id %d out of range", env_ids[k]);
+    // gather the chosen layout rows into staging, then install
+    for (int k = 0; k < n; k++) {
+      HIPCHK(c, hipMemcpyAsync(c->st_f + (size_t)k * SAG_REC_FLOATS, c->L_f + (size_t)env_ids[k] * SAG_REC_FLOATS,
+                               SAG_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->st_i + (size_t)k * SAG_REC_INTS, c->L_i + (size_t)env_ids[k] * SAG_REC_INTS,
+                               SAG_REC_INTS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->st_ids, env_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
+                       c->st_ids, n, c->st_f, c->st_i, 0);
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_step_device(sag_ctx* c, const float* d_actions, const float* d_noise, int32_t nstep, float* d_obs,
+                    float* d_reward, uint8_t* d_cost, uint8_t* d_done, uint8_t* d_goal_met) {
+  if (!c) return SAG_ERR_ARG;
+  if (!c->have_layout) return fail(c, SAG_ERR_STATE, "sag_step before sag_set_layout");
+  if (!d_actions) return fail(c, SAG_ERR_ARG, "actions is NULL");
+  return launch_step(c, d_actions, d_noise, nullptr, 0, nstep, d_obs, d_reward, d_cost, d_done, d_goal_met,
+                     nullptr, 0);
+}
+
+int sag_wait(sag_ctx* c) {
+  if (!c) return SAG_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_step(sag_ctx* c, const float* actions, const float* noise, const uint32_t* tape, int32_t tape_len,
+             int32_t nstep, float* obs, float* reward, uint8_t* cost, uint8_t* done, uint8_t* goal_met,
+             int32_t* tape_used) {
+  if (!c) return SAG_ERR_ARG;
+  if (!c->have_layout) return fail(c, SAG_ERR_STATE, "sag_step before sag_set_layout");
+  if (!actions) return fail(c, SAG_ERR_ARG, "actions is NULL");
+  if (tape && tape_len <= 0) return fail(c, SAG_ERR_ARG, "tape without tape_len");
+  const size_t N = (size_t)c->N, nu = (size_t)c->rb.nu, od = (size_t)c->rb.obs_dim;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMemcpyAsync(c->d_act, actions, N * nu * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (noise) HIPCHK(c, hipMemcpyAsync(c->d_noise, noise, N * nu * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (tape) {
+    size_t need = N * (size_t)tape_len * sizeof(uint32_t);
+    if (c->tape_cap < need) {
+      if (c->d_tape) (void)hipFree(c->d_tape);
+      c->d_tape = nullptr; c->tape_cap = 0;
+      HIPCHK(c, hipMalloc(&c->d_tape, need));
+      c->tape_cap = need;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_tape, tape, need, hipMemcpyHostToDevice, c->stream));
+  }
+  int rc = launch_step(c, c->d_act, noise ? c->d_noise : nullptr, tape ? c->d_tape : nullptr, tape_len, nstep,
+                       obs ? c->d_obs : nullptr, reward ? c->d_rew : nullptr, cost ? c->d_cost : nullptr,
+                       done ? c->d_done : nullptr, goal_met ? c->d_met : nullptr,
+                       tape_used ? c->d_used : nullptr, 0);
+  if (rc) return rc;
+  if (obs) HIPCHK(c, hipMemcpyAsync(obs, c->d_obs, N * od * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (reward) HIPCHK(c, hipMemcpyAsync(reward, c->d_rew, N * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  if (cost) HIPCHK(c, hipMemcpyAsync(cost, c->d_cost, N, hipMemcpyDeviceToHost, c->stream));
+  if (done) HIPCHK(c, hipMemcpyAsync(done, c->d_done, N, hipMemcpyDeviceToHost, c->stream));
+  if (goal_met) HIPCHK(c, hipMemcpyAsync(goal_met, c->d_met, N, hipMemcpyDeviceToHost, c->stream));
+  if (tape_used) HIPCHK(c, hipMemcpyAsync(tape_used, c->d_used, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_observe(sag_ctx* c, float* obs) {
+  if (!c || !obs) return SAG_ERR_ARG;
+  if (!c->have_layout) return fail(c, SAG_ERR_STATE, "sag_observe before sag_set_layout");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  int rc = launch_step(c, nullptr, nullptr, nullptr, 0, 0, c->d_obs, nullptr, nullptr, nullptr, nullptr, nullptr, 1);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(obs, c->d_obs, (size_t)c->N * c->rb.obs_dim * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_lidar_cost(sag_ctx* c, int32_t n, int32_t K, const float* robot, const float* points,
+                   const uint8_t* group, float hazard_size, float* lidar, int32_t* bins, uint8_t* cost) {
+  if (!c) return SAG_ERR_ARG;
+  if (n <= 0 || K < 0 || !robot || (K > 0 && (!points || !group)) || !lidar || !cost)
+    return fail(c, SAG_ERR_ARG, "bad sag_lidar_cost arguments");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const size_t b_robot = (size_t)n * 3 * 4, b_pts = (size_t)n * K * 2 * 4, b_grp = ((size_t)n * K + 15) & ~(size_t)15,
+               b_lid = (size_t)n * 48 * 4, b_bins = (size_t)n * K * 4, b_cost = ((size_t)n + 15) & ~(size_t)15;
+  int rc = ensure_scratch(c, b_robot + b_pts + b_grp + b_lid + b_bins + b_cost + 256);
+  if (rc) return rc;
+  char* base = (char*)c->scratch;
+  float* d_robot = (float*)base; base += b_robot;
+  float* d_pts = (float*)base; base += b_pts;
+  float* d_lid = (float*)base; base += b_lid;
+  int32_t* d_bins = (int32_t*)base; base += b_bins;
+  uint8_t* d_grp = (uint8_t*)base; base += b_grp;
+  uint8_t* d_cost = (uint8_t*)base;
+  HIPCHK(c, hipMemcpyAsync(d_robot, robot, b_robot, hipMemcpyHostToDevice, c->stream));
+  if (K > 0) {
+    HIPCHK(c, hipMemcpyAsync(d_pts, points, b_pts, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_grp, group, (size_t)n * K, hipMemcpyHostToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts,
+                     d_grp, hazard_size, d_lid, bins ? d_bins : nullptr, d_cost);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(lidar, d_lid, b_lid, hipMemcpyDeviceToHost, c->stream));
+  if (bins && K > 0) HIPCHK(c, hipMemcpyAsync(bins, d_bins, b_bins, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cost, d_cost, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_dev_alloc(sag_ctx* c, uint64_t bytes, void** dptr) {
+  if (!c || !dptr) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMalloc(dptr, bytes));
+  return SAG_OK;
+}
+int sag_dev_free(sag_ctx* c, void* dptr) {
+  if (!c) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipFree(dptr));
+  return SAG_OK;
+}
+int sag_dev_upload(sag_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+int sag_dev_download(sag_ctx* c, void* dst, const void* src, uint64_t bytes) {
+  if (!c) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+int sag_dev_fill_actions(sag_ctx* c, float* d_actions, uint32_t step_index) {
+  if (!c || !d_actions) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(k_fill_actions, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, d_actions, c->I, c->N,
+                     c->rb.nu, (uint32_t)(c->cfg.seed & 0xffffffffu), (uint32_t)(c->cfg.seed >> 32), step_index);
+  HIPCHK(c, hipGetLastError());
+  return SAG_OK;
+}
+
+int sag_enable_timing(sag_ctx* c, int32_t on) {
+  if (!c) return SAG_ERR_ARG;
+  c->timing = on != 0;
+  return SAG_OK;
+}
+
+int sag_kernel_time_ms(sag_ctx* c, int32_t reset, double* mean_ms, int64_t* launches) {
+  if (!c) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_events(c);
+  if (mean_ms) *mean_ms = c->ev_n ? c->ev_ms / (double)c->ev_n : 0.0;
+  if (launches) *launches = c->ev_n;
+  if (reset) { c->ev_ms = 0; c->ev_n = 0; }
+  return SAG_OK;
+}
+
+}  // extern "C"

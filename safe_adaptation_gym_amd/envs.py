@@ -1,0 +1,216 @@
+"""Batched SafeAdaptationGym: the reference's make / reset / step / set_task surface
+(safe_adaptation_gym.py:21-257) over N independent environments stepped by the HIP
+kernels of libsag.so.  NumPy only; no torch.
+
+Environments never interact, so a batch is split into contiguous shards, one
+native context (= one GPU, one stream) per shard, with no collective anywhere."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from safe_adaptation_gym_amd import _native as nat
+from safe_adaptation_gym_amd.robot import Robot
+from safe_adaptation_gym_amd.tasks.task import Task
+from safe_adaptation_gym_amd.world import World
+
+TAPE_WORDS = 256  # raw generator words offered to the device per env per step (parity mode)
+
+
+class Box:
+  """Minimal stand-in for gym.spaces.Box (gym is not a dependency)."""
+
+  def __init__(self, low, high, shape, dtype=np.float32, seed=None):
+    self.low = np.broadcast_to(np.asarray(low, dtype), shape).copy()
+    self.high = np.broadcast_to(np.asarray(high, dtype), shape).copy()
+    self.shape, self.dtype = tuple(shape), dtype
+    self._rs = np.random.RandomState(seed)
+
+  def sample(self):
+    return self._rs.uniform(self.low, self.high).astype(self.dtype)
+
+  def contains(self, x):
+    x = np.asarray(x)
+    return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+def shard_ranges(n, parts):
+  """Contiguous [start, stop) ranges splitting n envs over `parts` devices."""
+  base, rem = divmod(n, parts)
+  out, s = [], 0
+  for p in range(parts):
+    e = s + base + (1 if p < rem else 0)
+    out.append((s, e))
+    s = e
+  return out
+
+
+class BatchedSafeAdaptationGym:
+  NUM_LIDAR_BINS = 16
+  LIDAR_MAX_DIST = 5.
+  BASE_SENSORS = ['accelerometer', 'velocimeter', 'gyro', 'magnetometer']
+
+  def __init__(self, robot_base, n_envs=1, rgb_observation=False, config=None, devices=None,
+               parity_rng=False, device_seed=0):
+    if rgb_observation:
+      raise NotImplementedError('rgb_observation (SURVEY 8f rank 3) is not built yet')
+    self.robot = Robot(robot_base)
+    self.n_envs = int(n_envs)
+    self.base_config = config
+    self.parity_rng = bool(parity_rng)
+    self.devices = [0] if devices is None else list(devices)
+    if self.n_envs < len(self.devices):
+      self.devices = self.devices[:self.n_envs]
+    self._ranges = shard_ranges(self.n_envs, len(self.devices))
+    self._ctx = [
+        nat.Context(self.robot.name, e - s, device=d, seed=device_seed)
+        for (s, e), d in zip(self._ranges, self.devices)
+    ]
+    self._pool = ThreadPoolExecutor(len(self._ctx)) if len(self._ctx) > 1 else None
+    self._worlds = [None] * self.n_envs
+    self._episode = 0
+    self._base_seed = int(np.random.randint(2**31))
+    self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
+    self.rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
+    self.action_space = Box(-1, 1, (self.robot.nu,), np.float32)
+    self._observation_space = None
+    self._reward_dim = 1
+
+  # -- reference surface ----------------------------------------------------------
+  @property
+  def observation_space(self):
+    if self._observation_space is None:
+      d = self.robot.obs_dim
+      lidar = 3 * self.NUM_LIDAR_BINS
+      low = np.array([0.] * lidar + [-np.inf] * (d - lidar), np.float32)
+      high = np.array([1.] * lidar + [np.inf] * (d - lidar), np.float32)
+      self._observation_space = Box(low, high, (d,), np.float32)
+    return self._observation_space
+
+  def seed(self, seed=None):
+    """Env i uses seed + i (the reference's single env uses `seed`,
+    safe_adaptation_gym.py:113-118)."""
+    self._base_seed = int(np.random.randint(2**31)) if seed is None else int(seed)
+    self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
+    self.rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
+    for w, rs in zip(self._worlds, self.rs):
+      if w is not None:
+        w.rs = rs
+
+  def set_task(self, task):
+    """A Task instance / class (every env gets its own instance of that class) or a
+    sequence of n_envs instances (heterogeneous batch)."""
+    tasks = self._expand_tasks(task)
+    self._worlds = [
+        World(rs, t, self.robot, self.base_config) for rs, t in zip(self.rs, tasks)
+    ]
+    self._reward_dim = max(t.REWARD_DIM for t in tasks)
+    self._build_world()
+
+  def reset(self, *, seed=None, return_info=False, options=None):
+    assert self._worlds[0] is not None or (options is not None and 'task' in options), (
+        'A task should be first set before reset.')
+    if seed is not None:
+      self._seeds = int(seed) + np.arange(self.n_envs, dtype=np.int64)
+    else:
+      # the reference's single env moves to seed + 1 (safe_adaptation_gym.py:97-101);
+      # a batch moves every env past the whole batch so episodes never share a seed.
+      self._seeds = self._seeds + self.n_envs
+    self.rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
+    if options is not None and 'task' in options:
+      self.set_task(options['task'])
+      return self._observe()
+    self._pull_task_state()
+    for w, rs in zip(self._worlds, self.rs):
+      w.rs = rs
+    self._build_world()
+    return self._observe()
+
+  def step(self, action):
+    """-> (obs [N, obs_dim] f32, reward [N] (or [N, 2]) f32, done [N] bool,
+    info {'cost': [N] f32, 'bound': [N] f32, 'goal_met': [N] bool})"""
+    a = np.asarray(action, np.float32).reshape(self.n_envs, self.robot.nu)
+    noise = tapes = None
+    if self.parity_rng:
+      noise = np.stack([rs.normal(size=self.robot.nu) for rs in self.rs]).astype(np.float32)
+      tapes = np.stack([_peek_words(rs, TAPE_WORDS) for rs in self.rs])
+    outs = self._map(lambda c, s, e: c.step(a[s:e], None if noise is None else noise[s:e],
+                                            None if tapes is None else tapes[s:e]))
+    obs = np.concatenate([o[0] for o in outs])
+    rew = np.concatenate([o[1] for o in outs])
+    cost = np.concatenate([o[2] for o in outs]).astype(np.float32)
+    done = np.concatenate([o[3] for o in outs]).astype(bool)
+    met = np.concatenate([o[4] for o in outs]).astype(bool)
+    if self.parity_rng:
+      used = np.concatenate([o[5] for o in outs])
+      for rs, n in zip(self.rs, used):
+        if n > TAPE_WORDS:
+          raise RuntimeError('in-step random draws exceeded the tape; raise TAPE_WORDS')
+        if n:
+          rs.randint(0, 2**32, size=int(n), dtype=np.uint32)
+    reward = rew if self._reward_dim == 2 else rew[:, 0]
+    info = {'cost': cost, 'bound': self._bounds, 'goal_met': met}
+    return obs, reward, done, info
+
+  def render(self, mode='human'):
+    raise NotImplementedError('rendering is out of scope (SURVEY 8f rank 4)')
+
+  def close(self):
+    for c in self._ctx:
+      c.close()
+    if self._pool:
+      self._pool.shutdown()
+
+  # -- state access (checkpoint / tests) ---------------------------------------------
+  def get_state(self):
+    outs = self._map(lambda c, s, e: c.get_state())
+    return np.concatenate([o[0] for o in outs]), np.concatenate([o[1] for o in outs])
+
+  def set_state(self, rec_f, rec_i):
+    self._map(lambda c, s, e: c.set_state(rec_f[s:e], rec_i[s:e]))
+
+  # -- internals ------------------------------------------------------------------------
+  def _expand_tasks(self, task):
+    if isinstance(task, type) and issubclass(task, Task):
+      return [task() for _ in range(self.n_envs)]
+    if isinstance(task, Task):
+      return [task] + [type(task)() for _ in range(self.n_envs - 1)]
+    tasks = list(task)
+    assert len(tasks) == self.n_envs, 'one task per env'
+    return tasks
+
+  def _map(self, fn):
+    jobs = list(zip(self._ctx, self._ranges))
+    if self._pool is None:
+      return [fn(c, s, e) for c, (s, e) in jobs]
+    return list(self._pool.map(lambda j: fn(j[0], j[1][0], j[1][1]), jobs))
+
+  def _build_world(self):
+    rf = np.zeros((self.n_envs, nat.REC_FLOATS), np.float32)
+    ri = np.zeros((self.n_envs, nat.REC_INTS), np.int32)
+    for i, w in enumerate(self._worlds):
+      w.sample_layout()
+      w.reset()
+      rf[i], ri[i] = w.record(env_id=i)
+    self._bounds = np.array([w.bound for w in self._worlds], np.float32)
+    self._map(lambda c, s, e: c.set_layout(rf[s:e], ri[s:e]))
+
+  def _pull_task_state(self):
+    """Task attributes that outlive an episode in the reference because they live on
+    the Task object, not in the simulator: PressButtons._state (press_buttons.py:23),
+    CatchGoal radii and timer (catch_goal.py:14-18)."""
+    rf, ri = self.get_state()
+    for i, w in enumerate(self._worlds):
+      st = w.task_state
+      st['btn_state'] = int(ri[i, nat.I_BTN_STATE])
+      st['catch_timer'] = int(ri[i, nat.I_CATCH_TIMER])
+      st['catch_cur'] = float(rf[i, nat.F_CATCH + 2])
+      st['catch_next'] = float(rf[i, nat.F_CATCH + 3])
+
+  def _observe(self):
+    return np.concatenate(self._map(lambda c, s, e: c.observe()))
+
+
+def _peek_words(rs, n):
+  c = np.random.RandomState()
+  c.set_state(rs.get_state())
+  return c.randint(0, 2**32, size=n, dtype=np.uint32)

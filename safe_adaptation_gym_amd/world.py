@@ -1,0 +1,153 @@
+"""Host-side world: config, placements, rejection-sampled layout and the record that
+`sag_set_layout` installs on the device.
+
+Mirrors what the reference's World does at construction / reset time (world.py:36-137,
+172-217) with the same RandomState draw order, so a given seed yields
+the reference's layout; pinned by tests/golden/resets.json.gz.  The per-step half of
+World (compute_cost / compute_reward / set_mocaps / body_positions, world.py:139-165,
+219-231) lives in the step kernel."""
+from copy import deepcopy
+from types import SimpleNamespace
+
+import numpy as np
+
+from safe_adaptation_gym_amd import _native as nat
+from safe_adaptation_gym_amd import consts, utils
+
+
+class World:
+  DEFAULT = consts.WORLD_DEFAULT
+
+  def __init__(self, rs, task, robot, config=None):
+    config = {} if config is None else dict(config)
+    unknown = set(config) - set(self.DEFAULT)
+    if unknown:
+      # the reference silently accepts anything (world.py:43-44); a typo there is a
+      # silent no-op, here it is an error.
+      raise KeyError(f'unknown world config keys: {sorted(unknown)}')
+    cfg = deepcopy(self.DEFAULT)
+    cfg.update(config)
+    if robot.name == 'doggo':
+      cfg['placements_margin'] += 0.165  # world.py:45-46
+    self.config = SimpleNamespace(**cfg)
+    self.task, self.rs, self.robot = task, rs, robot
+    sizes = [cfg['hazards_size'], cfg['vases_size'], cfg['gremlins_size'], cfg['pillars_size']]
+    keeps = [cfg['hazards_keepout'], cfg['vases_keepout'], cfg['gremlins_keepout'],
+             cfg['pillars_keepout']]
+    self._obstacle_sizes = dict(zip(consts.OBSTACLES, sizes))
+    # keepout is never smaller than the object (world.py:60-69)
+    self._obstacle_keepouts = {k: max(ko, sz) for k, ko, sz in zip(consts.OBSTACLES, keeps, sizes)}
+    self._obstacle_keepouts['robot'] = cfg['robot_keepout']
+    self._placements = self._setup_placements()
+    self._robot_ctrl_range_scale = (
+        task.ctrl_scale(rs, robot.nu) * cfg['robot_ctrl_range_scale'] + 1.0)  # world.py:72-73
+    self._layout = None
+    self.bound = (task.constraint_bound(rs, cfg['max_bound']) if cfg['random_bound'] else
+                  cfg['max_bound'])
+    self.rots = {}
+    self.robot_rot = 0.0
+    self.task_state = {}
+
+  def _setup_placements(self):
+    placements = {'robot': (None, self._obstacle_keepouts['robot'])}
+    for kind, num in zip(consts.OBSTACLES, self.task.obstacles):
+      for i in range(num):
+        placements[f'{kind}{i}'] = (None, self._obstacle_keepouts[kind])
+    for k, v in self.task.setup_placements().items():
+      if k in placements and placements[k] != v:
+        raise Exception(f'Conflict at {k}')
+      placements[k] = v
+    return placements
+
+  # -- layout -------------------------------------------------------------------
+  def _try_layout(self, extents):
+    margin = self.config.placements_margin
+    layout = {}
+    for name, (rects, keepout) in self._placements.items():
+      for _ in range(1000):
+        xy = utils.draw_placement(self.rs, rects, extents, keepout)
+        if all(np.linalg.norm(xy - o) >= self._placements[n][1] + margin + keepout
+               for n, o in layout.items()):
+          layout[name] = xy
+          break
+      else:
+        return None
+    return layout
+
+  def _generate_new_layout(self):
+    extents = self.task.placement_extents
+    for _ in range(10000):
+      layout = self._try_layout(extents)
+      if layout is not None:
+        return layout
+    # The reference would now enlarge the extents (world.py:180-188), but its code
+    # raises TypeError there for every task that has a fixed placement rectangle
+    # (all of them).  Fail with the error the reference means.
+    raise utils.ResamplingError('Failed to generate layout')
+
+  def sample_layout(self):
+    """sample_layout + _build_world_config (world.py:104-137): positions, then the
+    yaw draws: robot, obstacles in layout order, then the task's bodies."""
+    self._layout = self._generate_new_layout()
+    self.robot_rot = utils.random_rot(self.rs)
+    self.rots = {}
+    for name in self._layout:
+      if any(k in name for k in ('vase', 'gremlin', 'hazard', 'pillar')):
+        self.rots[name] = utils.random_rot(self.rs)
+    self.rots.update(self.task.draw_world_config(self._layout, self.rs))
+    return self._layout
+
+  def reset(self):
+    """World.reset -> task.reset (world.py:167-170), host half."""
+    self.task.reset(self._layout, self._placements, self.rs, self.task_state)
+
+  # -- device record ----------------------------------------------------------------
+  def record(self, env_id=0):
+    """The sag.h record for this world (what rebuild() + World.reset() install)."""
+    t, lay, cfg = self.task, self._layout, self.config
+    rf = np.zeros(nat.REC_FLOATS, np.float32)
+    ri = np.zeros(nat.REC_INTS, np.int32)
+    nH, nV, _, nP = t.obstacles
+    ri[nat.I_TASK], ri[nat.I_NH], ri[nat.I_NV], ri[nat.I_NP] = t.TASK_ID, nH, nV, nP
+    ri[nat.I_NB], ri[nat.I_BOX_KIND] = t.NUM_BUTTONS, t.BOX_KIND
+    ri[nat.I_ENV_ID] = env_id
+    st = self.task_state
+    ri[nat.I_GOAL_BUTTON] = st.get('goal_button', 0)
+    ri[nat.I_BTN_STATE] = st.get('btn_state', 1)
+    ri[nat.I_BTN_TIMER] = st.get('btn_timer', 0)
+    ri[nat.I_CATCH_TIMER] = st.get('catch_timer', 0)
+    ri[nat.I_ACTIVE_MASK] = st.get('active_mask', 0)
+    rf[nat.F_ROBOT:nat.F_ROBOT + 2] = lay['robot']
+    rf[nat.F_ROBOT + 2] = self.robot_rot
+    rf[nat.F_ROBOT0:nat.F_ROBOT0 + 3] = rf[nat.F_ROBOT:nat.F_ROBOT + 3]
+    rf[nat.F_GEAR], rf[nat.F_DAMP] = t.GEAR, t.DAMPING
+    rf[nat.F_ACTION_NOISE] = cfg.action_noise
+    rf[nat.F_CTRL_SCALE:nat.F_CTRL_SCALE + nat.MAX_NU] = 1.0
+    rf[nat.F_CTRL_SCALE:nat.F_CTRL_SCALE + self.robot.nu] = self._robot_ctrl_range_scale
+    rf[nat.F_HAZARD_SIZE] = cfg.hazards_size
+    rf[nat.F_VASE_SIZE] = cfg.vases_size
+    rf[nat.F_PILLAR_SIZE] = cfg.pillars_size
+    rf[nat.F_KEEPOUT:nat.F_KEEPOUT + 4] = [
+        self._obstacle_keepouts['robot'], self._obstacle_keepouts['hazards'],
+        self._obstacle_keepouts['vases'], self._obstacle_keepouts['pillars']
+    ]
+    rf[nat.F_KEEPOUT + 4] = self._placements['box'][1] if 'box' in self._placements else 0.0
+    if 'goal' in lay:
+      rf[nat.F_GOAL:nat.F_GOAL + 2] = lay['goal']
+    rf[nat.F_CATCH:nat.F_CATCH + 2] = st.get('catch_origin', (0., 0.))
+    rf[nat.F_CATCH + 2] = st.get('catch_cur', 1.0)   # catch_goal.py:15 MAX_RADIUS
+    rf[nat.F_CATCH + 3] = st.get('catch_next', 0.2)  # catch_goal.py:16 MIN_RADIUS
+    if 'box' in lay:
+      rf[nat.F_BOX:nat.F_BOX + 2] = lay['box']
+      rf[nat.F_BOX + 2] = self.rots.get('box', 0.0)
+    for k in range(nH):
+      rf[nat.F_HAZARDS + 2 * k:nat.F_HAZARDS + 2 * k + 2] = lay[f'hazards{k}']
+    for k in range(nP):
+      rf[nat.F_PILLARS + 2 * k:nat.F_PILLARS + 2 * k + 2] = lay[f'pillars{k}']
+    for k in range(t.NUM_BUTTONS):
+      rf[nat.F_BUTTONS + 2 * k:nat.F_BUTTONS + 2 * k + 2] = lay[f'buttons{k}']
+    for k in range(nV):
+      o = nat.F_VASES + 6 * k
+      rf[o:o + 2] = lay[f'vases{k}']
+      rf[o + 2] = self.rots[f'vases{k}']
+    return rf, ri

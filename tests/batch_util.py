@@ -1,0 +1,47 @@
+"""Builds batches of layouts with the package's host sampler (reference semantics,
+seed base 666) for the parity tests and the bench."""
+import numpy as np
+
+from safe_adaptation_gym_amd import _native as nat
+from safe_adaptation_gym_amd import benchmark
+from safe_adaptation_gym_amd.robot import Robot
+from safe_adaptation_gym_amd.world import World
+
+
+def sample_records(robot_name, task_name, n, seed=666, config=None):
+  """n records: env i sampled with RandomState(seed + i) exactly as make() would."""
+  robot = Robot(f'xmls/{robot_name}.xml')
+  rf = np.zeros((n, nat.REC_FLOATS), np.float32)
+  ri = np.zeros((n, nat.REC_INTS), np.int32)
+  for i in range(n):
+    rs = np.random.RandomState(seed + i)
+    task = benchmark.TASKS[task_name]() if isinstance(task_name, str) else benchmark.TASKS[task_name[i]]()
+    w = World(rs, task, robot, config)
+    w.sample_layout()
+    w.reset()
+    rf[i], ri[i] = w.record(env_id=i)
+  return rf, ri
+
+
+def pursuit_actions(rf, ri, rng, p_random=0.2):
+  """A policy that drives Point robots towards their current target with noise, so
+  goals are met and obstacles are hit: u0 = forward, u1 = turn rate command."""
+  n = len(rf)
+  x, y, yaw = rf[:, nat.F_ROBOT], rf[:, nat.F_ROBOT + 1], rf[:, nat.F_ROBOT + 2]
+  tx, ty = rf[:, nat.F_GOAL].copy(), rf[:, nat.F_GOAL + 1].copy()
+  nb = ri[:, nat.I_NB]
+  for i in np.flatnonzero(nb > 0):
+    task = ri[i, nat.I_TASK]
+    if task == 1:  # collect: lowest active button
+      m = ri[i, nat.I_ACTIVE_MASK]
+      b = (m & -m).bit_length() - 1 if m else 0
+    else:
+      b = ri[i, nat.I_GOAL_BUTTON]
+    tx[i], ty[i] = rf[i, nat.F_BUTTONS + 2 * b], rf[i, nat.F_BUTTONS + 2 * b + 1]
+  ang = np.arctan2(ty - y, tx - x) - yaw
+  ang = (ang + np.pi) % (2 * np.pi) - np.pi
+  a = np.stack([np.where(np.abs(ang) < 1.0, 1.0, 0.2), np.clip(2.0 * ang, -1, 1)], -1)
+  rnd = rng.uniform(-1, 1, (n, 2))
+  pick = rng.uniform(size=n) < p_random
+  a[pick] = rnd[pick]
+  return a.astype(np.float32)

@@ -75,6 +75,11 @@ class Oracle:
         C.POINTER(OEnv), C.c_int, C.c_int, fp, C.c_uint32, C.c_uint32, fp, fp, bp, bp, bp,
         C.c_int
     ]
+    lib.sago_step_batch_full.argtypes = [
+        C.POINTER(OEnv), C.c_int, C.c_int, fp, fp, up, C.c_int, C.c_uint32, C.c_uint32, C.c_int,
+        fp, fp, bp, bp, bp, ip, dp
+    ]
+    lib.sago_observe_batch.argtypes = [C.POINTER(OEnv), C.c_int, C.c_int, fp]
     lib.sago_noise.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, fp]
     lib.sago_actions.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, fp]
     lib.sago_philox.argtypes = [up, up, up]
@@ -198,6 +203,33 @@ class Oracle:
                              cost.ctypes.data_as(bp), done.ctypes.data_as(bp),
                              met.ctypes.data_as(bp), nthreads)
     return obs, rew, cost, done, met
+
+  def step_batch_full(self, arr, robot, actions, noise=None, tape=None, key=(0, 0), nstep=-1,
+                      obs_dim=60):
+    n = len(arr)
+    actions = np.ascontiguousarray(actions, np.float32)
+    nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
+    tp = None if tape is None else np.ascontiguousarray(tape, np.uint32).reshape(n, -1)
+    obs = np.zeros((n, obs_dim), np.float32)
+    rew = np.zeros((n, 2), np.float32)
+    cost, done, met = (np.zeros(n, np.uint8) for _ in range(3))
+    used = np.zeros(n, np.int32)
+    margin = np.zeros(n, np.float64)
+    fp, bp = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
+    self.lib.sago_step_batch_full(
+        arr, n, robot, actions.ctypes.data_as(fp),
+        None if nz is None else nz.ctypes.data_as(fp),
+        None if tp is None else tp.ctypes.data_as(C.POINTER(C.c_uint32)),
+        0 if tp is None else tp.shape[1], key[0], key[1], nstep, obs.ctypes.data_as(fp),
+        rew.ctypes.data_as(fp), cost.ctypes.data_as(bp), done.ctypes.data_as(bp),
+        met.ctypes.data_as(bp), used.ctypes.data_as(C.POINTER(C.c_int32)),
+        margin.ctypes.data_as(C.POINTER(C.c_double)))
+    return obs, rew, cost, done, met, used, margin
+
+  def observe_batch(self, arr, robot, obs_dim=60):
+    obs = np.zeros((len(arr), obs_dim), np.float32)
+    self.lib.sago_observe_batch(arr, len(arr), robot, obs.ctypes.data_as(C.POINTER(C.c_float)))
+    return obs
 
   def noise(self, key, env_id, step, nu):
     out = np.zeros(nu + 1, np.float32)

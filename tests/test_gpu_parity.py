@@ -1,0 +1,315 @@
+"""HIP path (libsag.so through the C ABI) vs the CPU oracle and the golden fixtures.
+Run on an MI355X: python -m pytest tests -m gpu."""
+import numpy as np
+import pytest
+
+import batch_util as bu
+import golden_util as gu
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+OBS_TOL = 2e-5     # fp32 state -> fp64 lidar closeness, sensors
+STATE_TOL = 1e-4   # one-step qpos/qvel: HIP fp32 vs oracle fp64 from the same fp32 state
+REW_TOL = 2e-6
+
+
+@pytest.fixture(scope='module')
+def nat():
+  from safe_adaptation_gym_amd import _native
+  if _native.device_count() < 1:
+    pytest.fail('no HIP device visible: the GPU tests need an MI355X')
+  return _native
+
+
+@pytest.fixture(scope='module')
+def oracle():
+  return Oracle()
+
+
+# ----------------------------------------------------------------------------------
+# BASELINE config 2: lidar + hazard cost kernel, 4096 envs
+# ----------------------------------------------------------------------------------
+def _lidar_inputs(n, K, seed):
+  rs = np.random.RandomState(seed)
+  robot = np.concatenate([rs.uniform(-2, 2, (n, 2)), rs.uniform(0, 2 * np.pi, (n, 1))], 1).astype(np.float32)
+  pts = rs.uniform(-2.5, 2.5, (n, K, 2)).astype(np.float32)
+  grp = rs.randint(0, 4, (n, K)).astype(np.uint8)
+  haz = (grp == 1) & (rs.uniform(size=(n, K)) < 0.5)
+  grp = (grp | (haz.astype(np.uint8) << 7)).astype(np.uint8)
+  # make hazard hits common: pull some hazards next to the robot
+  near = haz & (rs.uniform(size=(n, K)) < 0.1)
+  pts[near] = (robot[:, None, :2] + rs.uniform(-0.25, 0.25, (n, K, 2)).astype(np.float32))[near]
+  return robot, pts, grp
+
+
+def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle):
+  n, K = 4096, 21
+  robot, pts, grp = _lidar_inputs(n, K, 1)
+  ctx = nat.Context('point', n)
+  lidar, bins, cost = ctx.lidar_cost(robot, pts, grp)
+  o_lidar, o_bins, o_cost = oracle.lidar_cost(robot, pts, grp)
+  np.testing.assert_array_equal(bins, o_bins)          # bit-exact bin indices
+  np.testing.assert_array_equal(cost, o_cost)          # bit-exact cost flags
+  assert 0.05 < cost.mean() < 0.95
+  np.testing.assert_allclose(lidar, o_lidar, rtol=0, atol=1e-6)
+  ctx.close()
+
+
+def test_lidar_cost_kernel_golden_planar_cases(nat):
+  """Reference-generated cases (tests/golden/lidar.npz) that a planar robot can express."""
+  z = np.load(gu.GOLDEN + '/lidar.npz')
+  ctx = nat.Context('point', 64)
+  checked = 0
+  for i in range(len(z['count'])):
+    m, k = z['robot_mat'][i], int(z['count'][i])
+    planar = abs(m[2, 2] - 1) < 1e-15 and k > 0
+    if not planar:
+      continue
+    yaw = np.arctan2(m[1, 0], m[0, 0])
+    f32 = lambda a: np.asarray(a, np.float32)
+    if not (np.array_equal(f32(z['robot_pos'][i][:2]), z['robot_pos'][i][:2]) and
+            np.array_equal(f32(z['points'][i, :k]), z['points'][i, :k]) and float(np.float32(yaw)) == yaw):
+      continue  # inputs not exactly representable in the fp32 ABI
+    lidar, bins, _ = ctx.lidar_cost(np.r_[z['robot_pos'][i][:2], yaw][None], z['points'][i, :k][None],
+                                    np.ones((1, k), np.uint8))
+    want = z['bins'][i, :k]
+    ok = want >= 0
+    np.testing.assert_array_equal(bins[0][ok], want[ok], err_msg=f'case {i}')
+    np.testing.assert_allclose(lidar[0, :16], z['obs'][i], rtol=0, atol=1e-6)
+    checked += 1
+  assert checked >= 20
+  ctx.close()
+
+
+def test_lidar_cost_empty_and_ragged(nat, oracle):
+  ctx = nat.Context('point', 8)
+  robot = np.zeros((3, 3), np.float32)
+  lidar, bins, cost = ctx.lidar_cost(robot, np.zeros((3, 0, 2), np.float32), np.zeros((3, 0), np.uint8))
+  assert not lidar.any() and not cost.any()
+  # ragged: inactive slots (group 0) are ignored and report bin -1
+  pts = np.array([[[1, 0], [0, 1], [9, 9]]] * 3, np.float32)
+  grp = np.array([[1, 0, 0], [1, 2, 0], [0, 0, 0]], np.uint8)
+  lidar, bins, cost = ctx.lidar_cost(robot, pts, grp)
+  o = oracle.lidar_cost(robot, pts, grp)
+  np.testing.assert_array_equal(bins, o[1])
+  np.testing.assert_allclose(lidar, o[0], atol=1e-7)
+  assert (bins[2] == -1).all() and bins[0, 0] == 0 and bins[1, 1] == 4
+  ctx.close()
+
+
+# ----------------------------------------------------------------------------------
+# full step: lockstep against the oracle
+# ----------------------------------------------------------------------------------
+LOCKSTEP_TASKS = ['go_to_goal', 'go_to_goal_scarce', 'go_to_goal_motor', 'go_to_goal_damping',
+                  'catch_goal', 'unsupervised', 'press_buttons', 'press_buttons_scarce', 'collect']
+
+
+def _flags_agree(dev, orc, margin, tol=1e-5):
+  """Flags must be equal unless the oracle says the decision sits within tol of its threshold."""
+  bad = (dev != orc) & (margin > tol)
+  return int(bad.sum()), int((dev != orc).sum())
+
+
+@pytest.mark.parametrize('task', LOCKSTEP_TASKS)
+def test_step_lockstep_vs_oracle(nat, oracle, task):
+  """Every step: take the device state, advance BOTH from it with identical action /
+  noise / random tape, compare outputs and next state, continue from the device state."""
+  n, T = 192, 160
+  rf, ri = bu.sample_records('point', task, n, seed=666)
+  ctx = nat.Context('point', n, seed=1234)
+  ctx.set_layout(rf, ri)
+  rng = np.random.RandomState(7)
+  mt = np.random.RandomState(99)
+  obs0 = ctx.observe()
+  rf, ri = ctx.get_state()
+  arr = oracle.make_batch(rf, ri)
+  np.testing.assert_allclose(obs0, oracle.observe_batch(arr, 0), rtol=0, atol=OBS_TOL)
+  n_met = n_cost = n_near = 0
+  for t in range(T):
+    rf, ri = ctx.get_state()
+    arr = oracle.make_batch(rf, ri)
+    act = bu.pursuit_actions(rf, ri, rng)
+    noise = mt.normal(size=(n, 2)).astype(np.float32)
+    tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
+    d_obs, d_rew, d_cost, d_done, d_met, d_used = ctx.step(act, noise, tape)
+    o_obs, o_rew, o_cost, o_done, o_met, o_used, o_margin = oracle.step_batch_full(arr, 0, act, noise, tape)
+    d_rf, d_ri = ctx.get_state()
+    o_rf, o_ri = oracle.batch_records(arr)
+    # discrete outputs
+    np.testing.assert_array_equal(d_done, o_done)
+    np.testing.assert_array_equal(d_met, o_met, err_msg=f'goal_met step {t}')
+    np.testing.assert_array_equal(d_used, o_used)
+    hard, soft = _flags_agree(d_cost, o_cost, o_margin)
+    assert hard == 0, f'cost flag mismatch away from the threshold at step {t}'
+    n_near += soft
+    # continuous outputs
+    same = d_met == o_met
+    np.testing.assert_allclose(d_rew[same], o_rew[same], rtol=0, atol=REW_TOL + 1e-4 * 0, err_msg=f'reward step {t}')
+    np.testing.assert_allclose(d_obs[:, :48], o_obs[:, :48], rtol=0, atol=OBS_TOL, err_msg=f'lidar step {t}')
+    np.testing.assert_allclose(d_obs[:, 50:], o_obs[:, 50:], rtol=0, atol=1e-4, err_msg=f'sensors step {t}')
+    np.testing.assert_allclose(d_obs[:, 48:50], o_obs[:, 48:50], rtol=2e-3, atol=2e-3, err_msg=f'accel step {t}')
+    # next state: positions/velocities within the stated fp32 tolerance, ints exact
+    np.testing.assert_array_equal(d_ri, o_ri, err_msg=f'task ints step {t}')
+    np.testing.assert_allclose(d_rf, o_rf, rtol=STATE_TOL, atol=STATE_TOL, err_msg=f'state step {t}')
+    n_met += int(d_met.sum())
+    n_cost += int(d_cost.sum())
+  assert n_met > 20, 'the rollout should exercise goal-met events'
+  assert n_cost > 20, 'the rollout should exercise cost events'
+  assert n_near <= 0.001 * n * T
+  ctx.close()
+
+
+# ----------------------------------------------------------------------------------
+# golden episodes (reference step() with scripted poses) through the device
+# ----------------------------------------------------------------------------------
+GOAL_FAMILY = ['go_to_goal', 'go_to_goal_scarce', 'go_to_goal_motor', 'go_to_goal_damping',
+               'catch_goal', 'unsupervised']
+
+
+@pytest.mark.parametrize('task', GOAL_FAMILY)
+def test_golden_episode_on_device(nat, task):
+  """For the goal family nothing but `cost` depends on contacts, so reward, lidar,
+  goal resampling and RNG consumption can be checked against the reference directly."""
+  from oracle_lib import F_GOAL, F_LAST
+  ep = [e for e in gu.load_json_gz('episodes.json.gz') if e['robot'] == 'point' and e['task'] == task][0]
+  names = ep['names']
+  rf, ri = gu.episode_init_record(ep)
+  ctx = nat.Context('point', 1)
+  ctx.set_state(rf[None].astype(np.float32), ri[None])
+  rs = gu.rs_from_dump(ep['rs_state'])
+  obs0 = ctx.observe()[0]
+  np.testing.assert_allclose(obs0[:48], ep['init_obs'][:48], rtol=0, atol=OBS_TOL)
+  for t, st in enumerate(ep['steps']):
+    noise = rs.normal(size=2)
+    tape = gu.rs_words(gu.rs_copy(rs), 256)
+    rf, ri = ctx.get_state()
+    rf = rf[0].astype(np.float64)
+    gu.set_poses(rf, names, st['pos'], yaw=st['robot_yaw'], v0=st['robot_v0'], wz=st['sensors']['gyro'][2])
+    # the goal is task state: keep the device's own (resampled) goal, not the fixture's
+    ctx.set_state(rf[None].astype(np.float32), ri)
+    obs, rew, cost, done, met, used = ctx.step(np.array([st['action']], np.float32), noise[None], tape[None], nstep=0)
+    gu.rs_words(rs, int(used[0]))
+    assert gu.rs_probe(rs) == st['rs_probe'], f'RNG position diverged at step {t}'
+    nr = len(st['reward'])
+    np.testing.assert_allclose(rew[0, :nr], st['reward'], rtol=0, atol=3e-6, err_msg=f'step {t}')
+    np.testing.assert_allclose(obs[0, :48], st['obs'][:48], rtol=0, atol=OBS_TOL, err_msg=f'step {t}')
+    np.testing.assert_allclose(obs[0, 50:60], st['obs'][50:60], rtol=0, atol=1e-5)
+    rf2, _ = ctx.get_state()
+    g = st['pos'][names.index('goal')]
+    np.testing.assert_allclose(rf2[0, F_GOAL:F_GOAL + 2], g[:2], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rf2[0, F_LAST], st['task_state']['_last_goal_distance'], rtol=0, atol=1e-6)
+  ctx.close()
+
+
+# ----------------------------------------------------------------------------------
+# API behaviour
+# ----------------------------------------------------------------------------------
+def test_state_roundtrip_reset_and_errors(nat):
+  n = 130  # not a multiple of the wavefront
+  rf, ri = bu.sample_records('point', 'go_to_goal', n)
+  ctx = nat.Context('point', n)
+  with pytest.raises(nat.SagError, match='before sag_set_layout'):
+    ctx.step(np.zeros((n, 2), np.float32))
+  ctx.set_layout(rf, ri)
+  g_rf, g_ri = ctx.get_state()
+  exp = rf.copy()
+  exp[:, 38] = np.hypot(rf[:, 0] - rf[:, 32], rf[:, 1] - rf[:, 33])  # task.reset installs `last`
+  np.testing.assert_allclose(g_rf, exp, rtol=0, atol=1e-6)
+  np.testing.assert_array_equal(g_ri, ri)
+  a = np.random.RandomState(0).uniform(-1, 1, (n, 2)).astype(np.float32)
+  out1 = [ctx.step(a) for _ in range(5)]
+  ctx.reset()
+  r_rf, r_ri = ctx.get_state()
+  np.testing.assert_array_equal(r_rf, g_rf)
+  np.testing.assert_array_equal(r_ri, g_ri)
+  out2 = [ctx.step(a) for _ in range(5)]
+  for x, y in zip(out1, out2):  # counter-based RNG: identical replay
+    for u, v in zip(x[:5], y[:5]):
+      np.testing.assert_array_equal(u, v)
+  # subset set_state / get_state by env id
+  ids = np.array([5, 129, 64], np.int32)
+  s_rf, s_ri = ctx.get_state(ids)
+  s_rf[:, 0] += 1.0
+  ctx.set_state(s_rf, s_ri, ids)
+  np.testing.assert_array_equal(ctx.get_state(ids)[0], s_rf)
+  with pytest.raises(nat.SagError):
+    ctx.get_state(np.array([n], np.int32))
+  bad = ri.copy(); bad[0, 2] = 11
+  with pytest.raises(nat.SagError, match='capacit'):
+    ctx.set_layout(rf, bad)
+  ctx.close()
+  with pytest.raises(nat.SagError):
+    nat.Context('point', 4, device=99)
+
+
+def test_physics_error_is_data(nat):
+  """Non-finite state -> (reward -10, done, cost 0) for that env only (safe_adaptation_gym.py:73-75)."""
+  n = 70
+  rf, ri = bu.sample_records('point', 'go_to_goal', n)
+  ctx = nat.Context('point', n)
+  ctx.set_layout(rf, ri)
+  s_rf, s_ri = ctx.get_state()
+  s_rf[3, 3] = np.nan
+  s_rf[66, 0] = np.inf
+  ctx.set_state(s_rf, s_ri)
+  obs, rew, cost, done, met, _ = ctx.step(np.zeros((n, 2), np.float32))
+  assert done[3] == 1 and done[66] == 1 and done.sum() == 2
+  assert rew[3, 0] == -10 and rew[66, 0] == -10 and cost[3] == 0
+  ok = np.ones(n, bool); ok[[3, 66]] = False
+  assert np.isfinite(obs[ok]).all() and np.isfinite(rew[ok]).all()
+  ctx.close()
+
+
+def test_env_api_shapes_and_reference_surface(nat):
+  import safe_adaptation_gym_amd as sag
+  env = sag.make('point', 'go_to_goal', seed=666, n_envs=100)
+  assert env.action_space.shape == (2,) and env.observation_space.shape == (60,)
+  obs = env.reset()
+  assert obs.shape == (100, 60) and obs.dtype == np.float32
+  a = np.stack([env.action_space.sample() for _ in range(100)])
+  obs, reward, done, info = env.step(a)
+  assert obs.shape == (100, 60) and reward.shape == (100,) and done.shape == (100,)
+  assert set(info) >= {'cost', 'bound'} and (info['bound'] == 25).all()
+  assert np.all((obs[:, :48] >= 0) & (obs[:, :48] <= 1))
+  env.set_task(sag.tasks.Unsupervised)
+  obs, reward, done, info = env.step(a)
+  assert reward.shape == (100, 2)
+  from safe_adaptation_gym_amd import benchmark
+  bm = benchmark.make('multitask', batch_size=3, seed=1)
+  for name, task in bm.train_tasks:
+    if task.BOX_KIND:
+      continue
+    obs = env.reset(options={'task': task})
+    assert obs.shape == (100, 60)
+  env.close()
+
+
+def test_parity_rng_mode_matches_reference_draw_order(nat, oracle):
+  """make(parity_rng=True): noise and in-step draws come from per-env RandomState in the
+  reference's order; stepping the oracle with the same generators gives the same result."""
+  import safe_adaptation_gym_amd as sag
+  n = 16
+  env = sag.make('point', 'go_to_goal', seed=666, n_envs=n, parity_rng=True)
+  env.reset(seed=666)
+  rf, ri = env.get_state()
+  arr = oracle.make_batch(rf, ri)
+  rss = [np.random.RandomState() for _ in range(n)]
+  for r, e in zip(rss, env.rs):
+    r.set_state(e.get_state())
+  rng = np.random.RandomState(3)
+  for t in range(60):
+    rf, ri = env.get_state()
+    act = bu.pursuit_actions(rf, ri, rng, p_random=0.05)
+    obs, rew, done, info = env.step(act)
+    noise = np.stack([r.normal(size=2) for r in rss]).astype(np.float32)
+    tape = np.stack([gu.rs_words(gu.rs_copy(r), 256) for r in rss])
+    arr = oracle.make_batch(rf, ri)
+    o = oracle.step_batch_full(arr, 0, act, noise, tape)
+    for r, u in zip(rss, o[5]):
+      gu.rs_words(r, int(u))
+    np.testing.assert_array_equal(info['goal_met'], o[4].astype(bool))
+    np.testing.assert_allclose(rew, o[1][:, 0], rtol=0, atol=1e-5)
+    for r, e in zip(rss, env.rs):
+      assert gu.rs_probe(r) == gu.rs_probe(e)
+  env.close()

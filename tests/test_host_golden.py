@@ -1,0 +1,107 @@
+"""Host logic (layout sampler, RNG draw order, registry, samplers) against fixtures
+generated from the reference (tests/golden/resets.json.gz, sampler.json).  No GPU."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from safe_adaptation_gym_amd import benchmark
+from safe_adaptation_gym_amd.robot import Robot
+from safe_adaptation_gym_amd.world import World
+
+RESETS = gu.load_json_gz('resets.json.gz')
+
+
+def test_registry_matches_reference():
+  ref = gu.load_json('sampler.json')
+  assert list(benchmark.TASKS.keys()) == ref['tasks_order']
+  assert {k: v.__name__ for k, v in benchmark.TASKS.items()} == ref['tasks_class']
+  assert list(benchmark.TASKS.keys()) == gu.TASKS
+
+
+@pytest.mark.parametrize('name', ['multitask', 'task_adaptation'])
+@pytest.mark.parametrize('seed', [666, 7])
+def test_task_sampler_sequences(name, seed):
+  ref = gu.load_json('sampler.json')[f'{name}_{seed}']
+  bm = benchmark.make(name, batch_size=12, seed=seed)
+  assert [n for n, _ in bm.train_tasks] == ref['train']
+  assert [n for n, _ in bm.test_tasks] == ref['test']
+  assert [n for n, _ in bm.train_tasks] == ref['train2']
+
+
+def test_stale_reference_benchmark_name_rejected():
+  # reference tests/test_benchmark.py asks for 'domain_randomization', which is not a
+  # benchmark (benchmark/__init__.py:11,69): the assert fires there as it does here.
+  with pytest.raises(AssertionError):
+    benchmark.make('domain_randomization', 16)
+
+
+def _check_snapshot(world, rs, snap, rots_ref, robot_rot_ref):
+  lay = world._layout
+  assert list(lay.keys()) == snap['layout_order']
+  for k, v in snap['layout'].items():
+    np.testing.assert_allclose(lay[k], v, rtol=0, atol=0, err_msg=k)
+  assert world.robot_rot == robot_rot_ref
+  assert [world.robot_rot] + list(world.rots.values()) == rots_ref
+  assert gu.rs_probe(rs) == snap['rs_probe']
+  ts = snap['task_state']
+  st = world.task_state
+  if ts.get('_goal_button'):
+    assert st['goal_button'] == int(ts['_goal_button'][len('buttons'):])
+  if '_origin' in ts:
+    np.testing.assert_array_equal(st['catch_origin'], ts['_origin'])
+
+
+@pytest.mark.parametrize('rec', RESETS, ids=lambda r: f"{r['robot']}-{r['task']}-{r['seed']}")
+def test_layout_and_draw_order(rec):
+  """make() -> set_task -> sample_layout -> task.reset, then reset(): every position,
+  yaw, ctrl-scale draw and the generator's final position equal the reference's."""
+  robot = Robot(f"xmls/{rec['robot']}.xml")
+  rs = np.random.RandomState(rec['seed'])
+  task = benchmark.TASKS[rec['task']]()
+  world = World(rs, task, robot)
+  np.testing.assert_array_equal(np.ravel(world._robot_ctrl_range_scale), rec['ctrl_range_scale'])
+  assert world.bound == rec['bound']
+  assert world.config.placements_margin == rec['placements_margin']
+  assert {k: v[1] for k, v in world._placements.items()} == rec['keepouts']
+  assert list(task.obstacles) == rec['obstacles']
+  assert [float(x) for x in task.placement_extents] == rec['extents']
+  world.sample_layout()
+  world.reset()
+  _check_snapshot(world, rs, rec['first'], rec['rots'], rec['robot_rot'])
+  # second episode: seed + 1, fresh RandomState, same World/Task (safe_adaptation_gym.py:97-107)
+  rs2 = np.random.RandomState(rec['seed'] + 1)
+  world.rs = rs2
+  world.sample_layout()
+  world.reset()
+  _check_snapshot(world, rs2, rec['second'], rec['second']['rots'], rec['second']['robot_rot'])
+
+
+def test_unknown_config_key_rejected():
+  with pytest.raises(KeyError):
+    World(np.random.RandomState(0), benchmark.TASKS['go_to_goal'](), Robot('xmls/point.xml'),
+          {'hazard_size': 0.3})
+
+
+def test_impossible_layout_raises_resampling_error():
+  # reference tests/test_layout_sampling.py:71-78 (obstacle sizes 2.0)
+  from safe_adaptation_gym_amd.utils import ResamplingError
+  cfg = {'hazards_size': 2.0, 'vases_size': 2.0, 'pillars_size': 2.0, 'gremlins_size': 2.0}
+  w = World(np.random.RandomState(0), benchmark.TASKS['go_to_goal'](), Robot('xmls/doggo.xml'), cfg)
+  w._generate_new_layout.__func__  # exists
+  import safe_adaptation_gym_amd.world as wm
+  # keep the test fast: the first placement after the robot can never fit, so one
+  # attempt already shows the failure mode; bound the outer loop
+  orig = wm.World._generate_new_layout
+
+  def bounded(self):
+    for _ in range(3):
+      if self._try_layout(self.task.placement_extents) is not None:
+        return
+    raise ResamplingError('Failed to generate layout')
+
+  wm.World._generate_new_layout = bounded
+  try:
+    with pytest.raises(ResamplingError):
+      w.sample_layout()
+  finally:
+    wm.World._generate_new_layout = orig

@@ -1,0 +1,157 @@
+"""Analytic known answers for the rigid-body specification (oracle/sag_oracle.c).
+The reference delegates dynamics to MuJoCo (absent here), so these pin the
+integrator to the MJCF's physics, not to MuJoCo's numbers."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle_lib import (F_GOAL, F_HAZARDS, F_PILLARS, F_ROBOT, F_VASES, I_NH, I_NP, I_NV, Oracle)
+
+
+@pytest.fixture(scope='module')
+def oracle():
+  return Oracle()
+
+
+def empty_world(task='go_to_goal', **kw):
+  names = ['robot', 'goal']
+  rf, ri = gu.base_record(task, names, {'robot': 0.4})
+  rf[F_GOAL:F_GOAL + 2] = [50., 50.]  # far away: never met
+  ri[I_NH] = ri[I_NV] = ri[I_NP] = 0
+  return rf, ri
+
+
+def run(oracle, rf, ri, action, steps, noise=(0., 0.)):
+  e = oracle.env(rf, ri)
+  outs = []
+  for _ in range(steps):
+    outs.append(oracle.step(e, 0, action, noise=noise, tape=np.zeros(8, np.uint32)))
+  return e, outs
+
+
+def test_terminal_forward_speed(oracle):
+  # motor force saturates at gear*0.05 = 0.015 N; slide damping 0.01 -> 1.5 m/s
+  rf, ri = empty_world()
+  rf[F_ROBOT + 2] = 0.7
+  e, _ = run(oracle, rf, ri, [1.0, 0.0], 400)
+  f, _ = oracle.record(e)
+  v = np.hypot(f[F_ROBOT + 3], f[F_ROBOT + 4])
+  assert abs(v - 1.5) < 1e-3
+  # heading unchanged, motion along it
+  assert abs(f[F_ROBOT + 2] - 0.7) < 1e-9
+  assert abs(np.arctan2(f[F_ROBOT + 4], f[F_ROBOT + 3]) - 0.7) < 1e-6
+
+
+def test_saturation_threshold(oracle):
+  # |ctrl| >= 0.05 saturates the motor: 0.05 and 1.0 give the same motion
+  rf, ri = empty_world()
+  a, _ = run(oracle, rf, ri, [0.05, 0.0], 50)
+  b, _ = run(oracle, rf, ri, [1.0, 0.0], 50)
+  np.testing.assert_allclose(oracle.record(a)[0], oracle.record(b)[0], atol=1e-12)
+  c, _ = run(oracle, rf, ri, [0.025, 0.0], 400)
+  f, _ = oracle.record(c)
+  assert abs(np.hypot(f[F_ROBOT + 3], f[F_ROBOT + 4]) - 0.75) < 1e-3
+
+
+def test_terminal_yaw_rate(oracle):
+  # velocity servo saturated: torque 0.3*0.05 = 0.015, hinge damping 0.005 -> 3 rad/s
+  rf, ri = empty_world()
+  e, _ = run(oracle, rf, ri, [0.0, 1.0], 400)
+  f, _ = oracle.record(e)
+  # (the COM offset makes the origin orbit, whose slide damping takes a little: 2.998)
+  assert abs(f[F_ROBOT + 5] - 3.0) < 5e-3
+
+
+@pytest.mark.parametrize('task,expect', [('go_to_goal_motor', 15.0), ('go_to_goal_damping', 15.0)])
+def test_variant_dynamics(oracle, task, expect):
+  rf, ri = empty_world(task)
+  e, _ = run(oracle, rf, ri, [1.0, 0.0], 4000)
+  f, _ = oracle.record(e)
+  assert abs(np.hypot(f[F_ROBOT + 3], f[F_ROBOT + 4]) - expect) < 0.05
+
+
+def test_free_decay_rate(oracle):
+  # zero control: m dv/dt = -d v  (implicit Euler: v <- v / (1 + h d/m) per substep)
+  rf, ri = empty_world()
+  rf[F_ROBOT + 3] = 1.0
+  e, _ = run(oracle, rf, ri, [0.0, 0.0], 10)
+  f, _ = oracle.record(e)
+  m = 4 / 3 * np.pi * 1e-3 + 1e-3
+  want = (1 + 0.004 * 0.01 / m) ** (-50)
+  assert abs(f[F_ROBOT + 3] - want) < 2e-3  # COM offset couples x/yaw slightly
+
+
+def test_pillar_stops_robot_and_costs(oracle):
+  rf, ri = empty_world()
+  ri[I_NP] = 1
+  rf[F_PILLARS:F_PILLARS + 2] = [1.0, 0.0]
+  e, outs = run(oracle, rf, ri, [1.0, 0.0], 200)
+  f, _ = oracle.record(e)
+  # arrow tip (0.15 ahead) rests on the pillar surface (x = 0.8), penetration < 1 mm
+  assert 0.65 - 1e-3 < f[F_ROBOT] < 0.65 + 1e-3
+  assert abs(f[F_ROBOT + 3]) < 1e-3
+  assert outs[-1].cost == 1 and outs[0].cost == 0
+  # accelerometer ~ 0 at rest against the pillar (drive force balanced by contact)
+  assert abs(outs[-1].obs[48]) < 0.3
+
+
+def test_vase_is_pushed_then_stops_by_floor_friction(oracle):
+  rf, ri = empty_world()
+  ri[I_NV] = 1
+  rf[F_VASES:F_VASES + 2] = [0.5, 0.0]
+  e, outs = run(oracle, rf, ri, [1.0, 0.0], 60)
+  f, _ = oracle.record(e)
+  assert f[F_VASES] > 0.6, 'vase should have been pushed along +x'
+  assert any(o.cost for o in outs), 'touching a vase is a cost event'
+  assert f[F_ROBOT] > 0.3, 'a vase (8 mg) barely slows the robot'
+  # stop pushing, back off: the vase comes to rest
+  e2, _ = run(oracle, f, _ri(oracle, e), [-1.0, 0.0], 100)
+  f2, _ = oracle.record(e2)
+  assert np.hypot(f2[F_VASES + 3], f2[F_VASES + 4]) < 1e-3
+  assert abs(f2[F_VASES + 5]) < 1e-2
+
+
+def _ri(oracle, e):
+  return oracle.record(e)[1]
+
+
+def test_hazard_is_not_a_collider(oracle):
+  rf, ri = empty_world()
+  ri[I_NH] = 1
+  rf[F_HAZARDS:F_HAZARDS + 2] = [0.5, 0.0]
+  a, outs = run(oracle, rf, ri, [1.0, 0.0], 40)
+  ri[I_NH] = 0
+  b, _ = run(oracle, rf, ri, [1.0, 0.0], 40)
+  np.testing.assert_allclose(oracle.record(a)[0][:6], oracle.record(b)[0][:6], atol=0)
+  assert any(o.cost for o in outs) and not outs[0].cost
+
+
+def test_long_random_rollout_stays_finite_and_deterministic(oracle):
+  ep = gu.load_json_gz('episodes.json.gz')[3]
+  assert ep['task'] == 'go_to_goal'
+  rf, ri = gu.episode_init_record(ep)
+  rs = np.random.RandomState(0)
+  acts = rs.uniform(-1, 1, (1500, 2))
+  finals = []
+  for _ in range(2):
+    e = oracle.env(rf, ri)
+    for a in acts:
+      o = oracle.step(e, 0, a, key=(5, 6))
+      assert not o.done
+    finals.append(oracle.record(e)[0])
+  assert np.isfinite(finals[0]).all()
+  np.testing.assert_array_equal(finals[0], finals[1])
+  assert np.abs(finals[0][:2]).max() < 50
+
+
+def test_f32_oracle_tracks_f64(oracle):
+  """Precision, not logic: the float build of the same source stays within 1e-4 over one step."""
+  o32 = Oracle(f32=True)
+  ep = gu.load_json_gz('episodes.json.gz')[3]
+  rf, ri = gu.episode_init_record(ep)
+  rf = rf.astype(np.float32)
+  e64, e32 = oracle.env(rf, ri), o32.env(rf, ri)
+  a = oracle.step(e64, 0, [1.0, 0.5], noise=[0, 0], tape=np.zeros(8, np.uint32))
+  b = o32.step(e32, 0, [1.0, 0.5], noise=[0, 0], tape=np.zeros(8, np.uint32))
+  np.testing.assert_allclose(oracle.record(e64)[0], o32.record(e32)[0], rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(np.array(a.obs[:60]), np.array(b.obs[:60]), rtol=1e-4, atol=1e-4)
