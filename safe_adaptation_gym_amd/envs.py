@@ -13,7 +13,7 @@ from safe_adaptation_gym_amd.robot import Robot
 from safe_adaptation_gym_amd.tasks.task import Task
 from safe_adaptation_gym_amd.world import World
 
-TAPE_WORDS = 256  # raw generator words offered to the device per env per step (parity mode)
+TAPE_WORDS = 1024  # raw generator words offered to the device per env per step (parity mode)
 
 
 class Box:

@@ -33,7 +33,7 @@ def pursuit_actions(rf, ri, rng, p_random=0.2):
   for i in np.flatnonzero(nb > 0):
     task = ri[i, nat.I_TASK]
     if task == 1:  # collect: lowest active button
-      m = ri[i, nat.I_ACTIVE_MASK]
+      m = int(ri[i, nat.I_ACTIVE_MASK])
       b = (m & -m).bit_length() - 1 if m else 0
     else:
       b = ri[i, nat.I_GOAL_BUTTON]

@@ -1,0 +1,38 @@
+"""GPU diagnostic: lockstep device vs oracle (f64 and f32), report the worst mismatches."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import batch_util as bu
+from oracle_lib import Oracle
+from safe_adaptation_gym_amd import _native as nat
+
+task = sys.argv[1] if len(sys.argv) > 1 else 'go_to_goal_damping'
+n, T = 192, 160
+o64, o32 = Oracle(), Oracle(f32=True)
+rf, ri = bu.sample_records('point', task, n, seed=666)
+ctx = nat.Context('point', n, seed=1234)
+ctx.set_layout(rf, ri)
+rng = np.random.RandomState(7); mt = np.random.RandomState(99)
+ctx.observe()
+worst = []
+for t in range(T):
+  rf, ri = ctx.get_state()
+  a64, a32 = o64.make_batch(rf, ri), o32.make_batch(rf, ri)
+  act = bu.pursuit_actions(rf, ri, rng)
+  noise = mt.normal(size=(n, 2)).astype(np.float32)
+  tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
+  d = ctx.step(act, noise, tape)
+  r64 = o64.step_batch_full(a64, 0, act, noise, tape)
+  r32 = o32.step_batch_full(a32, 0, act, noise, tape)
+  d_rf, _ = ctx.get_state()
+  f64, _ = o64.batch_records(a64)
+  f32, _ = o32.batch_records(a32)
+  e64 = np.abs(d_rf - f64); e32 = np.abs(d_rf - f32); e6432 = np.abs(f64 - f32)
+  i, k = np.unravel_index(np.argmax(e64), e64.shape)
+  if e64[i, k] > 5e-5:
+    worst.append((t, i, k, d_rf[i, k], f64[i, k], f32[i, k], d[2][i], r64[2][i], r64[6][i]))
+print('step env field  device  oracle64  oracle32  cost_dev cost_or margin')
+for w in worst[:40]:
+  print(w)
+print(len(worst), 'steps with max err > 5e-5')
