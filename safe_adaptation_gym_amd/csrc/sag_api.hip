@@ -120,9 +120,10 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.h = (float)c->rb.dt;
   a.key0 = (uint32_t)(c->cfg.seed & 0xffffffffu); a.key1 = (uint32_t)(c->cfg.seed >> 32);
   a.obs = d_obs; a.reward = d_rew; a.cost = d_cost; a.done = d_done; a.goal_met = d_met;
-  a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.observe_only = observe_only;
+  a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;
+  a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   const int blocks = (c->N + WAVE - 1) / WAVE;
-  const size_t lds = (size_t)(c->cfg.max_vases > 0 ? c->cfg.max_vases : 1) * VCOMP * WAVE * sizeof(float);
+  const size_t lds = 0;  // static __shared__ in the kernel
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing && !observe_only) {
     if (c->ev_used == c->ev_pool.size()) {

@@ -65,7 +65,7 @@ struct StepArgs {
   uint8_t* done;
   uint8_t* goal_met;
   int32_t* tape_used;
-  int32_t max_vases;      // LDS rows allocated
+  int32_t max_vases, max_hazards, max_pillars, max_buttons;  // context capacities (load bounds)
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
 };
 
@@ -273,26 +273,98 @@ __device__ inline double dist2d(double ax, double ay, double bx, double by) {
 // ---------------------------------------------------------------------------
 // the fused step kernel (Point robot)
 // ---------------------------------------------------------------------------
+// LDS map (floats), one wavefront per workgroup, [slot][lane]:
+//   slots  0.. 9 vase x      10..19 vase y     20..29 vase yaw
+//         30..39 vase vx     40..49 vase vy    50..59 vase w
+//         60..69 vase ax     70..79 vase ay    80..89 vase aw
+// After the physics the region from slot 30 on is reused as the observation staging
+// area [lane][61] (48 lidar bins + 12 sensors, row stride 61 = conflict-free both for
+// the per-lane writes and for the transposed, fully coalesced read-out).
+constexpr int LDS_FLOATS = 6016;  // 90 slots * 64 + tail of the staging area
+constexpr int STG_BASE = 30 * WAVE, STG_STRIDE = 61;
+enum { VS_X = 0, VS_Y = 10, VS_YAW = 20, VS_VX = 30, VS_VY = 40, VS_W = 50, VS_AX = 60, VS_AY = 70, VS_AW = 80 };
+
 #define SF(k) S[(size_t)(k) * N + i]
-#define LV(k, c) lds[((k) * VCOMP + (c)) * WAVE + lane]
+#define LV(comp, k) lds[((comp) + (k)) * WAVE + lane]
+#define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]
+
+// tstate bits 17..26: vase k has non-zero velocity (derived; lets the kernel skip the
+// velocity loads and the write-back of sleeping vases).  meta bit 19: some bodies overlap
+// at rest, so no vase may be treated as asleep (never the case for sampled layouts).
+constexpr uint32_t TS_AWAKE_SHIFT = 17, TS_AWAKE_MASK = 0x3ffu << 17;
+constexpr uint32_t META_FULL_PAIRS = 1u << 19;
+
+__device__ inline void load_vase(const float* lds, int lane, int k, float inv_m, float inv_I, BV& V) {
+  V.x = LV(VS_X, k); V.y = LV(VS_Y, k);
+  V.vx = LV(VS_VX, k); V.vy = LV(VS_VY, k); V.w = LV(VS_W, k);
+  V.ax = LV(VS_AX, k); V.ay = LV(VS_AY, k); V.aw = LV(VS_AW, k);
+  V.m0 = inv_m; V.m1 = 0; V.m2 = 0; V.m3 = inv_m; V.m4 = 0; V.m5 = inv_I; V.dyn = 1;
+}
+__device__ inline void store_vase_acc(float* lds, int lane, int k, const BV& V) {
+  LV(VS_AX, k) = V.ax; LV(VS_AY, k) = V.ay; LV(VS_AW, k) = V.aw;
+}
+
+// lidar: fp32 estimate of (bin, alias); the fp64 evaluation (the reference's arithmetic,
+// safe_adaptation_gym.py:208-216) is redone whenever the estimate is within 2e-5 bins of a
+// bin boundary, so the bin index is always the fp64 one.
+struct LidarHit { int bin; float alias, sensor; };
+
+__device__ __attribute__((noinline)) LidarHit lidar_exact(double rx, double ry, double cd, double sd,
+                                                           float px, float py) {
+  const double W0 = (double)px - rx, W1 = (double)py - ry;
+  const double EX = W0 * cd + W1 * sd, EY = W0 * -sd + W1 * cd;
+  const double two_pi = PI_D * 2, bin_size = two_pi / SAG_LIDAR_BINS;
+  double a = atan2(EY, EX);
+  if (a < 0) a += two_pi;
+  LidarHit h;
+  h.bin = (int)(a / bin_size);
+  if (h.bin >= SAG_LIDAR_BINS) h.bin -= SAG_LIDAR_BINS;
+  h.alias = (float)((a - bin_size * h.bin) / bin_size);
+  const double D = hypot(EX, EY);
+  h.sensor = (float)((5.0 - D > 0 ? 5.0 - D : 0.0) / 5.0);
+  return h;
+}
+
+__device__ inline void lidar_point(float* lds, int lane, int group_off, double rx, double ry,
+                                   double cd, double sd, float rxf, float ryf, float cf, float sf,
+                                   float px, float py) {
+  const float w0 = px - rxf, w1 = py - ryf;
+  const float ex = w0 * cf + w1 * sf, ey = w1 * cf - w0 * sf;
+  const float dist = sqrtf(ex * ex + ey * ey);
+  float ang = atan2f(ey, ex);
+  if (ang < 0) ang += 6.28318530717958647692f;
+  float t = ang * (16.0f / 6.28318530717958647692f);
+  int bin = (int)t;
+  float alias = t - (float)bin;
+  float sensor = fmaxf(5.0f - dist, 0.0f) * 0.2f;
+  if (alias < 2e-5f || alias > 1.0f - 2e-5f || bin > 15) {
+    const LidarHit h = lidar_exact(rx, ry, cd, sd, px, py);
+    bin = h.bin; alias = h.alias; sensor = h.sensor;
+  }
+  const int bp = (bin + 1) & 15, bm = (bin + 15) & 15;
+  float* o = &STG(group_off);
+  o[bin] = fmaxf(o[bin], sensor);
+  o[bp] = fmaxf(o[bp], alias * sensor);
+  o[bm] = fmaxf(o[bm], (1.0f - alias) * sensor);
+}
 
 __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
-  extern __shared__ float lds[];
+  __shared__ float lds[LDS_FLOATS];
   const int lane = threadIdx.x;
   const int N = p.N;
-  const int i = blockIdx.x * WAVE + lane;
-  if (i >= N) return;
+  const int gi = blockIdx.x * WAVE + lane;
+  const bool live = gi < N;
+  const int i = live ? gi : N - 1;  // idle lanes shadow the last env; they never store
   float* __restrict__ S = p.S;
   int32_t* __restrict__ I = p.I;
+  const int capV = p.max_vases, capH = p.max_hazards, capP = p.max_pillars, capB = p.max_buttons;
 
+  // ---- issue every load up front (bounds are context capacities, not per-env counts, so
+  //      nothing waits on the meta word) ------------------------------------------------------
   const uint32_t meta = (uint32_t)I[(size_t)DI_META * N + i];
   uint32_t tstate = (uint32_t)I[(size_t)DI_TSTATE * N + i];
   int step = I[(size_t)DI_STEP * N + i];
-  const int task = meta & 15, nH = meta >> 4 & 15, nV = meta >> 8 & 15, nP = meta >> 12 & 3,
-            nB = meta >> 14 & 7, box_kind = meta >> 17 & 3;
-  int flags = 0;
-
-  // ---- robot ----------------------------------------------------------------
+  const uint32_t env_id = (uint32_t)I[(size_t)DI_ENVID * N + i];
   BV R;
   R.x = SF(SAG_F_ROBOT); R.y = SF(SAG_F_ROBOT + 1);
   float yaw = SF(SAG_F_ROBOT + 2);
@@ -300,39 +372,68 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
   R.ax = R.ay = R.aw = 0; R.dyn = 1;
   const float gear = SF(SAG_F_GEAR), damp = SF(SAG_F_DAMP);
   const float vsz = SF(SAG_F_VASE_SIZE), psz = SF(SAG_F_PILLAR_SIZE);
-
-  // ---- vases -> LDS -----------------------------------------------------------
-  for (int k = 0; k < nV; k++) {
-#pragma unroll
-    for (int c = 0; c < 6; c++) LV(k, c) = SF(SAG_F_VASES + 6 * k + c);
+  float goalx = SF(SAG_F_GOAL), goaly = SF(SAG_F_GOAL + 1);
+  float last0 = SF(SAG_F_LAST);
+  float a0 = 0, a1 = 0, n0 = 0, n1 = 0;
+  if (!p.observe_only) {
+    const float2 a = reinterpret_cast<const float2*>(p.actions)[i];
+    a0 = a.x; a1 = a.y;
+    if (p.noise) { const float2 z = reinterpret_cast<const float2*>(p.noise)[i]; n0 = z.x; n1 = z.y; }
   }
-  // static colliders: pillars then buttons, kept in registers
+  uint32_t awake = (tstate >> TS_AWAKE_SHIFT) & 0x3ffu;
+  if (meta & META_FULL_PAIRS) awake = 0x3ffu;
+  {
+    float vpos[SAG_MAX_VASES * 3];
+#pragma unroll
+    for (int k = 0; k < SAG_MAX_VASES; k++) {
+      if (k < capV) {
+        vpos[3 * k] = SF(SAG_F_VASES + 6 * k); vpos[3 * k + 1] = SF(SAG_F_VASES + 6 * k + 1);
+        vpos[3 * k + 2] = SF(SAG_F_VASES + 6 * k + 2);
+      } else { vpos[3 * k] = vpos[3 * k + 1] = vpos[3 * k + 2] = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < SAG_MAX_VASES; k++) {
+      LV(VS_X, k) = vpos[3 * k]; LV(VS_Y, k) = vpos[3 * k + 1]; LV(VS_YAW, k) = vpos[3 * k + 2];
+      float vx = 0, vy = 0, w = 0;
+      if (k < capV && (awake >> k & 1)) {
+        vx = SF(SAG_F_VASES + 6 * k + 3); vy = SF(SAG_F_VASES + 6 * k + 4); w = SF(SAG_F_VASES + 6 * k + 5);
+      }
+      LV(VS_VX, k) = vx; LV(VS_VY, k) = vy; LV(VS_W, k) = w;
+    }
+  }
+  // static colliders: pillars then buttons, in registers
   float stx[SAG_MAX_PILLARS + SAG_MAX_BUTTONS], sty[SAG_MAX_PILLARS + SAG_MAX_BUTTONS];
 #pragma unroll
   for (int k = 0; k < SAG_MAX_PILLARS; k++) {
-    stx[k] = k < nP ? SF(SAG_F_PILLARS + 2 * k) : 0.f;
-    sty[k] = k < nP ? SF(SAG_F_PILLARS + 2 * k + 1) : 0.f;
+    stx[k] = k < capP ? SF(SAG_F_PILLARS + 2 * k) : 0.f;
+    sty[k] = k < capP ? SF(SAG_F_PILLARS + 2 * k + 1) : 0.f;
   }
 #pragma unroll
   for (int k = 0; k < SAG_MAX_BUTTONS; k++) {
-    stx[SAG_MAX_PILLARS + k] = k < nB ? SF(SAG_F_BUTTONS + 2 * k) : 0.f;
-    sty[SAG_MAX_PILLARS + k] = k < nB ? SF(SAG_F_BUTTONS + 2 * k + 1) : 0.f;
+    stx[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k) : 0.f;
+    sty[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k + 1) : 0.f;
   }
-  float goalx = SF(SAG_F_GOAL), goaly = SF(SAG_F_GOAL + 1);
+  float hzx[SAG_MAX_HAZARDS], hzy[SAG_MAX_HAZARDS];
+#pragma unroll
+  for (int k = 0; k < SAG_MAX_HAZARDS; k++) {
+    hzx[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k) : 0.f;
+    hzy[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k + 1) : 0.f;
+  }
+  const float hsz = SF(SAG_F_HAZARD_SIZE);
+
+  const int task = meta & 15, nH = meta >> 4 & 15, nV = meta >> 8 & 15, nP = meta >> 12 & 3,
+            nB = meta >> 14 & 7, box_kind = meta >> 17 & 3;
+  int flags = 0;
 
   Rng rng;
   rng.tape = p.tape ? p.tape + (size_t)i * p.tape_len : nullptr;
   rng.len = p.tape_len; rng.pos = 0; rng.exhausted = 0;
-  rng.k0 = p.key0; rng.k1 = p.key1;
-  rng.env = (uint32_t)I[(size_t)DI_ENVID * N + i]; rng.step = (uint32_t)step;
+  rng.k0 = p.key0; rng.k1 = p.key1; rng.env = env_id; rng.step = (uint32_t)step;
 
   // ---- action noise + clip (safe_adaptation_gym.py:58-67) ---------------------
   float ctrl0 = 0, ctrl1 = 0;
   if (!p.observe_only) {
-    float a0 = p.actions[(size_t)i * 2], a1 = p.actions[(size_t)i * 2 + 1];
-    float n0, n1;
-    if (p.noise) { n0 = p.noise[(size_t)i * 2]; n1 = p.noise[(size_t)i * 2 + 1]; }
-    else {
+    if (!p.noise) {
       uint32_t c[4] = {rng.env, rng.step, 0u, 1u};
       philox4x32_10(c, p.key0, p.key1);
       float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -353,7 +454,7 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
         cur = nxt;
         nxt = (float)rng.uniform(0.2, 1.0);
         if (rng.exhausted) flags |= 2;
-        SF(SAG_F_CATCH + 2) = cur; SF(SAG_F_CATCH + 3) = nxt;
+        if (live) { SF(SAG_F_CATCH + 2) = cur; SF(SAG_F_CATCH + 3) = nxt; }
         t = 10;
       }
       tstate = (tstate & ~(15u << 7)) | (uint32_t)t << 7;
@@ -374,6 +475,9 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
   const float vase_r = vsz * 1.41421356237309504880f;
   const float inv_vm = 1.0f / vase_m, inv_vI = 1.0f / vase_I;
   const int nsub = p.observe_only ? 0 : p.nstep;
+  const uint32_t vmask = (1u << nV) - 1;
+  awake &= vmask;
+  uint32_t dirty = 0;  // vases whose state changed during this step
   int cost_contacts = 0;
   uint32_t btn_mask = 0;
   float cy = 1, sy = 0;
@@ -402,116 +506,130 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
       R.ay = R.m1 * Fx + R.m3 * Fy + R.m4 * Tz;
       R.aw = R.m2 * Fx + R.m4 * Fy + R.m5 * Tz;
     }
-    for (int k = 0; k < nV; k++) { LV(k, 6) = 0; LV(k, 7) = 0; LV(k, 8) = 0; }
     const float arx = R.x + cy * 0.1f, ary = R.y + sy * 0.1f;  // arrow box centre
     cost_contacts = 0; btn_mask = 0;
+    // `active` = vases that can have a non-zero acceleration or velocity this substep.
+    // A sleeping vase (v = 0, untouched) overlaps nothing (invariant of sampled layouts, else
+    // META_FULL_PAIRS), so every pair test it would take part in is a no-op and is skipped;
+    // the pair ORDER of the specification is kept for the ones that run.
+    uint32_t active = awake;
+    for (uint32_t m = active; m; m &= m - 1) {
+      const int k = __ffs(m) - 1;
+      LV(VS_AX, k) = 0; LV(VS_AY, k) = 0; LV(VS_AW, k) = 0;
+    }
     // robot vs static circles (pillars, then buttons)
 #pragma unroll 1
     for (int k = 0; k < SAG_MAX_PILLARS + SAG_MAX_BUTTONS; k++) {
-      bool is_p = k < SAG_MAX_PILLARS;
-      if (is_p ? (k >= nP) : (k - SAG_MAX_PILLARS >= nB)) continue;
-      float sx = stx[k], syy = sty[k], sr = is_p ? psz : BUTTON_R;
-      float dx = sx - R.x, dy = syy - R.y, rs = ROBOT_BOUND + sr;
-      if (dx * dx + dy * dy > rs * rs) continue;
-      BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
-      St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-      int n = cc_contact(R, St, R.x, R.y, 0.1f, sx, syy, sr, bcoef, kcoef);
-      n += cb_contact(St, R, sx, syy, sr, arx, ary, cy, sy, 0.05f, 0.05f, false, bcoef, kcoef);
-      if (is_p) cost_contacts += n;
-      else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
+      const bool is_p = k < SAG_MAX_PILLARS;
+      const bool on = is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB);
+      const float sx = stx[k], syy = sty[k], sr = is_p ? psz : BUTTON_R;
+      const float dx = sx - R.x, dy = syy - R.y, rs = ROBOT_BOUND + sr;
+      if (on && dx * dx + dy * dy <= rs * rs) {
+        BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
+        St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
+        int n = cc_contact(R, St, R.x, R.y, 0.1f, sx, syy, sr, bcoef, kcoef);
+        n += cb_contact(St, R, sx, syy, sr, arx, ary, cy, sy, 0.05f, 0.05f, false, bcoef, kcoef);
+        if (is_p) cost_contacts += n;
+        else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
+      }
     }
     // robot vs vases
 #pragma unroll 1
     for (int k = 0; k < nV; k++) {
-      float vx_ = LV(k, 0), vy_ = LV(k, 1);
-      float dx = vx_ - R.x, dy = vy_ - R.y, rs = ROBOT_BOUND + vase_r;
+      const float vx_ = LV(VS_X, k), vy_ = LV(VS_Y, k);
+      const float dx = vx_ - R.x, dy = vy_ - R.y, rs = ROBOT_BOUND + vase_r;
       if (dx * dx + dy * dy > rs * rs) continue;
-      BV V; V.x = vx_; V.y = vy_; V.vx = LV(k, 3); V.vy = LV(k, 4); V.w = LV(k, 5);
-      V.ax = LV(k, 6); V.ay = LV(k, 7); V.aw = LV(k, 8);
-      V.m0 = inv_vm; V.m1 = 0; V.m2 = 0; V.m3 = inv_vm; V.m4 = 0; V.m5 = inv_vI; V.dyn = 1;
-      float cv, sv; sincosf(LV(k, 2), &sv, &cv);
+      if (!(active >> k & 1)) { LV(VS_AX, k) = 0; LV(VS_AY, k) = 0; LV(VS_AW, k) = 0; }
+      BV V; load_vase(lds, lane, k, inv_vm, inv_vI, V);
+      float cv, sv; sincosf(LV(VS_YAW, k), &sv, &cv);
       int n = cb_contact(R, V, R.x, R.y, 0.1f, vx_, vy_, cv, sv, vsz, vsz, true, bcoef, kcoef);
       n += bb_contact(R, V, arx, ary, cy, sy, 0.05f, 0.05f, vx_, vy_, cv, sv, vsz, vsz, bcoef, kcoef);
       cost_contacts += n;
-      LV(k, 6) = V.ax; LV(k, 7) = V.ay; LV(k, 8) = V.aw;
+      if (n) { store_vase_acc(lds, lane, k, V); active |= 1u << k; }
     }
-    // vases vs static circles
+    if (sub == nsub) break;  // final forward: robot acceleration + contact flags only
+    if (active) {
+      // vases vs static circles
+      for (uint32_t m = active; m; m &= m - 1) {
+        const int k = __ffs(m) - 1;
+        const float vx_ = LV(VS_X, k), vy_ = LV(VS_Y, k);
 #pragma unroll 1
-    for (int k = 0; k < nV; k++) {
-      float vx_ = LV(k, 0), vy_ = LV(k, 1);
-#pragma unroll 1
-      for (int q = 0; q < SAG_MAX_PILLARS + SAG_MAX_BUTTONS; q++) {
-        bool is_p = q < SAG_MAX_PILLARS;
-        if (is_p ? (q >= nP) : (q - SAG_MAX_PILLARS >= nB)) continue;
-        float sx = stx[q], syy = sty[q], sr = is_p ? psz : BUTTON_R;
-        float dx = sx - vx_, dy = syy - vy_, rs = vase_r + sr;
-        if (dx * dx + dy * dy > rs * rs) continue;
-        BV V; V.x = vx_; V.y = vy_; V.vx = LV(k, 3); V.vy = LV(k, 4); V.w = LV(k, 5);
-        V.ax = LV(k, 6); V.ay = LV(k, 7); V.aw = LV(k, 8);
-        V.m0 = inv_vm; V.m1 = 0; V.m2 = 0; V.m3 = inv_vm; V.m4 = 0; V.m5 = inv_vI; V.dyn = 1;
-        BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
-        St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-        float cv, sv; sincosf(LV(k, 2), &sv, &cv);
-        cb_contact(St, V, sx, syy, sr, vx_, vy_, cv, sv, vsz, vsz, false, bcoef, kcoef);
-        LV(k, 6) = V.ax; LV(k, 7) = V.ay; LV(k, 8) = V.aw;
+        for (int q = 0; q < SAG_MAX_PILLARS + SAG_MAX_BUTTONS; q++) {
+          const bool is_p = q < SAG_MAX_PILLARS;
+          if (is_p ? (q >= nP) : (q - SAG_MAX_PILLARS >= nB)) continue;
+          const float sx = stx[q], syy = sty[q], sr = is_p ? psz : BUTTON_R;
+          const float dx = sx - vx_, dy = syy - vy_, rs = vase_r + sr;
+          if (dx * dx + dy * dy > rs * rs) continue;
+          BV V; load_vase(lds, lane, k, inv_vm, inv_vI, V);
+          BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
+          St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
+          float cv, sv; sincosf(LV(VS_YAW, k), &sv, &cv);
+          cb_contact(St, V, sx, syy, sr, vx_, vy_, cv, sv, vsz, vsz, false, bcoef, kcoef);
+          store_vase_acc(lds, lane, k, V);
+        }
       }
-    }
-    // vase vs vase
+      // vase vs vase, pairs (a < b) in lexicographic order, at least one of them active
 #pragma unroll 1
-    for (int a = 0; a < nV; a++) {
-      float axp = LV(a, 0), ayp = LV(a, 1);
+      for (int a = 0; a < nV - 1; a++) {
+        const float axp = LV(VS_X, a), ayp = LV(VS_Y, a);
 #pragma unroll 1
-      for (int b = a + 1; b < nV; b++) {
-        float bxp = LV(b, 0), byp = LV(b, 1);
-        float dx = bxp - axp, dy = byp - ayp, rs = 2 * vase_r;
-        if (dx * dx + dy * dy > rs * rs) continue;
-        BV A, B;
-        A.x = axp; A.y = ayp; A.vx = LV(a, 3); A.vy = LV(a, 4); A.w = LV(a, 5);
-        A.ax = LV(a, 6); A.ay = LV(a, 7); A.aw = LV(a, 8);
-        A.m0 = inv_vm; A.m1 = 0; A.m2 = 0; A.m3 = inv_vm; A.m4 = 0; A.m5 = inv_vI; A.dyn = 1;
-        B.x = bxp; B.y = byp; B.vx = LV(b, 3); B.vy = LV(b, 4); B.w = LV(b, 5);
-        B.ax = LV(b, 6); B.ay = LV(b, 7); B.aw = LV(b, 8);
-        B.m0 = inv_vm; B.m1 = 0; B.m2 = 0; B.m3 = inv_vm; B.m4 = 0; B.m5 = inv_vI; B.dyn = 1;
-        float ca, sa, cb, sb;
-        sincosf(LV(a, 2), &sa, &ca); sincosf(LV(b, 2), &sb, &cb);
-        bb_contact(A, B, axp, ayp, ca, sa, vsz, vsz, bxp, byp, cb, sb, vsz, vsz, bcoef, kcoef);
-        LV(a, 6) = A.ax; LV(a, 7) = A.ay; LV(a, 8) = A.aw;
-        LV(b, 6) = B.ax; LV(b, 7) = B.ay; LV(b, 8) = B.aw;
+        for (int b = a + 1; b < nV; b++) {
+          if (!((active >> a | active >> b) & 1)) continue;
+          const float bxp = LV(VS_X, b), byp = LV(VS_Y, b);
+          const float dx = bxp - axp, dy = byp - ayp, rs = 2 * vase_r;
+          if (dx * dx + dy * dy > rs * rs) continue;
+          if (!(active >> a & 1)) { LV(VS_AX, a) = 0; LV(VS_AY, a) = 0; LV(VS_AW, a) = 0; }
+          if (!(active >> b & 1)) { LV(VS_AX, b) = 0; LV(VS_AY, b) = 0; LV(VS_AW, b) = 0; }
+          BV A, B;
+          load_vase(lds, lane, a, inv_vm, inv_vI, A);
+          load_vase(lds, lane, b, inv_vm, inv_vI, B);
+          float ca, sa, cb, sb;
+          sincosf(LV(VS_YAW, a), &sa, &ca); sincosf(LV(VS_YAW, b), &sb, &cb);
+          int n = bb_contact(A, B, axp, ayp, ca, sa, vsz, vsz, bxp, byp, cb, sb, vsz, vsz, bcoef, kcoef);
+          if (n) {
+            store_vase_acc(lds, lane, a, A); store_vase_acc(lds, lane, b, B);
+            active |= 1u << a | 1u << b;
+          }
+        }
       }
+      // floor friction + semi-implicit Euler for the active vases
+      const float fmax_ = MU * GRAV * vase_m;
+      for (uint32_t m = active; m; m &= m - 1) {
+        const int k = __ffs(m) - 1;
+        float vx_ = LV(VS_VX, k), vy_ = LV(VS_VY, k), w_ = LV(VS_W, k);
+        float ax_ = LV(VS_AX, k), ay_ = LV(VS_AY, k), aw_ = LV(VS_AW, k);
+        float fx = -SOL_D0 * vase_m * (bcoef * vx_ + ax_), fy = -SOL_D0 * vase_m * (bcoef * vy_ + ay_);
+        float f2 = fx * fx + fy * fy;
+        if (f2 > fmax_ * fmax_) { float sc = fmax_ / sqrtf(f2); fx *= sc; fy *= sc; }
+        ax_ += fx / vase_m; ay_ += fy / vase_m;
+        float t = clampf(-SOL_D0 * vase_I * (bcoef * w_ + aw_), -fmax_ * vase_r, fmax_ * vase_r);
+        aw_ += t / vase_I;
+        vx_ += h * ax_; vy_ += h * ay_; w_ += h * aw_;
+        LV(VS_VX, k) = vx_; LV(VS_VY, k) = vy_; LV(VS_W, k) = w_;
+        LV(VS_X, k) += h * vx_; LV(VS_Y, k) += h * vy_; LV(VS_YAW, k) += h * w_;
+        if (vx_ == 0 && vy_ == 0 && w_ == 0) awake &= ~(1u << k); else awake |= 1u << k;
+      }
+      dirty |= active;
     }
-    if (sub == nsub) break;  // final forward: accelerations + contact flags only
-    // floor friction + semi-implicit Euler for the vases
-    const float fmax_ = MU * GRAV * vase_m;
-#pragma unroll 1
-    for (int k = 0; k < nV; k++) {
-      float vx_ = LV(k, 3), vy_ = LV(k, 4), w_ = LV(k, 5);
-      float ax_ = LV(k, 6), ay_ = LV(k, 7), aw_ = LV(k, 8);
-      if (vx_ == 0 && vy_ == 0 && w_ == 0 && ax_ == 0 && ay_ == 0 && aw_ == 0) continue;
-      float fx = -SOL_D0 * vase_m * (bcoef * vx_ + ax_), fy = -SOL_D0 * vase_m * (bcoef * vy_ + ay_);
-      float f2 = fx * fx + fy * fy;
-      if (f2 > fmax_ * fmax_) { float sc = fmax_ / sqrtf(f2); fx *= sc; fy *= sc; }
-      ax_ += fx / vase_m; ay_ += fy / vase_m;
-      float t = clampf(-SOL_D0 * vase_I * (bcoef * w_ + aw_), -fmax_ * vase_r, fmax_ * vase_r);
-      aw_ += t / vase_I;
-      vx_ += h * ax_; vy_ += h * ay_; w_ += h * aw_;
-      LV(k, 3) = vx_; LV(k, 4) = vy_; LV(k, 5) = w_;
-      LV(k, 0) += h * vx_; LV(k, 1) += h * vy_; LV(k, 2) += h * w_;
-    }
+    if (meta & META_FULL_PAIRS) awake = vmask;
     R.vx += h * R.ax; R.vy += h * R.ay; R.w += h * R.aw;
     R.x += h * R.vx; R.y += h * R.vy; yaw += h * R.w;
   }
 
   // ---- write back dynamic state -------------------------------------------------
-  if (!p.observe_only) {
+  if (!p.observe_only && live) {
     SF(SAG_F_ROBOT) = R.x; SF(SAG_F_ROBOT + 1) = R.y; SF(SAG_F_ROBOT + 2) = yaw;
     SF(SAG_F_ROBOT + 3) = R.vx; SF(SAG_F_ROBOT + 4) = R.vy; SF(SAG_F_ROBOT + 5) = R.w;
-    for (int k = 0; k < nV; k++) {
-#pragma unroll
-      for (int c = 0; c < 6; c++) SF(SAG_F_VASES + 6 * k + c) = LV(k, c);
+    for (uint32_t m = dirty; m; m &= m - 1) {
+      const int k = __ffs(m) - 1;
+      SF(SAG_F_VASES + 6 * k) = LV(VS_X, k); SF(SAG_F_VASES + 6 * k + 1) = LV(VS_Y, k);
+      SF(SAG_F_VASES + 6 * k + 2) = LV(VS_YAW, k); SF(SAG_F_VASES + 6 * k + 3) = LV(VS_VX, k);
+      SF(SAG_F_VASES + 6 * k + 4) = LV(VS_VY, k); SF(SAG_F_VASES + 6 * k + 5) = LV(VS_W, k);
     }
     step += 1;
     I[(size_t)DI_STEP * N + i] = step;
   }
+  tstate = (tstate & ~TS_AWAKE_MASK) | (awake & 0x3ffu) << TS_AWAKE_SHIFT;
 
   // ---- PhysicsError branch (safe_adaptation_gym.py:73-75) -------------------------
   bool bad = false;
@@ -521,7 +639,7 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
     for (int k = 0; k < 6; k++) bad |= !(fabsf(v[k]) <= 1e10f);
   }
 
-  // ---- reward (tasks/*.py compute_reward), fp64 from the fp32 state ---------------
+  // ---- reward (tasks/<task>.py compute_reward), fp64 from the fp32 state -----------
   double rew0 = 0, rew1 = 0;
   int met = 0;
   const double rx = R.x, ry = R.y;
@@ -529,7 +647,7 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
     if (task == SAG_TASK_PRESS_BUTTONS || task == SAG_TASK_PRESS_BUTTONS_SCARCE) {
       int gb = tstate & 7, bstate = tstate >> 3 & 1, timer = tstate >> 4 & 7;
       double gd = dist2d(rx, ry, SF(SAG_F_BUTTONS + 2 * gb), SF(SAG_F_BUTTONS + 2 * gb + 1));
-      double r = task == SAG_TASK_PRESS_BUTTONS ? (double)SF(SAG_F_LAST) - gd : 0.0;
+      double r = task == SAG_TASK_PRESS_BUTTONS ? (double)last0 - gd : 0.0;
       float last = (float)gd;
       if (btn_mask >> gb & 1) {
         r += 1.0; met = 1;
@@ -543,7 +661,7 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
         if (timer != 0) timer -= 1;
         else { bstate = 1; timer = 5; }
       }
-      SF(SAG_F_LAST) = last;
+      last0 = last;
       tstate = (tstate & ~127u) | (uint32_t)gb | (uint32_t)bstate << 3 | (uint32_t)timer << 4;
       rew0 = r;
     } else if (task == SAG_TASK_COLLECT) {
@@ -560,7 +678,7 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
       double gx = goalx, gy = goaly;
       double dx = rx - gx, dy = ry - gy, dz = PT_Z - GOAL_Z;
       double dist = sqrt(dx * dx + dy * dy + dz * dz);
-      double r = (double)SF(SAG_F_LAST) - dist;
+      double r = (double)last0 - dist;
       if (task == SAG_TASK_GO_TO_GOAL_SCARCE) r *= (dist <= GOAL_SIZE * 1.5) ? 1.0 : 0.0;
       float last = (float)dist;
       if (dist <= GOAL_SIZE) {
@@ -579,7 +697,7 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
           for (int k = 0; k < nH && ok; k++)
             ok = !(dist2d(ngx, ngy, SF(SAG_F_HAZARDS + 2 * k), SF(SAG_F_HAZARDS + 2 * k + 1)) < k_haz + GOAL_KEEPOUT);
           for (int k = 0; k < nV && ok; k++)
-            ok = !(dist2d(ngx, ngy, LV(k, 0), LV(k, 1)) < k_vase + GOAL_KEEPOUT);
+            ok = !(dist2d(ngx, ngy, LV(VS_X, k), LV(VS_Y, k)) < k_vase + GOAL_KEEPOUT);
           for (int k = 0; k < nP && ok; k++)
             ok = !(dist2d(ngx, ngy, SF(SAG_F_PILLARS + 2 * k), SF(SAG_F_PILLARS + 2 * k + 1)) < k_pil + GOAL_KEEPOUT);
           if (ok) { goalx = (float)ngx; goaly = (float)ngy; found = true; }
@@ -587,10 +705,10 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
         }
         if (!found) flags |= rng.exhausted ? 2 : 1;
         last = (float)dist2d(rx, ry, goalx, goaly);  // GoToGoal.reset: 2-D (:54-55)
-        if (task == SAG_TASK_CATCH_GOAL) { SF(SAG_F_CATCH) = goalx; SF(SAG_F_CATCH + 1) = goaly; }
+        if (task == SAG_TASK_CATCH_GOAL && live) { SF(SAG_F_CATCH) = goalx; SF(SAG_F_CATCH + 1) = goaly; }
         r += 1.0;
       }
-      SF(SAG_F_LAST) = last;
+      last0 = last;
       if (task == SAG_TASK_UNSUPERVISED) {  // tasks/unsupervised.py:48-67
         double c = cos((double)yaw), s = sin((double)yaw), off = (double)PT_MC / (double)PT_MASS;
         double x = rx + c * off, y = ry + s * off, w = R.w;
@@ -600,69 +718,95 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
         rew1 = r;
       } else rew0 = r;
     }
-    SF(SAG_F_GOAL) = goalx; SF(SAG_F_GOAL + 1) = goaly;
-    I[(size_t)DI_TSTATE * N + i] = (int32_t)tstate;
+    if (live) {
+      SF(SAG_F_LAST) = last0;
+      SF(SAG_F_GOAL) = goalx; SF(SAG_F_GOAL + 1) = goaly;
+    }
   }
+  if (!p.observe_only && live) I[(size_t)DI_TSTATE * N + i] = (int32_t)tstate;
 
-  // ---- cost (world.py:144-155) -------------------------------------------------------
+  // ---- cost (world.py:144-155): hazard test in fp32 unless within 1e-5 of the threshold,
+  //      where the reference's fp64 expression decides -----------------------------------
   int cost = 0;
   if (!p.observe_only && !bad) {
     int c = cost_contacts;
-    const double hs = SF(SAG_F_HAZARD_SIZE);
-    for (int k = 0; k < nH; k++)
-      if (dist2d(rx, ry, SF(SAG_F_HAZARDS + 2 * k), SF(SAG_F_HAZARDS + 2 * k + 1)) <= hs) c++;
+#pragma unroll 1
+    for (int k = 0; k < SAG_MAX_HAZARDS; k++) {
+      if (k < nH) {
+        const float dx = R.x - hzx[k], dy = R.y - hzy[k];
+        const float d2 = dx * dx + dy * dy, t2 = hsz * hsz;
+        bool in = d2 <= t2;
+        if (fabsf(d2 - t2) < 1e-5f) in = dist2d(rx, ry, hzx[k], hzy[k]) <= (double)hsz;
+        c += in;
+      }
+    }
     cost = c > 0;
   }
-  if (flags) I[(size_t)DI_FLAGS * N + i] |= flags;
+  if (flags && live) I[(size_t)DI_FLAGS * N + i] |= flags;
 
-  // ---- observation (safe_adaptation_gym.py:120-139, 225-237) -------------------------
+  // ---- observation (safe_adaptation_gym.py:120-139, 225-237) -> LDS staging -----------
   if (p.obs) {
-    // lidar bins live in LDS after the vase rows are no longer needed as floats:
-    // 48 doubles per lane would not fit beside them, so use a per-lane scratch array.
-    double lid[48];
 #pragma unroll
-    for (int k = 0; k < 48; k++) lid[k] = 0;
-    const double c = cos((double)yaw), s = sin((double)yaw);
-    auto ego = [&](double px, double py, double* o) {
-      double w0 = px - rx, w1 = py - ry;
-      lidar_accum(w0 * c + w1 * s, w0 * -s + w1 * c, o);
-    };
-    for (int k = 0; k < nH; k++) ego(SF(SAG_F_HAZARDS + 2 * k), SF(SAG_F_HAZARDS + 2 * k + 1), lid);
-    for (int k = 0; k < nV; k++) ego(LV(k, 0), LV(k, 1), lid);
-    for (int k = 0; k < nP; k++) ego(SF(SAG_F_PILLARS + 2 * k), SF(SAG_F_PILLARS + 2 * k + 1), lid);
+    for (int k = 0; k < 48; k++) STG(k) = 0.0f;
+    const double cd = cos((double)yaw), sd = sin((double)yaw);
+    const float cf = (float)cd, sf = (float)sd;
+#pragma unroll 1
+    for (int k = 0; k < SAG_MAX_HAZARDS; k++)
+      if (k < nH) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
+#pragma unroll 1
+    for (int k = 0; k < nV; k++)
+      lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, LV(VS_X, k), LV(VS_Y, k));
+#pragma unroll 1
+    for (int k = 0; k < SAG_MAX_PILLARS; k++)
+      if (k < nP) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, stx[k], sty[k]);
     if (nB) {
       const int gb = tstate & 7, bstate = tstate >> 3 & 1;
       const uint32_t act = tstate >> 11 & 63;
-      for (int b = 0; b < nB; b++) {
-        int g;
-        if (task == SAG_TASK_COLLECT) g = (act >> b & 1) ? 2 : 0;
-        else g = bstate == 0 ? 0 : (b == gb ? 2 : 3);
-        if (g == 3) ego(SF(SAG_F_BUTTONS + 2 * b), SF(SAG_F_BUTTONS + 2 * b + 1), lid + 16);
-        if (g == 2) ego(SF(SAG_F_BUTTONS + 2 * b), SF(SAG_F_BUTTONS + 2 * b + 1), lid + 32);
+#pragma unroll 1
+      for (int b = 0; b < SAG_MAX_BUTTONS; b++) {
+        if (b < nB) {
+          int g;
+          if (task == SAG_TASK_COLLECT) g = (act >> b & 1) ? 2 : 0;
+          else g = bstate == 0 ? 0 : (b == gb ? 2 : 3);
+          if (g) lidar_point(lds, lane, g == 3 ? 16 : 32, rx, ry, cd, sd, R.x, R.y, cf, sf,
+                             stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b]);
+        }
       }
     } else {
-      ego(goalx, goaly, lid + 32);
+      lidar_point(lds, lane, 32, rx, ry, cd, sd, R.x, R.y, cf, sf, goalx, goaly);
     }
-    float* o = p.obs + (size_t)i * 60;
-#pragma unroll
-    for (int k = 0; k < 48; k++) o[k] = (float)lid[k];
-    const double qax = bad ? 0.0 : (double)R.ax, qay = bad ? 0.0 : (double)R.ay;
-    o[48] = (float)(c * qax + s * qay);
-    o[49] = (float)(-s * qax + c * qay);
-    o[50] = GRAV;
-    o[51] = (float)(c * (double)R.vx + s * (double)R.vy);
-    o[52] = (float)(-s * (double)R.vx + c * (double)R.vy);
-    o[53] = 0; o[54] = 0; o[55] = 0; o[56] = R.w;
-    o[57] = (float)(-0.5 * s); o[58] = (float)(-0.5 * c); o[59] = 0;
+    const float qax = bad ? 0.0f : R.ax, qay = bad ? 0.0f : R.ay;
+    STG(48) = cf * qax + sf * qay;
+    STG(49) = cf * qay - sf * qax;
+    STG(50) = GRAV;
+    STG(51) = cf * R.vx + sf * R.vy;
+    STG(52) = cf * R.vy - sf * R.vx;
+    STG(53) = 0; STG(54) = 0; STG(55) = 0; STG(56) = R.w;
+    STG(57) = -0.5f * sf; STG(58) = -0.5f * cf; STG(59) = 0;
+    __syncthreads();
+    // transposed read-out: element e of this wavefront's contiguous [64][60] block
+    const int base_env = blockIdx.x * WAVE;
+    const int nvalid = min(WAVE, N - base_env);
+    float* __restrict__ o = p.obs + (size_t)base_env * 60;
+#pragma unroll 4
+    for (int j = 0; j < 60; j++) {
+      const int e = j * WAVE + lane;
+      const int env = (int)(((uint32_t)e * 34953u) >> 21);  // e / 60, exact for e < 3840
+      const float v = lds[STG_BASE + e + env];  // env*61 + (e - env*60)
+      if (env < nvalid) o[e] = v;
+    }
   }
-  if (p.reward) {
-    p.reward[(size_t)i * 2] = bad ? -10.0f : (float)rew0;
-    p.reward[(size_t)i * 2 + 1] = bad ? 0.0f : (float)rew1;
+  if (live) {
+    if (p.reward) {
+      float2 r;
+      r.x = bad ? -10.0f : (float)rew0; r.y = bad ? 0.0f : (float)rew1;
+      reinterpret_cast<float2*>(p.reward)[i] = r;
+    }
+    if (p.cost) p.cost[i] = (uint8_t)cost;
+    if (p.done) p.done[i] = bad ? 1 : 0;
+    if (p.goal_met) p.goal_met[i] = (uint8_t)met;
+    if (p.tape_used) p.tape_used[i] = rng.pos;
   }
-  if (p.cost) p.cost[i] = (uint8_t)cost;
-  if (p.done) p.done[i] = bad ? 1 : 0;
-  if (p.goal_met) p.goal_met[i] = (uint8_t)met;
-  if (p.tape_used) p.tape_used[i] = rng.pos;
 }
 
 // ---------------------------------------------------------------------------
@@ -677,8 +821,34 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
   const float* rf = rec_f + (size_t)j * SAG_REC_FLOATS;
   const int32_t* ri = rec_i + (size_t)j * SAG_REC_INTS;
   for (int k = 0; k < SAG_REC_FLOATS; k++) S[(size_t)k * N + i] = rf[k];
-  I[(size_t)DI_META * N + i] = (int32_t)pack_meta(ri);
-  I[(size_t)DI_TSTATE * N + i] = (int32_t)pack_tstate(ri);
+  // derived words: which vases move (velocity loads / write-backs of the others are skipped)
+  // and whether any bodies overlap at rest (then nothing may be treated as asleep)
+  uint32_t awake = 0, overlap = 0;
+  {
+    const int nV = ri[SAG_I_NV], nP = ri[SAG_I_NP], nB = ri[SAG_I_NB];
+    const float vr = rf[SAG_F_VASE_SIZE] * 1.41421356237309504880f;
+    for (int a = 0; a < nV; a++) {
+      const float* va = rf + SAG_F_VASES + 6 * a;
+      if (va[3] != 0 || va[4] != 0 || va[5] != 0) awake |= 1u << a;
+      for (int b = a + 1; b < nV; b++) {
+        const float* vb = rf + SAG_F_VASES + 6 * b;
+        float dx = va[0] - vb[0], dy = va[1] - vb[1];
+        if (dx * dx + dy * dy <= 4 * vr * vr) overlap = 1;
+      }
+      for (int q = 0; q < nP; q++) {
+        float dx = va[0] - rf[SAG_F_PILLARS + 2 * q], dy = va[1] - rf[SAG_F_PILLARS + 2 * q + 1];
+        float rs = vr + rf[SAG_F_PILLAR_SIZE];
+        if (dx * dx + dy * dy <= rs * rs) overlap = 1;
+      }
+      for (int q = 0; q < nB; q++) {
+        float dx = va[0] - rf[SAG_F_BUTTONS + 2 * q], dy = va[1] - rf[SAG_F_BUTTONS + 2 * q + 1];
+        float rs = vr + BUTTON_R;
+        if (dx * dx + dy * dy <= rs * rs) overlap = 1;
+      }
+    }
+  }
+  I[(size_t)DI_META * N + i] = (int32_t)(pack_meta(ri) | (overlap ? META_FULL_PAIRS : 0u));
+  I[(size_t)DI_TSTATE * N + i] = (int32_t)(pack_tstate(ri) | awake << TS_AWAKE_SHIFT);
   I[(size_t)DI_STEP * N + i] = ri[SAG_I_STEP];
   I[(size_t)DI_ENVID * N + i] = ri[SAG_I_ENV_ID];
   I[(size_t)DI_FLAGS * N + i] = ri[SAG_I_FLAGS];
