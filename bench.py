@@ -84,6 +84,12 @@ class DeviceRun:
     self.ctx.wait()
     self.t = 0
 
+  def burn_in(self, steps):
+    """Untimed ageing: the cost of a step depends on how many vases the robots have set in
+    motion; ~150 steps after reset the population is stationary (profiles/steptime)."""
+    self.run(steps)
+    self.ctx.wait()
+
   def step(self):
     c = self.ctx
     c.step_device(self.d_act[self.t % N_ACTION_BUFS], None, -1, self.d_obs, self.d_rew, self.d_cost,
@@ -124,7 +130,7 @@ def cpu_baseline(task, seconds=12.0):
   rf, ri = build_records(task, n, 0)
   arr = o.make_batch(rf, ri)
   acts = np.stack([[o.actions((666, 0), int(ri[i, 12]), s, 2) for i in range(n)] for s in range(4)])
-  cores = os.cpu_count() or 1
+  cores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box is given 16 host cores
   out = {}
   for label, nt in (('1', 1), ('all', cores)):
     o.step_batch(arr, 0, acts[0], key=(666, 0), nthreads=nt)  # warm
@@ -155,6 +161,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=20)
   ap.add_argument('--envs', type=int, default=1 << 20, help='environments per GPU (weak scaling)')
   ap.add_argument('--task', default='go_to_goal')
+  ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (stationary contact load)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line')
   args = ap.parse_args()
@@ -194,6 +201,7 @@ def main():
   device = local % ndev
 
   run = DeviceRun(args.task, args.envs, device, rank)
+  run.burn_in(args.burn_in)
   # timed region with per-launch HIP events on the context stream (kernel time for the roofline)
   run.ctx.enable_timing(True)
   run.ctx.kernel_time_ms(reset=True)
@@ -245,6 +253,7 @@ def main():
   if rank == 0 and world == 1:
     if not args.no_c2:
       c2 = DeviceRun(args.task, 4096, device, 0)
+      c2.burn_in(args.burn_in)
       c2.ctx.enable_timing(True)
       t = timed(c2, max(args.steps, 200), args.warmup, lambda: None)
       ms, _ = c2.ctx.kernel_time_ms(reset=True)

@@ -664,6 +664,21 @@ static void integrate(Body* b, real h) {
   b->x += h * b->vx; b->y += h * b->vy; b->yaw += h * b->w;
 }
 
+/* Free bodies on the floor come to rest (static friction capture; SPECIFICATION): when the
+ * new velocity and this substep's velocity change are both below REST_V (linear, m/s) /
+ * REST_W (angular, rad/s) the body stops exactly, before the position update. */
+#define REST_V 1e-5
+#define REST_W 1e-4
+static void integrate_free(Body* b, real h) {
+  b->vx += h * b->ax; b->vy += h * b->ay; b->w += h * b->aw;
+  if (R_FABS(b->vx) < (real)REST_V && R_FABS(b->vy) < (real)REST_V && R_FABS(b->w) < (real)REST_W &&
+      R_FABS(h * b->ax) < (real)REST_V && R_FABS(h * b->ay) < (real)REST_V &&
+      R_FABS(h * b->aw) < (real)REST_W) {
+    b->vx = 0; b->vy = 0; b->w = 0;
+  }
+  b->x += h * b->vx; b->y += h * b->vy; b->yaw += h * b->w;
+}
+
 /* nstep x mj_step (safe_adaptation_gym.py:72) */
 void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) {
   World w;
@@ -672,7 +687,7 @@ void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) {
   for (int s = 0; s < nstep; s++) {
     world_forward(&w, e, ctrl, &sol, NULL);
     integrate(&w.robot, sol.h);
-    for (int k = 0; k < w.nV; k++) integrate(&w.vase[k], sol.h);
+    for (int k = 0; k < w.nV; k++) integrate_free(&w.vase[k], sol.h);
   }
   world_to_env(&w, e);
 }

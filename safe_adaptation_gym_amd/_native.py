@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsag.so')
+# SAG_LIB overrides the library file (A/B builds of the same ABI during kernel tuning)
+LIB_PATH = os.environ.get('SAG_LIB') or os.path.join(_HERE, 'libsag.so')
 
 ABI_VERSION = 1
 MAX_HAZARDS, MAX_VASES, MAX_PILLARS, MAX_BUTTONS, MAX_NU = 9, 10, 2, 6, 12

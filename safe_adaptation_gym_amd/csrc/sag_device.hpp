@@ -80,6 +80,7 @@ constexpr double PT_Z = 0.1, GOAL_Z = 0.3 / 2.0 + 1e-2, GOAL_SIZE = 0.3, GOAL_KE
 constexpr double PI_D = 3.14159265358979323846;
 constexpr float SOL_D0 = 0.9f, SOL_D1 = 0.95f, SOL_WIDTH = 0.001f, MU = 1.0f, GRAV = 9.81f;
 constexpr float BUTTON_R = 0.1f, VASE_DENSITY = 0.001f;
+constexpr float REST_V = 1e-5f, REST_W = 1e-4f;
 constexpr float ROBOT_BOUND = 0.15811388300841897f;  // arrow corner (0.15, 0.05)
 
 // ---- counter-based generator ------------------------------------------------
@@ -284,6 +285,13 @@ constexpr int LDS_FLOATS = 6016;  // 90 slots * 64 + tail of the staging area
 constexpr int STG_BASE = 30 * WAVE, STG_STRIDE = 61;
 enum { VS_X = 0, VS_Y = 10, VS_YAW = 20, VS_VX = 30, VS_VY = 40, VS_W = 50, VS_AX = 60, VS_AY = 70, VS_AW = 80 };
 
+// timing-only ablations (tools/ablate.py): -DSAG_ABLATE=<mask>; results are wrong by design
+#ifndef SAG_ABLATE
+#define SAG_ABLATE 0
+#endif
+enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL_NO_RV = 16, ABL_NO_RS = 32,
+       ABL_NSUB1 = 64, ABL_NO_ACTIVE = 128 };
+#define ABL(f) ((SAG_ABLATE & (f)) != 0)
 #define SF(k) S[(size_t)(k) * N + i]
 #define LV(comp, k) lds[((comp) + (k)) * WAVE + lane]
 #define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]
@@ -348,7 +356,10 @@ __device__ inline void lidar_point(float* lds, int lane, int group_off, double r
   o[bm] = fmaxf(o[bm], (1.0f - alias) * sensor);
 }
 
-__global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
+#ifndef SAG_STEP_MIN_WAVES
+#define SAG_STEP_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArgs p) {
   __shared__ float lds[LDS_FLOATS];
   const int lane = threadIdx.x;
   const int N = p.N;
@@ -474,7 +485,9 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
   const float vase_I = vase_m * (8 * vsz * vsz) / 12;
   const float vase_r = vsz * 1.41421356237309504880f;
   const float inv_vm = 1.0f / vase_m, inv_vI = 1.0f / vase_I;
-  const int nsub = p.observe_only ? 0 : p.nstep;
+  const int nsub = p.observe_only ? 0 : (ABL(ABL_NSUB1) ? 1 : p.nstep);
+  // statics occupy [0, capP) and [SAG_MAX_PILLARS, SAG_MAX_PILLARS + capB) of stx/sty
+  const int n_static = capB ? SAG_MAX_PILLARS + capB : capP;
   const uint32_t vmask = (1u << nV) - 1;
   awake &= vmask;
   uint32_t dirty = 0;  // vases whose state changed during this step
@@ -519,9 +532,10 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
     }
     // robot vs static circles (pillars, then buttons)
 #pragma unroll 1
-    for (int k = 0; k < SAG_MAX_PILLARS + SAG_MAX_BUTTONS; k++) {
+    for (int k = 0; k < n_static; k++) {
+      if (k == capP) k = SAG_MAX_PILLARS;  // jump over unused pillar slots to the buttons
       const bool is_p = k < SAG_MAX_PILLARS;
-      const bool on = is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB);
+      const bool on = (is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB)) && !ABL(ABL_NO_RS);
       const float sx = stx[k], syy = sty[k], sr = is_p ? psz : BUTTON_R;
       const float dx = sx - R.x, dy = syy - R.y, rs = ROBOT_BOUND + sr;
       if (on && dx * dx + dy * dy <= rs * rs) {
@@ -533,33 +547,59 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
         else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
       }
     }
-    // robot vs vases
+    // robot vs vases: cheap broadphase for all, then each lane walks ITS OWN hit list (ascending
+    // index = the specification's order), so a wavefront runs the narrowphase max-hits times,
+    // not once per vase index that any lane happens to touch
+    uint32_t hits = 0;
 #pragma unroll 1
     for (int k = 0; k < nV; k++) {
+      const float dx = LV(VS_X, k) - R.x, dy = LV(VS_Y, k) - R.y, rs = ROBOT_BOUND + vase_r;
+      if (dx * dx + dy * dy <= rs * rs) hits |= 1u << k;
+    }
+    if (ABL(ABL_NO_RV)) hits = 0;
+    for (uint32_t m = hits; m; m &= m - 1) {
+      const int k = __ffs(m) - 1;
       const float vx_ = LV(VS_X, k), vy_ = LV(VS_Y, k);
-      const float dx = vx_ - R.x, dy = vy_ - R.y, rs = ROBOT_BOUND + vase_r;
-      if (dx * dx + dy * dy > rs * rs) continue;
       if (!(active >> k & 1)) { LV(VS_AX, k) = 0; LV(VS_AY, k) = 0; LV(VS_AW, k) = 0; }
       BV V; load_vase(lds, lane, k, inv_vm, inv_vI, V);
       float cv, sv; sincosf(LV(VS_YAW, k), &sv, &cv);
-      int n = cb_contact(R, V, R.x, R.y, 0.1f, vx_, vy_, cv, sv, vsz, vsz, true, bcoef, kcoef);
-      n += bb_contact(R, V, arx, ary, cy, sy, 0.05f, 0.05f, vx_, vy_, cv, sv, vsz, vsz, bcoef, kcoef);
+      // per-geom bounding circles first: sphere (r .1) and arrow box (half diagonal .0707)
+      int n = 0;
+      {
+        const float dx = vx_ - R.x, dy = vy_ - R.y, rs = 0.1f + vase_r;
+        if (dx * dx + dy * dy <= rs * rs)
+          n = cb_contact(R, V, R.x, R.y, 0.1f, vx_, vy_, cv, sv, vsz, vsz, true, bcoef, kcoef);
+      }
+      {
+        const float dx = vx_ - arx, dy = vy_ - ary, rs = 0.0707106781186548f + vase_r;
+        if (dx * dx + dy * dy <= rs * rs)
+          n += bb_contact(R, V, arx, ary, cy, sy, 0.05f, 0.05f, vx_, vy_, cv, sv, vsz, vsz, bcoef, kcoef);
+      }
       cost_contacts += n;
       if (n) { store_vase_acc(lds, lane, k, V); active |= 1u << k; }
     }
     if (sub == nsub) break;  // final forward: robot acceleration + contact flags only
-    if (active) {
-      // vases vs static circles
+    if (active && !ABL(ABL_NO_ACTIVE)) {
+      // vases vs static circles (pillars then buttons), per active vase
       for (uint32_t m = active; m; m &= m - 1) {
         const int k = __ffs(m) - 1;
         const float vx_ = LV(VS_X, k), vy_ = LV(VS_Y, k);
+        uint32_t shit = 0;
 #pragma unroll 1
-        for (int q = 0; q < SAG_MAX_PILLARS + SAG_MAX_BUTTONS; q++) {
+        for (int q = 0; q < n_static; q++) {
+          if (q == capP) q = SAG_MAX_PILLARS;
           const bool is_p = q < SAG_MAX_PILLARS;
-          if (is_p ? (q >= nP) : (q - SAG_MAX_PILLARS >= nB)) continue;
-          const float sx = stx[q], syy = sty[q], sr = is_p ? psz : BUTTON_R;
-          const float dx = sx - vx_, dy = syy - vy_, rs = vase_r + sr;
-          if (dx * dx + dy * dy > rs * rs) continue;
+          const bool on = (is_p ? (q < nP) : (q - SAG_MAX_PILLARS < nB)) && !ABL(ABL_NO_VS);
+          const float dx = stx[q] - vx_, dy = sty[q] - vy_, rs = vase_r + (is_p ? psz : BUTTON_R);
+          if (on && dx * dx + dy * dy <= rs * rs) shit |= 1u << q;
+        }
+        for (uint32_t mq = shit; mq; mq &= mq - 1) {
+          const int q = __ffs(mq) - 1;
+          // per-lane q: select from the register arrays without dynamic indexing
+          float sx = 0, syy = 0;
+#pragma unroll
+          for (int z = 0; z < SAG_MAX_PILLARS + SAG_MAX_BUTTONS; z++) if (z == q) { sx = stx[z]; syy = sty[z]; }
+          const float sr = q < SAG_MAX_PILLARS ? psz : BUTTON_R;
           BV V; load_vase(lds, lane, k, inv_vm, inv_vI, V);
           BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
           St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
@@ -568,16 +608,25 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
           store_vase_acc(lds, lane, k, V);
         }
       }
-      // vase vs vase, pairs (a < b) in lexicographic order, at least one of them active
+      // vase vs vase, pairs (a < b) in lexicographic order, at least one of them active;
+      // per a: broadphase mask over b, then the lane's own hit list.  (A per-lane walk over a
+      // 45-bit pair list was measured slower: 64-bit ffs + index decode per pair.)
 #pragma unroll 1
       for (int a = 0; a < nV - 1; a++) {
+        const uint32_t above = vmask & ~((2u << a) - 1);          // b > a
+        uint32_t cand = (active >> a & 1) ? above : (active & above);
+        if (ABL(ABL_NO_VV)) cand = 0;
+        if (!cand) continue;
         const float axp = LV(VS_X, a), ayp = LV(VS_Y, a);
-#pragma unroll 1
-        for (int b = a + 1; b < nV; b++) {
-          if (!((active >> a | active >> b) & 1)) continue;
+        uint32_t hit = 0;
+        for (uint32_t m = cand; m; m &= m - 1) {
+          const int b = __ffs(m) - 1;
+          const float dx = LV(VS_X, b) - axp, dy = LV(VS_Y, b) - ayp, rs = 2 * vase_r;
+          if (dx * dx + dy * dy <= rs * rs) hit |= 1u << b;
+        }
+        for (uint32_t m = hit; m; m &= m - 1) {
+          const int b = __ffs(m) - 1;
           const float bxp = LV(VS_X, b), byp = LV(VS_Y, b);
-          const float dx = bxp - axp, dy = byp - ayp, rs = 2 * vase_r;
-          if (dx * dx + dy * dy > rs * rs) continue;
           if (!(active >> a & 1)) { LV(VS_AX, a) = 0; LV(VS_AY, a) = 0; LV(VS_AW, a) = 0; }
           if (!(active >> b & 1)) { LV(VS_AX, b) = 0; LV(VS_AY, b) = 0; LV(VS_AW, b) = 0; }
           BV A, B;
@@ -605,6 +654,9 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
         float t = clampf(-SOL_D0 * vase_I * (bcoef * w_ + aw_), -fmax_ * vase_r, fmax_ * vase_r);
         aw_ += t / vase_I;
         vx_ += h * ax_; vy_ += h * ay_; w_ += h * aw_;
+        // static friction capture (specification, oracle integrate_free)
+        if (fabsf(vx_) < REST_V && fabsf(vy_) < REST_V && fabsf(w_) < REST_W && fabsf(h * ax_) < REST_V &&
+            fabsf(h * ay_) < REST_V && fabsf(h * aw_) < REST_W) { vx_ = 0; vy_ = 0; w_ = 0; }
         LV(VS_VX, k) = vx_; LV(VS_VY, k) = vy_; LV(VS_W, k) = w_;
         LV(VS_X, k) += h * vx_; LV(VS_Y, k) += h * vy_; LV(VS_YAW, k) += h * w_;
         if (vx_ == 0 && vy_ == 0 && w_ == 0) awake &= ~(1u << k); else awake |= 1u << k;
@@ -752,10 +804,10 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
     const float cf = (float)cd, sf = (float)sd;
 #pragma unroll 1
     for (int k = 0; k < SAG_MAX_HAZARDS; k++)
-      if (k < nH) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
+      if (k < nH && !ABL(ABL_NO_LIDAR)) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
 #pragma unroll 1
     for (int k = 0; k < nV; k++)
-      lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, LV(VS_X, k), LV(VS_Y, k));
+      if (!ABL(ABL_NO_LIDAR)) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, LV(VS_X, k), LV(VS_Y, k));
 #pragma unroll 1
     for (int k = 0; k < SAG_MAX_PILLARS; k++)
       if (k < nP) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, stx[k], sty[k]);
@@ -793,7 +845,7 @@ __global__ __launch_bounds__(WAVE) void k_step_point(StepArgs p) {
       const int e = j * WAVE + lane;
       const int env = (int)(((uint32_t)e * 34953u) >> 21);  // e / 60, exact for e < 3840
       const float v = lds[STG_BASE + e + env];  // env*61 + (e - env*60)
-      if (env < nvalid) o[e] = v;
+      if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[e] = v;
     }
   }
   if (live) {

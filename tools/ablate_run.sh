@@ -1,0 +1,4 @@
+#!/bin/bash
+python tools/ablate.py snapshot
+python tools/ablate.py time
+for f in safe_adaptation_gym_amd/libsag_a_*.so; do SAG_LIB=$PWD/$f python tools/ablate.py time; done
