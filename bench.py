@@ -100,6 +100,16 @@ class DeviceRun:
     for _ in range(steps):
       self.step()
 
+  def wait(self):
+    self.ctx.wait()
+
+  def timing(self, on):
+    self.ctx.enable_timing(on)
+    self.ctx.kernel_time_ms(reset=True)
+
+  def kernel_time_ms(self):
+    return self.ctx.kernel_time_ms(reset=True)
+
   def stats(self):
     cost = self.ctx.dev_download(self.d_cost, (self.envs,), np.uint8)
     done = self.ctx.dev_download(self.d_done, (self.envs,), np.uint8)
@@ -111,12 +121,13 @@ class DeviceRun:
 
 
 def timed(run, steps, warmup, barrier):
+  """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides."""
   run.run(warmup)
-  run.ctx.wait()
+  run.wait()
   barrier()
   t0 = time.perf_counter()
   run.run(steps)
-  run.ctx.wait()
+  run.wait()
   barrier()
   return time.perf_counter() - t0
 
@@ -154,7 +165,9 @@ def cpu_baseline(task, seconds=12.0):
   }
 
 
-def main():
+def main(argv=None, run_factory=None, emit=print):
+  """run_factory(task, envs, device, rank) -> run object; tests inject a CPU stand-in to
+  exercise the sharding / barrier / max-over-ranks harness under gloo without a GPU."""
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=200)
@@ -164,7 +177,7 @@ def main():
   ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (stationary contact load)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line')
-  args = ap.parse_args()
+  args = ap.parse_args(argv)
 
   rank = int(os.environ.get('RANK', '0'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -194,21 +207,24 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
-  from safe_adaptation_gym_amd import _native as nat
-  ndev = nat.device_count()
-  if ndev < 1:
-    sys.exit('no HIP device visible (there is no CPU fallback)')
-  device = local % ndev
+  if run_factory is None:
+    from safe_adaptation_gym_amd import _native as nat
+    ndev = nat.device_count()
+    if ndev < 1:
+      sys.exit('no HIP device visible (there is no CPU fallback)')
+    device = local % ndev
+    run_factory = DeviceRun
+  else:
+    device = local
 
-  run = DeviceRun(args.task, args.envs, device, rank)
+  run = run_factory(args.task, args.envs, device, rank)
   run.burn_in(args.burn_in)
   # timed region with per-launch HIP events on the context stream (kernel time for the roofline)
-  run.ctx.enable_timing(True)
-  run.ctx.kernel_time_ms(reset=True)
+  run.timing(True)
   elapsed = max_over_ranks(timed(run, args.steps, args.warmup, barrier))
-  k_ms, k_n = run.ctx.kernel_time_ms(reset=True)
+  k_ms, k_n = run.kernel_time_ms()
   # kernel_time covers warmup + timed launches; both are the same kernel on the same data
-  run.ctx.enable_timing(False)
+  run.timing(False)
   cost_rate, n_done, finite = run.stats()
   total_env_steps = world * args.envs * args.steps
   value = total_env_steps / elapsed
@@ -232,6 +248,7 @@ def main():
                       f'{args.envs} envs per GPU, counter-based actions U(-1,1) and noise 0.01 on device',
           'envs_per_gpu': args.envs,
           'global_envs': world * args.envs,
+          'env_id_range_rank0': [0, args.envs],
           'parallelism': f'env-sharded x{world}, no collective',
       },
       'roofline': {
@@ -250,13 +267,13 @@ def main():
   }
   run.close()
 
-  if rank == 0 and world == 1:
+  if rank == 0 and world == 1 and run_factory is DeviceRun:
     if not args.no_c2:
       c2 = DeviceRun(args.task, 4096, device, 0)
       c2.burn_in(args.burn_in)
-      c2.ctx.enable_timing(True)
+      c2.timing(True)
       t = timed(c2, max(args.steps, 200), args.warmup, lambda: None)
-      ms, _ = c2.ctx.kernel_time_ms(reset=True)
+      ms, _ = c2.kernel_time_ms()
       res['c2_4096_envs'] = {
           'value': 4096 * max(args.steps, 200) / t,
           'unit': 'env-steps/s',
@@ -268,7 +285,7 @@ def main():
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(args.task)
   if rank == 0:
-    print(json.dumps(res))
+    emit(json.dumps(res))
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()

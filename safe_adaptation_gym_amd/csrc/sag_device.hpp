@@ -281,8 +281,15 @@ __device__ inline double dist2d(double ax, double ay, double bx, double by) {
 // After the physics the region from slot 30 on is reused as the observation staging
 // area [lane][61] (48 lidar bins + 12 sensors, row stride 61 = conflict-free both for
 // the per-lane writes and for the transposed, fully coalesced read-out).
+#ifdef SAG_LDS_ALIAS  // timing probe only (wrong results): fold the 90 slots onto 45
+constexpr int LDS_FLOATS = 3968;
+constexpr int STG_BASE = 0, STG_STRIDE = 61;
+#define SLOT_MOD(x) ((x) % 45)
+#else
 constexpr int LDS_FLOATS = 6016;  // 90 slots * 64 + tail of the staging area
 constexpr int STG_BASE = 30 * WAVE, STG_STRIDE = 61;
+#define SLOT_MOD(x) (x)
+#endif
 enum { VS_X = 0, VS_Y = 10, VS_YAW = 20, VS_VX = 30, VS_VY = 40, VS_W = 50, VS_AX = 60, VS_AY = 70, VS_AW = 80 };
 
 // timing-only ablations (tools/ablate.py): -DSAG_ABLATE=<mask>; results are wrong by design
@@ -293,7 +300,7 @@ enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL
        ABL_NSUB1 = 64, ABL_NO_ACTIVE = 128 };
 #define ABL(f) ((SAG_ABLATE & (f)) != 0)
 #define SF(k) S[(size_t)(k) * N + i]
-#define LV(comp, k) lds[((comp) + (k)) * WAVE + lane]
+#define LV(comp, k) lds[SLOT_MOD((comp) + (k)) * WAVE + lane]
 #define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]
 
 // tstate bits 17..26: vase k has non-zero velocity (derived; lets the kernel skip the
@@ -360,7 +367,10 @@ __device__ inline void lidar_point(float* lds, int lane, int group_off, double r
 #define SAG_STEP_MIN_WAVES 1
 #endif
 __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArgs p) {
-  __shared__ float lds[LDS_FLOATS];
+#ifndef SAG_LDS_PAD
+#define SAG_LDS_PAD 0
+#endif
+  __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
   const int lane = threadIdx.x;
   const int N = p.N;
   const int gi = blockIdx.x * WAVE + lane;

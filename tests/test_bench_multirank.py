@@ -1,0 +1,99 @@
+"""The N>1 path of bench.py (sharding by env index, barrier, max over ranks, one JSON line
+from rank 0) under torch.distributed/gloo with world_size 2 on CPU.  The GPU stepper is
+replaced by the CPU oracle here - the only place outside bench's cpu_baseline leg where that
+is allowed - so what is tested is the harness, not the kernel."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, os, sys, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np
+import bench
+from oracle_lib import Oracle
+
+class OracleRun:
+  """CPU stand-in with DeviceRun's interface."""
+  def __init__(self, task, envs, device, rank):
+    self.o = Oracle()
+    rf, ri = bench.build_records(task, envs, rank)
+    self.ids = ri[:, 12].copy()
+    self.arr = self.o.make_batch(rf, ri)
+    self.envs, self.t, self.rank = envs, 0, rank
+    self.acts = np.stack([[self.o.actions((666, 0), int(i), s, 2) for i in self.ids] for s in range(2)])
+    self.ms, self.n = 0.0, 0
+  def burn_in(self, steps): self.run(steps)
+  def run(self, steps):
+    for _ in range(steps):
+      t0 = time.perf_counter()
+      self.out = self.o.step_batch(self.arr, 0, self.acts[self.t %% 2], key=(666, 0))
+      self.ms += (time.perf_counter() - t0) * 1e3; self.n += 1; self.t += 1
+      if self.rank == 1: time.sleep(0.002)   # a slower rank: the max over ranks must see it
+  def wait(self): pass
+  def timing(self, on): self.ms, self.n = 0.0, 0
+  def kernel_time_ms(self): return (self.ms / max(self.n, 1), self.n)
+  def stats(self): return float(self.out[2].mean()), int(self.out[3].sum()), bool(np.isfinite(self.out[0]).all())
+  def close(self):
+    json.dump({'rank': self.rank, 'ids': [int(self.ids[0]), int(self.ids[-1])], 'steps': self.t},
+              open(os.path.join(%(out)r, 'rank%%d.json' %% self.rank), 'w'))
+
+lines = []
+bench.main(['--gpus', '2', '--steps', '6', '--warmup', '2', '--burn-in', '1', '--envs', '48',
+            '--no-cpu-baseline', '--no-c2'], run_factory=OracleRun, emit=lines.append)
+if int(os.environ['RANK']) == 0:
+  open(os.path.join(%(out)r, 'line.json'), 'w').write('\n'.join(lines))
+else:
+  assert lines == []
+'''
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def test_two_rank_gloo_bench(tmp_path):
+  script = tmp_path / 'worker.py'
+  script.write_text(WORKER % {'root': ROOT, 'out': str(tmp_path)})
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), str(script)]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  lines = (tmp_path / 'line.json').read_text().strip().splitlines()
+  assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
+  res = json.loads(lines[0])
+  assert res['n_gpus'] == 2 and res['steps'] == 6 and res['warmup'] == 2
+  assert res['scaling'] == 'weak' and res['higher_is_better'] is True and res['vs_baseline'] is None
+  assert res['config']['global_envs'] == 96 and res['config']['envs_per_gpu'] == 48
+  # value = ALL ranks' env-steps / max-over-ranks time
+  assert abs(res['value'] - 96 * 6 / (res['ms_per_step'] * 6e-3)) < 1e-6 * res['value']
+  # the slow rank sleeps 2 ms per step: the max over ranks cannot be below that
+  assert res['ms_per_step'] >= 2.0
+  for k in ('roofline', 'config', 'metric', 'unit', 'dtype', 'data'):
+    assert k in res
+  assert set(res['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
+  # shards are disjoint contiguous env-id ranges and every rank ran burn-in + warmup + K steps
+  r0 = json.loads((tmp_path / 'rank0.json').read_text())
+  r1 = json.loads((tmp_path / 'rank1.json').read_text())
+  assert r0['ids'] == [0, 47] and r1['ids'] == [48, 95]
+  assert r0['steps'] == r1['steps'] == 1 + 2 + 6
+
+
+def test_shard_ranges():
+  from safe_adaptation_gym_amd.envs import shard_ranges
+  assert shard_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+  assert shard_ranges(4096 * 8, 8)[-1] == (4096 * 7, 4096 * 8)
+  r = shard_ranges(5, 8)
+  assert r[0] == (0, 1) and r[-1] == (5, 5)
