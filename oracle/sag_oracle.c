@@ -285,13 +285,17 @@ void sago_lidar_cost(int K, const float* robot3, const float* points, const uint
 /* ------------------------------------------------------------------------ */
 typedef struct { int type; real ox, oy, a, b; } Geom; /* type 0 circle (a=r), 1 box (a=hx,b=hy) */
 
-typedef struct {
+typedef struct Body_ {
   real x, y, yaw, vx, vy, w;   /* state */
   real ax, ay, aw;             /* accumulated acceleration this substep */
   real minv[6];                /* symmetric inverse inertia: xx, xy, xw, yy, yw, ww (0 for static) */
   int ngeom;
   Geom g[5];
   int dynamic;
+  /* contact material (MuJoCo geom friction[0], priority, solref): the higher priority geom's
+   * values win, equal priority takes max friction / equal solref (all defaults are equal) */
+  real mu, tc, dr;
+  int prio;
 } Body;
 
 typedef struct { real nx, ny, px, py, depth; } Contact;
@@ -402,16 +406,20 @@ static real bound_radius(const Body* b) {
 /* ------------------------------------------------------------------------ */
 /* soft contact (MuJoCo-style reference acceleration, one Gauss-Seidel sweep) */
 /* ------------------------------------------------------------------------ */
-typedef struct { real kcoef, bcoef, h; } Sol;
+typedef struct { real kcoef, bcoef, h, mu; } Sol;
 
-static Sol make_sol(double h) {
-  double tc = SOL_TC < 2 * h ? 2 * h : SOL_TC; /* refsafe */
+static Sol make_sol_tc(double h, double tc0, double dr) {
+  double tc = tc0 < 2 * h ? 2 * h : tc0; /* refsafe */
   Sol s;
   s.bcoef = (real)(2.0 / (SOL_D1 * tc));
-  s.kcoef = (real)(1.0 / (SOL_D1 * SOL_D1 * tc * tc)); /* dampratio 1 */
+  s.kcoef = (real)(1.0 / (SOL_D1 * SOL_D1 * tc * tc * dr * dr));
   s.h = (real)h;
+  s.mu = (real)FRICTION_MU;
   return s;
 }
+static Sol make_sol(double h) { return make_sol_tc(h, SOL_TC, 1.0); }
+
+
 
 static real impedance(real depth) {
   real x = depth / (real)SOL_WIDTH;
@@ -473,14 +481,25 @@ static void solve_contact(Body* A, Body* B, const Contact* c, const Sol* sol) {
   if (B->dynamic) At += minv_apply(B, tx, ty, rbx * ty - rby * tx, ub);
   if (At <= 0) return;
   real ft = d * (-sol->bcoef * vt - at) / At;
-  ft = clampr(ft, -(real)FRICTION_MU * fn, (real)FRICTION_MU * fn);
+  ft = clampr(ft, -sol->mu * fn, sol->mu * fn);
   apply_dir(A, B, tx, ty, rax, ray, rbx, rby, ft, ua, ub);
 }
 
+static Sol pair_sol(const Body* A, const Body* B, const Sol* base) {
+  const Body* P = A->prio > B->prio ? A : (B->prio > A->prio ? B : NULL);
+  real mu = P ? P->mu : (A->mu > B->mu ? A->mu : B->mu);
+  real tc = P ? P->tc : A->tc, dr = P ? P->dr : A->dr;
+  Sol s = make_sol_tc(base->h, tc, dr);
+  s.mu = mu;
+  return s;
+}
+
 /* all contacts of one body pair; returns number of contacts (penetrations) */
-static int collide_pair(Body* A, Body* B, real ra, real rb, const Sol* sol, int solve) {
+static int collide_pair(Body* A, Body* B, real ra, real rb, const Sol* base, int solve) {
   real dx = B->x - A->x, dy = B->y - A->y, rs = ra + rb;
   if (dx * dx + dy * dy > rs * rs) return 0; /* broadphase */
+  Sol psol = pair_sol(A, B, base);
+  const Sol* sol = &psol;
   int total = 0;
   Contact c[8];
   for (int i = 0; i < A->ngeom; i++)
@@ -513,15 +532,125 @@ static void floor_friction(Body* b, real mass, real inertia, real reff, const So
 /* world assembly from the record                                            */
 /* ------------------------------------------------------------------------ */
 typedef struct {
-  Body robot, vase[SAG_MAX_VASES], pillar[SAG_MAX_PILLARS], button[SAG_MAX_BUTTONS];
-  real r_robot, r_vase, r_pillar, r_button;
+  Body robot, vase[SAG_MAX_VASES], pillar[SAG_MAX_PILLARS], button[SAG_MAX_BUTTONS], box;
+  real r_robot, r_vase, r_pillar, r_button, r_box;
   real vase_m, vase_I, vase_reff;
-  int nV, nP, nB;
+  real box_m, box_I;
+  int nV, nP, nB, box_kind, haul;
 } World;
+
+static void material_default(Body* b) { b->mu = (real)FRICTION_MU; b->tc = (real)SOL_TC; b->dr = 1; b->prio = 0; }
 
 static void body_static_circle(Body* b, real x, real y, real r) {
   memset(b, 0, sizeof(*b));
   b->x = x; b->y = y; b->ngeom = 1; b->g[0].type = 0; b->g[0].a = r; b->dynamic = 0;
+  material_default(b);
+}
+
+/* The task object of the PushBox family, as a planar free body.
+ *  BOX  (push_box.py:28-72): box half .2 + four corner columns half .1 at (+-.2, +-.2), density
+ *       .001 each (masses add, overlaps included, as MuJoCo does)
+ *  ROD  (roll_rod.py:19-43): cylinder r .08, half length .3 lying along local y (euler 90 0 0),
+ *       density .0005, friction 1.2 / rolling .05, priority 1.  It rolls along local x
+ *       (translational inertia m + I_axis/r^2 = 1.5 m) and slides along its axis.
+ *  BALL (dribble_ball.py:18-41): sphere r .14, density .0005, friction 1.2 / rolling .05,
+ *       solref (.018, .2), priority 1; rolls in every direction (inertia 1.4 m). */
+#define BOX_DENSITY 0.001
+static void box_from_env(const OEnv* e, World* w) {
+  const real* f = e->f;
+  Body* b = &w->box;
+  memset(b, 0, sizeof(*b));
+  material_default(b);
+  w->box_kind = e->i[SAG_I_BOX_KIND];
+  w->haul = e->i[SAG_I_TASK] == SAG_TASK_HAUL_BOX;
+  if (w->box_kind == SAG_BOX_NONE) return;
+  const real* v = f + SAG_F_BOX;
+  b->x = v[0]; b->y = v[1]; b->yaw = v[2]; b->vx = v[3]; b->vy = v[4]; b->w = v[5];
+  b->dynamic = 1;
+  real c = R_COS(b->yaw), s = R_SIN(b->yaw);
+  if (w->box_kind == SAG_BOX_BOX) {
+    static const real OX[5] = {0, 0.2, -0.2, 0.2, -0.2}, OY[5] = {0, 0.2, 0.2, -0.2, -0.2};
+    b->ngeom = 5;
+    for (int k = 0; k < 5; k++) {
+      b->g[k].type = 1; b->g[k].ox = OX[k]; b->g[k].oy = OY[k];
+      b->g[k].a = b->g[k].b = k == 0 ? (real)0.2 : (real)0.1;
+    }
+    real m0 = (real)BOX_DENSITY * (real)(0.4 * 0.4 * 0.4), m1 = (real)BOX_DENSITY * (real)(0.2 * 0.2 * 0.4);
+    w->box_m = m0 + 4 * m1;
+    w->box_I = m0 * (real)(0.16 + 0.16) / 12 + 4 * (m1 * (real)(0.04 + 0.04) / 12 + m1 * (real)0.08);
+    b->minv[0] = b->minv[3] = 1 / w->box_m; b->minv[5] = 1 / w->box_I;
+  } else if (w->box_kind == SAG_BOX_ROD) {
+    b->ngeom = 1; b->g[0].type = 1; b->g[0].a = (real)0.08; b->g[0].b = (real)0.3;
+    real m = (real)(BOX_DENSITY / 2) * (real)(PI * 0.08 * 0.08 * 0.6);
+    w->box_m = m;
+    w->box_I = m * (real)(3 * 0.08 * 0.08 + 0.6 * 0.6) / 12;
+    /* world-frame inverse of R diag(1.5 m, m) R^T */
+    real ix = 1 / ((real)1.5 * m), iy = 1 / m;
+    b->minv[0] = c * c * ix + s * s * iy; b->minv[1] = c * s * (ix - iy);
+    b->minv[3] = s * s * ix + c * c * iy; b->minv[5] = 1 / w->box_I;
+    b->mu = (real)1.2; b->prio = 1;
+  } else {
+    b->ngeom = 1; b->g[0].type = 0; b->g[0].a = (real)0.14;
+    real m = (real)(BOX_DENSITY / 2) * (real)(4.0 / 3.0 * PI * 0.14 * 0.14 * 0.14);
+    w->box_m = m;
+    w->box_I = (real)0.4 * m * (real)(0.14 * 0.14);
+    b->minv[0] = b->minv[3] = 1 / ((real)1.4 * m); b->minv[5] = 1 / w->box_I;
+    b->mu = (real)1.2; b->prio = 1; b->tc = (real)0.018; b->dr = (real)0.2;
+  }
+  w->r_box = bound_radius(b);
+}
+
+/* floor interaction of the task object (see floor_friction for vases) */
+static void box_floor_friction(World* w, const Sol* sol) {
+  Body* b = &w->box;
+  real d0 = (real)SOL_D0, m = w->box_m, g = (real)GRAVITY;
+  if (w->box_kind == SAG_BOX_BOX) { floor_friction(b, m, w->box_I, (real)(0.2 * 1.41421356237309504880), sol); return; }
+  real c = R_COS(b->yaw), s = R_SIN(b->yaw);
+  /* body-frame velocity / acceleration */
+  real vx = c * b->vx + s * b->vy, vy = -s * b->vx + c * b->vy;
+  real ax = c * b->ax + s * b->ay, ay = -s * b->ax + c * b->ay;
+  real fx, fy, tlim;
+  if (w->box_kind == SAG_BOX_ROD) {
+    real mx = (real)1.5 * m;
+    fx = clampr(-d0 * mx * (sol->bcoef * vx + ax), -(real)0.05 * m * g / (real)0.08, (real)0.05 * m * g / (real)0.08);
+    fy = clampr(-d0 * m * (sol->bcoef * vy + ay), -(real)1.2 * m * g, (real)1.2 * m * g);
+    ax += fx / mx; ay += fy / m;
+    tlim = (real)1.2 * m * g * (real)0.15;
+  } else {
+    real me = (real)1.4 * m, lim = (real)0.05 * m * g / (real)0.14;
+    fx = -d0 * me * (sol->bcoef * vx + ax); fy = -d0 * me * (sol->bcoef * vy + ay);
+    real f2 = fx * fx + fy * fy;
+    if (f2 > lim * lim) { real sc = lim / R_SQRT(f2); fx *= sc; fy *= sc; }
+    ax += fx / me; ay += fy / me;
+    tlim = (real)0.003 * m * g;
+  }
+  b->ax = c * ax - s * ay; b->ay = s * ax + c * ay;
+  real t = clampr(-d0 * w->box_I * (sol->bcoef * b->w + b->aw), -tlim, tlim);
+  b->aw += t / w->box_I;
+}
+
+/* HaulBox (haul_box.py:21-29): spatial tendon robot site <-> box site, limited to [0, .75].
+ * Sites are the robot origin (z .1) and the box centre (z .2): length L = sqrt(d^2 + .1^2).
+ * Beyond the limit it acts as a soft constraint (default solref/solimp) pulling the two
+ * together along the tendon; its planar Jacobian is (d/L) times the unit vector. */
+static void haul_tendon(World* w, const Sol* sol) {
+  Body* A = &w->robot; Body* B = &w->box;
+  real dx = B->x - A->x, dy = B->y - A->y;
+  real d = R_SQRT(dx * dx + dy * dy), L = R_SQRT(d * d + (real)0.01);
+  real viol = L - (real)0.75;
+  if (viol <= 0 || d < (real)1e-9) return;
+  real jx = dx / L, jy = dy / L; /* d(L)/d(pB) ; d(L)/d(pA) = -j */
+  /* rate and acceleration of L along the constraint */
+  real Ldot = jx * (B->vx - A->vx) + jy * (B->vy - A->vy);
+  real Lacc = jx * (B->ax - A->ax) + jy * (B->ay - A->ay);
+  real ua[3], ub[3];
+  real Ainv = minv_apply(A, jx, jy, 0, ua) + minv_apply(B, jx, jy, 0, ub);
+  real dimp = impedance(viol);
+  /* want Lacc -> aref = -b*Ldot - k*viol */
+  real f = dimp * ((-sol->bcoef * Ldot - sol->kcoef * viol) - Lacc) / Ainv;
+  if (f >= 0) return; /* a tendon only pulls */
+  A->ax -= ua[0] * f; A->ay -= ua[1] * f; A->aw -= ua[2] * f;
+  B->ax += ub[0] * f; B->ay += ub[1] * f; B->aw += ub[2] * f;
 }
 
 static void point_minv(Body* b, real damp, real h) {
@@ -547,6 +676,7 @@ static void world_from_env(const OEnv* e, World* w) {
   r->x = f[SAG_F_ROBOT]; r->y = f[SAG_F_ROBOT + 1]; r->yaw = f[SAG_F_ROBOT + 2];
   r->vx = f[SAG_F_ROBOT + 3]; r->vy = f[SAG_F_ROBOT + 4]; r->w = f[SAG_F_ROBOT + 5];
   r->dynamic = 1; r->ngeom = 2;
+  material_default(r);
   r->g[0].type = 0; r->g[0].a = (real)0.1;                       /* point.xml:18 */
   r->g[1].type = 1; r->g[1].ox = (real)0.1; r->g[1].a = (real)0.05; r->g[1].b = (real)0.05; /* :19 */
   w->r_robot = bound_radius(r);
@@ -557,6 +687,7 @@ static void world_from_env(const OEnv* e, World* w) {
     const real* v = f + SAG_F_VASES + 6 * k;
     b->x = v[0]; b->y = v[1]; b->yaw = v[2]; b->vx = v[3]; b->vy = v[4]; b->w = v[5];
     b->dynamic = 1; b->ngeom = 1; b->g[0].type = 1; b->g[0].a = vs; b->g[0].b = vs;
+    material_default(b);
   }
   /* vase mass properties: box of half extent vs, density .001 */
   w->vase_m = (real)VASE_DENSITY * 8 * vs * vs * vs;
@@ -575,6 +706,7 @@ static void world_from_env(const OEnv* e, World* w) {
     body_static_circle(&w->button[k], f[SAG_F_BUTTONS + 2 * k], f[SAG_F_BUTTONS + 2 * k + 1],
                        (real)BUTTON_R);
   w->r_button = (real)BUTTON_R;
+  box_from_env(e, w);
 }
 
 static void world_to_env(const World* w, OEnv* e) {
@@ -585,6 +717,11 @@ static void world_to_env(const World* w, OEnv* e) {
   for (int k = 0; k < w->nV; k++) {
     const Body* b = &w->vase[k];
     real* v = f + SAG_F_VASES + 6 * k;
+    v[0] = b->x; v[1] = b->y; v[2] = b->yaw; v[3] = b->vx; v[4] = b->vy; v[5] = b->w;
+  }
+  if (w->box_kind != SAG_BOX_NONE) {
+    const Body* b = &w->box;
+    real* v = f + SAG_F_BOX;
     v[0] = b->x; v[1] = b->y; v[2] = b->yaw; v[3] = b->vx; v[4] = b->vy; v[5] = b->w;
   }
 }
@@ -629,14 +766,22 @@ static void point_smooth(Body* r, const real ctrl[2], real gear, real damp, real
 
 /* One forward-dynamics evaluation: accelerations of every body at the current
  * state.  Fixed pair order (specification):
- *   robot-pillars, robot-buttons, robot-vases, vase-pillars, vase-buttons,
- *   vase-vase (i<j), then floor friction of each vase.
+ *   robot-pillars, robot-buttons, robot-vases, robot-box, haul tendon,
+ *   vase-pillars/buttons, box-pillars/buttons, vase-vase (i<j), box-vases,
+ *   then floor friction of each vase and of the box.
  * Returns robot/obstacle penetration count (cost rule, mujoco_bridge.py:177-191
- * with prefixes consts.OBSTACLES) and the button contact mask. */
+ * with prefixes consts.OBSTACLES; the box is not an obstacle) and the button contact mask. */
 static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol* sol,
                          uint32_t* btn_mask) {
   point_smooth(&w->robot, ctrl, e->f[SAG_F_GEAR], e->f[SAG_F_DAMP], sol->h);
   for (int k = 0; k < w->nV; k++) { w->vase[k].ax = w->vase[k].ay = w->vase[k].aw = 0; }
+  w->box.ax = w->box.ay = w->box.aw = 0;
+  if (w->box_kind == SAG_BOX_ROD) { /* orientation-dependent inverse inertia */
+    real c = R_COS(w->box.yaw), s = R_SIN(w->box.yaw), ix = 1 / ((real)1.5 * w->box_m), iy = 1 / w->box_m;
+    w->box.minv[0] = c * c * ix + s * s * iy; w->box.minv[1] = c * s * (ix - iy);
+    w->box.minv[3] = s * s * ix + c * c * iy;
+  }
+  const int has_box = w->box_kind != SAG_BOX_NONE;
   int cost_contacts = 0;
   uint32_t mask = 0;
   for (int p = 0; p < w->nP; p++)
@@ -645,16 +790,42 @@ static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol*
     if (collide_pair(&w->robot, &w->button[b], w->r_robot, w->r_button, sol, 1)) mask |= 1u << b;
   for (int k = 0; k < w->nV; k++)
     cost_contacts += collide_pair(&w->robot, &w->vase[k], w->r_robot, w->r_vase, sol, 1);
+  if (has_box) {
+    if (w->box_kind == SAG_BOX_BALL) {
+      /* the ball's centre is .04 above the robot sphere's: they touch at horizontal distance
+       * sqrt(.24^2 - .04^2) - the ball presents radius .1366 to the sphere, .14 to the arrow */
+      Body sphere = w->robot, arrow = w->robot;
+      sphere.ngeom = 1; arrow.ngeom = 1; arrow.g[0] = w->robot.g[1];
+      Body ball = w->box;
+      ball.g[0].a = (real)(0.23664319132398464 - 0.1);
+      collide_pair(&sphere, &ball, w->r_robot, w->r_box, sol, 1);
+      w->robot.ax = sphere.ax; w->robot.ay = sphere.ay; w->robot.aw = sphere.aw;
+      w->box.ax = ball.ax; w->box.ay = ball.ay; w->box.aw = ball.aw;
+      arrow.ax = sphere.ax; arrow.ay = sphere.ay; arrow.aw = sphere.aw;
+      collide_pair(&arrow, &w->box, w->r_robot, w->r_box, sol, 1);
+      w->robot.ax = arrow.ax; w->robot.ay = arrow.ay; w->robot.aw = arrow.aw;
+    } else {
+      collide_pair(&w->robot, &w->box, w->r_robot, w->r_box, sol, 1);
+    }
+    if (w->haul) haul_tendon(w, sol);
+  }
   for (int k = 0; k < w->nV; k++) {
     for (int p = 0; p < w->nP; p++)
       collide_pair(&w->vase[k], &w->pillar[p], w->r_vase, w->r_pillar, sol, 1);
     for (int b = 0; b < w->nB; b++)
       collide_pair(&w->vase[k], &w->button[b], w->r_vase, w->r_button, sol, 1);
   }
+  if (has_box) {
+    for (int p = 0; p < w->nP; p++) collide_pair(&w->box, &w->pillar[p], w->r_box, w->r_pillar, sol, 1);
+    for (int b = 0; b < w->nB; b++) collide_pair(&w->box, &w->button[b], w->r_box, w->r_button, sol, 1);
+  }
   for (int i = 0; i < w->nV; i++)
     for (int j = i + 1; j < w->nV; j++)
       collide_pair(&w->vase[i], &w->vase[j], w->r_vase, w->r_vase, sol, 1);
+  if (has_box)
+    for (int k = 0; k < w->nV; k++) collide_pair(&w->box, &w->vase[k], w->r_box, w->r_vase, sol, 1);
   for (int k = 0; k < w->nV; k++) floor_friction(&w->vase[k], w->vase_m, w->vase_I, w->vase_reff, sol);
+  if (has_box) box_floor_friction(w, sol);
   if (btn_mask) *btn_mask = mask;
   return cost_contacts;
 }
@@ -688,6 +859,7 @@ void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) {
     world_forward(&w, e, ctrl, &sol, NULL);
     integrate(&w.robot, sol.h);
     for (int k = 0; k < w.nV; k++) integrate_free(&w.vase[k], sol.h);
+    if (w.box_kind != SAG_BOX_NONE) integrate_free(&w.box, sol.h);
   }
   world_to_env(&w, e);
 }
@@ -865,8 +1037,39 @@ static void task_reward(OEnv* e, Rng* g, uint32_t btn_mask, OOut* out) {
       out->reward[0] = (real)r;
       break;
     }
+    case SAG_TASK_PUSH_BOX:
+    case SAG_TASK_PUSH_BOX_SCARCE:
+    case SAG_TASK_ROLL_ROD:
+    case SAG_TASK_DRIBBLE_BALL:
+    case SAG_TASK_HAUL_BOX: {
+      /* tasks/push_box.py:74-100 (RollRod, DribbleBall inherit it), push_box_scarce.py:24-50,
+       * haul_box.py:34-48: 2-D distances */
+      double bx = f[SAG_F_BOX], by = f[SAG_F_BOX + 1], gx = f[SAG_F_GOAL], gy = f[SAG_F_GOAL + 1];
+      double r = 0;
+      if (task != SAG_TASK_HAUL_BOX) {
+        double bd = dist2d(rx, ry, bx, by);
+        double prog = (double)f[SAG_F_LAST + 1] - bd;
+        if (task == SAG_TASK_PUSH_BOX_SCARCE) /* indicator(0 <= d <= GOAL_SIZE * 1.70) */
+          prog *= (0 <= bd && bd <= GOAL_SIZE * 1.70) ? 1.0 : 0.0;
+        r += prog;
+        f[SAG_F_LAST + 1] = (real)bd;
+      }
+      double bg = dist2d(bx, by, gx, gy);
+      r += (double)f[SAG_F_LAST + 2] - bg;
+      f[SAG_F_LAST + 2] = (real)bg;
+      if (bg <= GOAL_SIZE) {
+        out->goal_met = 1;
+        goal_reset(e, g); /* GoToGoal.reset: new goal, last goal distance (2-D) */
+        /* PushBox.reset (push_box.py:94-100) */
+        f[SAG_F_LAST + 2] = (real)dist2d(f[SAG_F_GOAL], f[SAG_F_GOAL + 1], bx, by);
+        f[SAG_F_LAST + 1] = (real)dist2d(rx, ry, bx, by);
+        r += 1.0;
+      }
+      out->reward[0] = (real)r;
+      break;
+    }
     default:
-      break; /* box tasks: not in this build of the oracle */
+      break;
   }
 }
 
@@ -1021,6 +1224,10 @@ void sago_task_reset(OEnv* e) {
   else if (task != SAG_TASK_COLLECT) {
     int b = e->i[SAG_I_GOAL_BUTTON];
     f[SAG_F_LAST] = (real)dist2d(f[SAG_F_ROBOT], f[SAG_F_ROBOT + 1], f[SAG_F_BUTTONS + 2 * b], f[SAG_F_BUTTONS + 2 * b + 1]);
+  }
+  if (e->i[SAG_I_BOX_KIND] != SAG_BOX_NONE) { /* PushBox.reset (push_box.py:94-100) */
+    f[SAG_F_LAST + 2] = (real)dist2d(f[SAG_F_GOAL], f[SAG_F_GOAL + 1], f[SAG_F_BOX], f[SAG_F_BOX + 1]);
+    f[SAG_F_LAST + 1] = (real)dist2d(f[SAG_F_ROBOT], f[SAG_F_ROBOT + 1], f[SAG_F_BOX], f[SAG_F_BOX + 1]);
   }
 }
 

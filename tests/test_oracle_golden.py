@@ -38,13 +38,7 @@ def episodes():
   return EPISODES
 
 
-NO_BOX_TASKS = [
-    'catch_goal', 'collect', 'go_to_goal', 'go_to_goal_damping', 'go_to_goal_motor',
-    'go_to_goal_scarce', 'press_buttons', 'press_buttons_scarce', 'unsupervised'
-]
-
-
-@pytest.mark.parametrize('task', NO_BOX_TASKS)
+@pytest.mark.parametrize('task', gu.TASKS)
 def test_episode_matches_reference(oracle, task):
   """Replay the reference's step() (scripted poses) through the oracle with physics
   off: noise draw order, reward, cost, lidar grouping, goal resample, button / catch
@@ -89,6 +83,9 @@ def test_episode_matches_reference(oracle, task):
     ts = st['task_state']
     if ts.get('_last_goal_distance') is not None:
       assert abs(rf[F_LAST] - ts['_last_goal_distance']) < 1e-12
+    if ts.get('_last_box_distance') is not None:
+      assert abs(rf[F_LAST + 1] - ts['_last_box_distance']) < 1e-12
+      assert abs(rf[F_LAST + 2] - ts['_last_box_goal_distance']) < 1e-12
     if 'goal' in names:
       g = st['pos'][names.index('goal')]
       np.testing.assert_allclose(rf[F_GOAL:F_GOAL + 2], g[:2], rtol=0, atol=1e-12)

@@ -155,3 +155,67 @@ def test_f32_oracle_tracks_f64(oracle):
   b = o32.step(e32, 0, [1.0, 0.5], noise=[0, 0], tape=np.zeros(8, np.uint32))
   np.testing.assert_allclose(oracle.record(e64)[0], o32.record(e32)[0], rtol=1e-4, atol=1e-5)
   np.testing.assert_allclose(np.array(a.obs[:60]), np.array(b.obs[:60]), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------
+# PushBox family: the task object as a planar free body (specification)
+# ---------------------------------------------------------------------------
+from oracle_lib import F_BOX, F_KEEPOUT, I_BOX_KIND, I_TASK  # noqa: E402
+
+
+def box_world(task, kind, box_xy, box_yaw=0.0):
+  rf, ri = empty_world(task)
+  ri[I_BOX_KIND] = kind
+  rf[F_BOX:F_BOX + 3] = [box_xy[0], box_xy[1], box_yaw]
+  rf[F_KEEPOUT + 4] = 0.5
+  return rf, ri
+
+
+def test_push_box_is_pushed_not_a_cost(oracle):
+  rf, ri = box_world('push_box', 1, (0.6, 0.0))
+  e, outs = run(oracle, rf, ri, [1.0, 0.0], 80)
+  f, _ = oracle.record(e)
+  assert f[F_BOX] > 0.7, 'box pushed along +x'
+  assert abs(f[F_BOX + 1]) < 0.05
+  assert not any(o.cost for o in outs), 'the box is not an obstacle (consts.OBSTACLES)'
+  # robot stays behind the box face (arrow tip .15 ahead of the origin, box half .2)
+  assert f[F_BOX] - f[F_ROBOT] > 0.34
+  # reward = -d(robot-box) - d(box-goal): pushing towards a far goal at (50,50) is progress
+  assert sum(o.reward[0] for o in outs[40:]) > 0
+
+
+def test_rod_rolls_easier_than_it_slides(oracle):
+  # rod axis along local y: a push along x rolls it, a push along y must slide it (mu 1.2)
+  rf, ri = box_world('roll_rod', 2, (0.45, 0.0))
+  e, _ = run(oracle, rf, ri, [1.0, 0.0], 60)
+  rolled = oracle.record(e)[0][F_BOX] - 0.45
+  rf, ri = box_world('roll_rod', 2, (0.0, 0.65))
+  rf[F_ROBOT + 2] = np.pi / 2
+  e, _ = run(oracle, rf, ri, [1.0, 0.0], 60)
+  slid = oracle.record(e)[0][F_BOX + 1] - 0.65
+  assert rolled > 0.2 and slid > 0.05
+
+
+def test_ball_keeps_rolling_after_the_kick(oracle):
+  rf, ri = box_world('dribble_ball', 3, (0.5, 0.0))
+  e, _ = run(oracle, rf, ri, [1.0, 0.0], 40)
+  f, ri2 = oracle.record(e)
+  v_kick = f[F_BOX + 3]
+  assert v_kick > 0.5
+  e, _ = run(oracle, f, ri2, [-1.0, 0.0], 10)   # robot backs off
+  f2, _ = oracle.record(e)
+  # rolling resistance .05 N / r: deceleration .357 g / 1.4 = 2.5 m/s^2 -> .5 m/s lost in .2 s
+  assert 0 < f2[F_BOX + 3] < v_kick
+  assert abs((v_kick - f2[F_BOX + 3]) - 2.5 * 0.2) < 0.25
+
+
+def test_haul_tendon_limits_the_distance(oracle):
+  rf, ri = box_world('haul_box', 1, (0.6, 0.0))
+  rf[F_ROBOT + 2] = np.pi  # drive away from the box
+  e, _ = run(oracle, rf, ri, [1.0, 0.0], 150)
+  f, _ = oracle.record(e)
+  d = np.hypot(f[F_BOX] - f[F_ROBOT], f[F_BOX + 1] - f[F_ROBOT + 1])
+  L = np.hypot(d, 0.1)
+  assert f[F_ROBOT] < -0.5, 'robot keeps moving'
+  assert L < 0.76, f'tendon stretched to {L}'
+  assert f[F_BOX] < 0.55, 'box is hauled along'
