@@ -767,8 +767,8 @@ static void point_smooth(Body* r, const real ctrl[2], real gear, real damp, real
 /* One forward-dynamics evaluation: accelerations of every body at the current
  * state.  Fixed pair order (specification):
  *   robot-pillars, robot-buttons, robot-vases, robot-box, haul tendon,
- *   vase-pillars/buttons, box-pillars/buttons, vase-vase (i<j), box-vases,
- *   then floor friction of each vase and of the box.
+ *   vase-pillars/buttons, box-pillars/buttons, free-body pairs (i<j, lexicographic, the task
+ *   object counting as the last body), then floor friction of each vase and of the box.
  * Returns robot/obstacle penetration count (cost rule, mujoco_bridge.py:177-191
  * with prefixes consts.OBSTACLES; the box is not an obstacle) and the button contact mask. */
 static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol* sol,
@@ -819,11 +819,12 @@ static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol*
     for (int p = 0; p < w->nP; p++) collide_pair(&w->box, &w->pillar[p], w->r_box, w->r_pillar, sol, 1);
     for (int b = 0; b < w->nB; b++) collide_pair(&w->box, &w->button[b], w->r_box, w->r_button, sol, 1);
   }
-  for (int i = 0; i < w->nV; i++)
+  /* free body pairs in lexicographic order, the task object being the last body */
+  for (int i = 0; i < w->nV; i++) {
     for (int j = i + 1; j < w->nV; j++)
       collide_pair(&w->vase[i], &w->vase[j], w->r_vase, w->r_vase, sol, 1);
-  if (has_box)
-    for (int k = 0; k < w->nV; k++) collide_pair(&w->box, &w->vase[k], w->r_box, w->r_vase, sol, 1);
+    if (has_box) collide_pair(&w->vase[i], &w->box, w->r_vase, w->r_box, sol, 1);
+  }
   for (int k = 0; k < w->nV; k++) floor_friction(&w->vase[k], w->vase_m, w->vase_I, w->vase_reff, sol);
   if (has_box) box_floor_friction(w, sol);
   if (btn_mask) *btn_mask = mask;

@@ -37,6 +37,7 @@ struct sag_ctx {
   hipStream_t stream = nullptr;
   float* S = nullptr;
   int32_t* I = nullptr;
+  float* G = nullptr;  // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   // last installed layout (sag_reset)
   float* L_f = nullptr;   // [N][SAG_REC_FLOATS] AoS, device
   int32_t* L_i = nullptr; // [N][SAG_REC_INTS]
@@ -122,6 +123,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.obs = d_obs; a.reward = d_rew; a.cost = d_cost; a.done = d_done; a.goal_met = d_met;
   a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
+  a.has_box = c->cfg.has_box; a.G = c->G;
   const int blocks = (c->N + WAVE - 1) / WAVE;
   const size_t lds = 0;  // static __shared__ in the kernel
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -141,7 +143,11 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     c->ev_used++;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
-  hipLaunchKernelGGL(k_step_point, dim3(blocks), dim3(WAVE), lds, c->stream, a);
+  const bool btn = c->cfg.max_buttons > 0, tbox = c->cfg.has_box != 0;
+  if (!btn && !tbox) hipLaunchKernelGGL((k_step_point<false, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
+  else if (btn && !tbox) hipLaunchKernelGGL((k_step_point<true, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
+  else if (!btn && tbox) hipLaunchKernelGGL((k_step_point<false, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
+  else hipLaunchKernelGGL((k_step_point<true, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -199,6 +205,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_CHK(hipMalloc(&c->S, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->I, N * DI_COUNT * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->L_f, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->L_i, N * SAG_REC_INTS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->st_f, N * SAG_REC_FLOATS * sizeof(float)));
@@ -225,7 +232,7 @@ int sag_destroy(sag_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  void* bufs[] = {c->S, c->I, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
+  void* bufs[] = {c->S, c->I, c->G, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
                   c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);

@@ -22,7 +22,6 @@
 namespace sag {
 
 constexpr int WAVE = 64;
-constexpr int VCOMP = 9;  // x y yaw vx vy w ax ay aw per vase in LDS
 
 // device int fields
 enum { DI_META = 0, DI_TSTATE = 1, DI_STEP = 2, DI_ENVID = 3, DI_FLAGS = 4, DI_COUNT = 5 };
@@ -66,6 +65,8 @@ struct StepArgs {
   uint8_t* goal_met;
   int32_t* tape_used;
   int32_t max_vases, max_hazards, max_pillars, max_buttons;  // context capacities (load bounds)
+  int32_t has_box;
+  float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
 };
 
@@ -144,6 +145,7 @@ struct BV {  // body view used by the contact solver
   float m0, m1, m2, m3, m4, m5;  // symmetric inverse inertia xx xy xw yy yw ww
   int dyn;
 };
+struct Sol { float bcoef, kcoef, mu; };  // soft-contact reference acceleration + friction of a pair
 
 __device__ inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
@@ -170,7 +172,7 @@ __device__ inline float impedance(float depth) {
 
 // soft contact, normal then friction; n points from A to B
 __device__ inline void solve_contact(BV& A, BV& B, float nx, float ny, float px, float py,
-                                     float depth, float bcoef, float kcoef) {
+                                     float depth, const Sol& sol) {
   float rax = px - A.x, ray = py - A.y, rbx = px - B.x, rby = py - B.y;
   float vx, vy, ax, ay, ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
   rel_at(A, B, rax, ray, rbx, rby, vx, vy, ax, ay);
@@ -179,7 +181,7 @@ __device__ inline void solve_contact(BV& A, BV& B, float nx, float ny, float px,
   if (B.dyn) An += minv_apply(B, nx, ny, rbx * ny - rby * nx, ub);
   if (!(An > 0)) return;
   float d = impedance(depth);
-  float fn = d * ((-bcoef * vn + kcoef * depth) - an) / An;
+  float fn = d * ((-sol.bcoef * vn + sol.kcoef * depth) - an) / An;
   if (!(fn > 0)) return;
   if (A.dyn) { A.ax -= ua[0] * fn; A.ay -= ua[1] * fn; A.aw -= ua[2] * fn; }
   if (B.dyn) { B.ax += ub[0] * fn; B.ay += ub[1] * fn; B.aw += ub[2] * fn; }
@@ -189,28 +191,27 @@ __device__ inline void solve_contact(BV& A, BV& B, float nx, float ny, float px,
   if (A.dyn) At += minv_apply(A, tx, ty, rax * ty - ray * tx, ua);
   if (B.dyn) At += minv_apply(B, tx, ty, rbx * ty - rby * tx, ub);
   if (!(At > 0)) return;
-  float ft = clampf(d * (-bcoef * vt - at) / At, -MU * fn, MU * fn);
+  float ft = clampf(d * (-sol.bcoef * vt - at) / At, -sol.mu * fn, sol.mu * fn);
   if (A.dyn) { A.ax -= ua[0] * ft; A.ay -= ua[1] * ft; A.aw -= ua[2] * ft; }
   if (B.dyn) { B.ax += ub[0] * ft; B.ay += ub[1] * ft; B.aw += ub[2] * ft; }
 }
 
 // circle (A, centre ax,ay radius ra) vs circle (B)
 __device__ inline int cc_contact(BV& A, BV& B, float ax, float ay, float ra, float bx, float by,
-                                 float rb, float bcoef, float kcoef) {
+                                 float rb, const Sol& sol) {
   float dx = bx - ax, dy = by - ay, d2 = dx * dx + dy * dy, rs = ra + rb;
   if (d2 >= rs * rs) return 0;
   float d = sqrtf(d2), nx = 1, ny = 0;
   if (d > 1e-12f) { nx = dx / d; ny = dy / d; }
   float depth = rs - d;
-  solve_contact(A, B, nx, ny, ax + nx * (ra - 0.5f * depth), ay + ny * (ra - 0.5f * depth), depth,
-                bcoef, kcoef);
+  solve_contact(A, B, nx, ny, ax + nx * (ra - 0.5f * depth), ay + ny * (ra - 0.5f * depth), depth, sol);
   return 1;
 }
 
 // circle vs oriented box; `circle_is_A` selects the normal direction (A -> B)
 __device__ inline int cb_contact(BV& Circ, BV& Box, float cx, float cy, float r, float bx, float by,
                                  float cb, float sb, float hx, float hy, bool circle_is_A,
-                                 float bcoef, float kcoef) {
+                                 const Sol& sol) {
   float wx = cx - bx, wy = cy - by;
   float lx = cb * wx + sb * wy, ly = -sb * wx + cb * wy;
   float qx = clampf(lx, -hx, hx), qy = clampf(ly, -hy, hy);
@@ -228,8 +229,8 @@ __device__ inline int cb_contact(BV& Circ, BV& Box, float cx, float cy, float r,
   // outward normal of the box, world frame; points from box to circle
   float wnx = cb * onx - sb * ony, wny = sb * onx + cb * ony;
   float px = bx + cb * qx - sb * qy, py = by + sb * qx + cb * qy;
-  if (circle_is_A) solve_contact(Circ, Box, -wnx, -wny, px, py, depth, bcoef, kcoef);
-  else solve_contact(Box, Circ, wnx, wny, px, py, depth, bcoef, kcoef);
+  if (circle_is_A) solve_contact(Circ, Box, -wnx, -wny, px, py, depth, sol);
+  else solve_contact(Box, Circ, wnx, wny, px, py, depth, sol);
   return 1;
 }
 
@@ -237,7 +238,7 @@ __device__ inline int cb_contact(BV& Circ, BV& Box, float cx, float cy, float r,
 // normal, else its negative.  A/B are passed in solver order.
 __device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp, float sp, float phx,
                                    float phy, float qxc, float qyc, float cq, float sq, float qhx,
-                                   float qhy, bool q_is_A, float bcoef, float kcoef) {
+                                   float qhy, bool q_is_A, const Sol& sol) {
   int n = 0;
 #pragma unroll 1
   for (int k = 0; k < 4; k++) {
@@ -251,8 +252,7 @@ __device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp,
     if (dx < dy) { onx = lx >= 0 ? 1.f : -1.f; ony = 0; depth = dx; }
     else { onx = 0; ony = ly >= 0 ? 1.f : -1.f; depth = dy; }
     float sgn = q_is_A ? 1.f : -1.f;
-    solve_contact(A, B, sgn * (cq * onx - sq * ony), sgn * (sq * onx + cq * ony), vx, vy, depth,
-                  bcoef, kcoef);
+    solve_contact(A, B, sgn * (cq * onx - sq * ony), sgn * (sq * onx + cq * ony), vx, vy, depth, sol);
     n++;
   }
   return n;
@@ -260,9 +260,9 @@ __device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp,
 
 __device__ inline int bb_contact(BV& A, BV& B, float ax, float ay, float ca, float sa, float ahx,
                                  float ahy, float bx, float by, float cb, float sb, float bhx,
-                                 float bhy, float bcoef, float kcoef) {
-  int n = verts_in_box(A, B, ax, ay, ca, sa, ahx, ahy, bx, by, cb, sb, bhx, bhy, false, bcoef, kcoef);
-  n += verts_in_box(A, B, bx, by, cb, sb, bhx, bhy, ax, ay, ca, sa, ahx, ahy, true, bcoef, kcoef);
+                                 float bhy, const Sol& sol) {
+  int n = verts_in_box(A, B, ax, ay, ca, sa, ahx, ahy, bx, by, cb, sb, bhx, bhy, false, sol);
+  n += verts_in_box(A, B, bx, by, cb, sb, bhx, bhy, ax, ay, ca, sa, ahx, ahy, true, sol);
   return n;
 }
 
@@ -271,26 +271,90 @@ __device__ inline double dist2d(double ax, double ay, double bx, double by) {
   return sqrt(dx * dx + dy * dy);
 }
 
+// ---- shapes -------------------------------------------------------------------
+// A body's footprint is a list of geoms (circle or axis-aligned box in the body frame).
+// Shape codes: the robot, a vase, the PushBox-family task object (box / rod / ball), a static
+// circle.  Values follow point.xml:18-19, primitive_objects.py, push_box.py:28-72,
+// roll_rod.py:19-43, dribble_ball.py:18-41.
+enum { SH_ROBOT = 0, SH_VASE = 1, SH_BOX = 2, SH_ROD = 3, SH_BALL = 4, SH_STATIC = 5 };
+struct Geom { int box; float ox, oy, a, b; };  // box ? half extents (a, b) : radius a
+
+__device__ inline int shape_ngeom(int sh) { return sh == SH_ROBOT ? 2 : (sh == SH_BOX ? 5 : 1); }
+
+__device__ inline Geom shape_geom(int sh, int g, float vsz, float rstatic) {
+  Geom q; q.ox = 0; q.oy = 0; q.b = 0;
+  switch (sh) {
+    case SH_ROBOT: q.box = g; q.ox = g ? 0.1f : 0.f; q.a = g ? 0.05f : 0.1f; q.b = 0.05f; break;
+    case SH_VASE: q.box = 1; q.a = vsz; q.b = vsz; break;
+    case SH_BOX:
+      q.box = 1; q.a = q.b = g ? 0.1f : 0.2f;
+      q.ox = g == 0 ? 0.f : ((g & 1) ? 0.2f : -0.2f);      // g: 1 (+,+) 2 (-,+) 3 (+,-) 4 (-,-)
+      q.oy = g == 0 ? 0.f : (g <= 2 ? 0.2f : -0.2f);
+      break;
+    case SH_ROD: q.box = 1; q.a = 0.08f; q.b = 0.3f; break;
+    case SH_BALL: q.box = 0; q.a = 0.14f; break;
+    default: q.box = 0; q.a = rstatic; break;
+  }
+  return q;
+}
+
+__device__ inline float shape_bound(int sh, float vsz, float rstatic) {
+  switch (sh) {
+    case SH_ROBOT: return ROBOT_BOUND;
+    case SH_VASE: return vsz * 1.41421356237309504880f;
+    case SH_BOX: return 0.42426406871192851f;   // column corner (0.3, 0.3)
+    case SH_ROD: return 0.31048349392520047f;   // sqrt(.08^2 + .3^2)
+    case SH_BALL: return 0.14f;
+    default: return rstatic;
+  }
+}
+
+// every geom pair of two bodies, geoms of A outer, of B inner (the specification's order)
+__device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, int shB, float cb,
+                                     float sb, float vsz, float rstatic, const Sol& sol) {
+  int n = 0;
+  const int na = shape_ngeom(shA), nb = shape_ngeom(shB);
+#pragma unroll 1
+  for (int ga = 0; ga < na; ga++) {
+    const Geom a = shape_geom(shA, ga, vsz, rstatic);
+    const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;
+#pragma unroll 1
+    for (int gb = 0; gb < nb; gb++) {
+      Geom b = shape_geom(shB, gb, vsz, rstatic);
+      // the ball's centre is .04 above the robot sphere's: it presents sqrt(.24^2-.04^2)-.1
+      if (shA == SH_ROBOT && ga == 0 && shB == SH_BALL) b.a = 0.13664319132398464f;
+      const float bx = B.x + cb * b.ox - sb * b.oy, by = B.y + sb * b.ox + cb * b.oy;
+      // per-geom bounding circles first
+      const float ra = a.box ? sqrtf(a.a * a.a + a.b * a.b) : a.a, rb = b.box ? sqrtf(b.a * b.a + b.b * b.b) : b.a;
+      const float dx = bx - ax, dy = by - ay, rs = ra + rb;
+      if (dx * dx + dy * dy > rs * rs) continue;
+      if (!a.box && !b.box) n += cc_contact(A, B, ax, ay, a.a, bx, by, b.a, sol);
+      else if (!a.box) n += cb_contact(A, B, ax, ay, a.a, bx, by, cb, sb, b.a, b.b, true, sol);
+      else if (!b.box) n += cb_contact(B, A, bx, by, b.a, ax, ay, ca, sa, a.a, a.b, false, sol);
+      else n += bb_contact(A, B, ax, ay, ca, sa, a.a, a.b, bx, by, cb, sb, b.a, b.b, sol);
+    }
+  }
+  return n;
+}
+
 // ---------------------------------------------------------------------------
 // the fused step kernel (Point robot)
 // ---------------------------------------------------------------------------
+// Free bodies: index 0..9 vases, 10 the task object (PushBox family).
 // LDS map (floats), one wavefront per workgroup, [slot][lane]:
-//   slots  0.. 9 vase x      10..19 vase y     20..29 vase yaw
-//         30..39 vase vx     40..49 vase vy    50..59 vase w
-//         60..69 vase ax     70..79 vase ay    80..89 vase aw
-// After the physics the region from slot 30 on is reused as the observation staging
-// area [lane][61] (48 lidar bins + 12 sensors, row stride 61 = conflict-free both for
-// the per-lane writes and for the transposed, fully coalesced read-out).
-#ifdef SAG_LDS_ALIAS  // timing probe only (wrong results): fold the 90 slots onto 45
-constexpr int LDS_FLOATS = 3968;
-constexpr int STG_BASE = 0, STG_STRIDE = 61;
-#define SLOT_MOD(x) ((x) % 45)
-#else
-constexpr int LDS_FLOATS = 6016;  // 90 slots * 64 + tail of the staging area
-constexpr int STG_BASE = 30 * WAVE, STG_STRIDE = 61;
-#define SLOT_MOD(x) (x)
-#endif
-enum { VS_X = 0, VS_Y = 10, VS_YAW = 20, VS_VX = 30, VS_VY = 40, VS_W = 50, VS_AX = 60, VS_AY = 70, VS_AW = 80 };
+//   slots  0..10 x      11..21 y      22..32 yaw            (every free body)
+//         33..50 a pool of DPOOL dynamic entries (vx vy w ax ay aw), handed to the bodies that
+//                move or get touched during the step; further ones spill to global memory
+// = 13 KB per wavefront -> 12 wavefronts per CU.  For the observation the region from slot 22
+// on is reused as a [lane][17] staging tile per 16-column chunk, read back transposed so the
+// row-major [N][60] output is written in 64-B runs instead of scattered dwords.
+constexpr int NBODY = SAG_MAX_VASES + 1, BOX_ID = SAG_MAX_VASES;
+constexpr int DPOOL = 3;
+enum { LS_X = 0, LS_Y = NBODY, LS_YAW = 2 * NBODY, LS_POOL = 3 * NBODY };
+constexpr int LDS_SLOTS = LS_POOL + 6 * DPOOL;
+constexpr int LDS_FLOATS = LDS_SLOTS * WAVE;
+constexpr int STG_BASE = LS_YAW * WAVE, STG_STRIDE = 17;
+static_assert(STG_BASE + WAVE * STG_STRIDE <= LDS_FLOATS, "staging tile must fit");
 
 // timing-only ablations (tools/ablate.py): -DSAG_ABLATE=<mask>; results are wrong by design
 #ifndef SAG_ABLATE
@@ -300,24 +364,61 @@ enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL
        ABL_NSUB1 = 64, ABL_NO_ACTIVE = 128 };
 #define ABL(f) ((SAG_ABLATE & (f)) != 0)
 #define SF(k) S[(size_t)(k) * N + i]
-#define LV(comp, k) lds[SLOT_MOD((comp) + (k)) * WAVE + lane]
+#define LP(base, k) lds[((base) + (k)) * WAVE + lane]
+#define POOL(d, c) lds[(LS_POOL + (d) * 6 + (c)) * WAVE + lane]
 #define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]
 
-// tstate bits 17..26: vase k has non-zero velocity (derived; lets the kernel skip the
-// velocity loads and the write-back of sleeping vases).  meta bit 19: some bodies overlap
-// at rest, so no vase may be treated as asleep (never the case for sampled layouts).
-constexpr uint32_t TS_AWAKE_SHIFT = 17, TS_AWAKE_MASK = 0x3ffu << 17;
-constexpr uint32_t META_FULL_PAIRS = 1u << 19;
+// tstate bits 17..27: body k has non-zero velocity or may overlap something (derived at
+// install); lets the kernel skip the loads, pair tests and write-back of sleeping bodies.
+constexpr uint32_t TS_AWAKE_SHIFT = 17, TS_AWAKE_BITS = (1u << NBODY) - 1;
 
-__device__ inline void load_vase(const float* lds, int lane, int k, float inv_m, float inv_I, BV& V) {
-  V.x = LV(VS_X, k); V.y = LV(VS_Y, k);
-  V.vx = LV(VS_VX, k); V.vy = LV(VS_VY, k); V.w = LV(VS_W, k);
-  V.ax = LV(VS_AX, k); V.ay = LV(VS_AY, k); V.aw = LV(VS_AW, k);
-  V.m0 = inv_m; V.m1 = 0; V.m2 = 0; V.m3 = inv_m; V.m4 = 0; V.m5 = inv_I; V.dyn = 1;
-}
-__device__ inline void store_vase_acc(float* lds, int lane, int k, const BV& V) {
-  LV(VS_AX, k) = V.ax; LV(VS_AY, k) = V.ay; LV(VS_AW, k) = V.aw;
-}
+// per-lane view of the dynamic part of the free bodies
+struct Dyn {
+  float* lds; float* S; float* G; int lane, N, i;
+  uint32_t dmap;  // 2 bits per body: 0 = no pool entry, 1..DPOOL
+  uint32_t ovf;   // bodies whose velocity/acceleration live in global memory
+  int nd;
+  __device__ int vel_field(int k) const { return k == BOX_ID ? SAG_F_BOX + 3 : SAG_F_VASES + 6 * k + 3; }
+  __device__ int slot(int k) const { return (int)(dmap >> (2 * k) & 3u) - 1; }
+  __device__ bool has(int k) const { return (dmap >> (2 * k) & 3u) || (ovf >> k & 1u); }
+  // give body k a dynamic entry (zero velocity unless `from_state`, zero acceleration)
+  __device__ void ensure(int k, bool from_state) {
+    if (has(k)) return;
+    float vx = 0, vy = 0, w = 0;
+    if (nd < DPOOL) {
+      if (from_state) { const int f = vel_field(k); vx = SF(f); vy = SF(f + 1); w = SF(f + 2); }
+      const int d = nd++;
+      dmap |= (uint32_t)(d + 1) << (2 * k);
+      POOL(d, 0) = vx; POOL(d, 1) = vy; POOL(d, 2) = w; POOL(d, 3) = 0; POOL(d, 4) = 0; POOL(d, 5) = 0;
+    } else {
+      ovf |= 1u << k;  // velocity stays in its SoA home, acceleration in the spill array
+      if (!from_state) { const int f = vel_field(k); SF(f) = 0; SF(f + 1) = 0; SF(f + 2) = 0; }
+      for (int c = 0; c < 3; c++) G[((size_t)c * NBODY + k) * N + i] = 0;
+    }
+  }
+  __device__ void get(int k, float& vx, float& vy, float& w, float& ax, float& ay, float& aw) const {
+    const int d = slot(k);
+    if (d >= 0) { vx = POOL(d, 0); vy = POOL(d, 1); w = POOL(d, 2); ax = POOL(d, 3); ay = POOL(d, 4); aw = POOL(d, 5); }
+    else if (ovf >> k & 1u) {
+      const int f = vel_field(k);
+      vx = SF(f); vy = SF(f + 1); w = SF(f + 2);
+      ax = G[((size_t)0 * NBODY + k) * N + i]; ay = G[((size_t)1 * NBODY + k) * N + i]; aw = G[((size_t)2 * NBODY + k) * N + i];
+    } else { vx = vy = w = ax = ay = aw = 0; }
+  }
+  __device__ void set_acc(int k, float ax, float ay, float aw) {
+    const int d = slot(k);
+    if (d >= 0) { POOL(d, 3) = ax; POOL(d, 4) = ay; POOL(d, 5) = aw; }
+    else { G[((size_t)0 * NBODY + k) * N + i] = ax; G[((size_t)1 * NBODY + k) * N + i] = ay; G[((size_t)2 * NBODY + k) * N + i] = aw; }
+  }
+  __device__ void set_vel(int k, float vx, float vy, float w) {
+    const int d = slot(k);
+    if (d >= 0) { POOL(d, 0) = vx; POOL(d, 1) = vy; POOL(d, 2) = w; }
+    else { const int f = vel_field(k); SF(f) = vx; SF(f + 1) = vy; SF(f + 2) = w; }
+  }
+};
+
+// constants of a free body: shape code, inverse inertia (world frame), friction model
+struct BodyK { int sh; float m, I, reff; };
 
 // lidar: fp32 estimate of (bin, alias); the fp64 evaluation (the reference's arithmetic,
 // safe_adaptation_gym.py:208-216) is redone whenever the estimate is within 2e-5 bins of a
@@ -340,9 +441,8 @@ __device__ __attribute__((noinline)) LidarHit lidar_exact(double rx, double ry, 
   return h;
 }
 
-__device__ inline void lidar_point(float* lds, int lane, int group_off, double rx, double ry,
-                                   double cd, double sd, float rxf, float ryf, float cf, float sf,
-                                   float px, float py) {
+__device__ inline void lidar_point(float* lds, int lane, double rx, double ry, double cd, double sd,
+                                   float rxf, float ryf, float cf, float sf, float px, float py) {
   const float w0 = px - rxf, w1 = py - ryf;
   const float ex = w0 * cf + w1 * sf, ey = w1 * cf - w0 * sf;
   const float dist = sqrtf(ex * ex + ey * ey);
@@ -357,19 +457,24 @@ __device__ inline void lidar_point(float* lds, int lane, int group_off, double r
     bin = h.bin; alias = h.alias; sensor = h.sensor;
   }
   const int bp = (bin + 1) & 15, bm = (bin + 15) & 15;
-  float* o = &STG(group_off);
+  float* o = &STG(0);
   o[bin] = fmaxf(o[bin], sensor);
   o[bp] = fmaxf(o[bp], alias * sensor);
   o[bm] = fmaxf(o[bm], (1.0f - alias) * sensor);
 }
 
 #ifndef SAG_STEP_MIN_WAVES
-#define SAG_STEP_MIN_WAVES 1
+#define SAG_STEP_MIN_WAVES 2  // 245 VGPRs: 8 waves per CU; forcing 3 per SIMD spills (measured slower)
 #endif
-__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArgs p) {
 #ifndef SAG_LDS_PAD
 #define SAG_LDS_PAD 0
 #endif
+// HAS_BTN / HAS_TBOX: compile-time knowledge that the context holds no buttons / no task object
+// (capacities of sag_create); the specialised instances drop those arrays, loops and the box
+// shapes altogether.  <true, true> serves mixed (multitask) batches.
+template <bool HAS_BTN, bool HAS_TBOX>
+__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArgs p) {
+  constexpr int NSTAT = SAG_MAX_PILLARS + (HAS_BTN ? SAG_MAX_BUTTONS : 0);
   __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
   const int lane = threadIdx.x;
   const int N = p.N;
@@ -378,7 +483,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
   const int i = live ? gi : N - 1;  // idle lanes shadow the last env; they never store
   float* __restrict__ S = p.S;
   int32_t* __restrict__ I = p.I;
-  const int capV = p.max_vases, capH = p.max_hazards, capP = p.max_pillars, capB = p.max_buttons;
+  const int capV = p.max_vases, capH = p.max_hazards, capP = p.max_pillars, capB = HAS_BTN ? p.max_buttons : 0;
 
   // ---- issue every load up front (bounds are context capacities, not per-env counts, so
   //      nothing waits on the meta word) ------------------------------------------------------
@@ -401,10 +506,8 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
     a0 = a.x; a1 = a.y;
     if (p.noise) { const float2 z = reinterpret_cast<const float2*>(p.noise)[i]; n0 = z.x; n1 = z.y; }
   }
-  uint32_t awake = (tstate >> TS_AWAKE_SHIFT) & 0x3ffu;
-  if (meta & META_FULL_PAIRS) awake = 0x3ffu;
   {
-    float vpos[SAG_MAX_VASES * 3];
+    float vpos[NBODY * 3];
 #pragma unroll
     for (int k = 0; k < SAG_MAX_VASES; k++) {
       if (k < capV) {
@@ -412,38 +515,28 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
         vpos[3 * k + 2] = SF(SAG_F_VASES + 6 * k + 2);
       } else { vpos[3 * k] = vpos[3 * k + 1] = vpos[3 * k + 2] = 0; }
     }
+    if (HAS_TBOX && p.has_box) { vpos[3 * BOX_ID] = SF(SAG_F_BOX); vpos[3 * BOX_ID + 1] = SF(SAG_F_BOX + 1); vpos[3 * BOX_ID + 2] = SF(SAG_F_BOX + 2); }
+    else { vpos[3 * BOX_ID] = vpos[3 * BOX_ID + 1] = vpos[3 * BOX_ID + 2] = 0; }
 #pragma unroll
-    for (int k = 0; k < SAG_MAX_VASES; k++) {
-      LV(VS_X, k) = vpos[3 * k]; LV(VS_Y, k) = vpos[3 * k + 1]; LV(VS_YAW, k) = vpos[3 * k + 2];
-      float vx = 0, vy = 0, w = 0;
-      if (k < capV && (awake >> k & 1)) {
-        vx = SF(SAG_F_VASES + 6 * k + 3); vy = SF(SAG_F_VASES + 6 * k + 4); w = SF(SAG_F_VASES + 6 * k + 5);
-      }
-      LV(VS_VX, k) = vx; LV(VS_VY, k) = vy; LV(VS_W, k) = w;
-    }
+    for (int k = 0; k < NBODY; k++) { LP(LS_X, k) = vpos[3 * k]; LP(LS_Y, k) = vpos[3 * k + 1]; LP(LS_YAW, k) = vpos[3 * k + 2]; }
   }
   // static colliders: pillars then buttons, in registers
-  float stx[SAG_MAX_PILLARS + SAG_MAX_BUTTONS], sty[SAG_MAX_PILLARS + SAG_MAX_BUTTONS];
+  float stx[NSTAT], sty[NSTAT];
 #pragma unroll
   for (int k = 0; k < SAG_MAX_PILLARS; k++) {
     stx[k] = k < capP ? SF(SAG_F_PILLARS + 2 * k) : 0.f;
     sty[k] = k < capP ? SF(SAG_F_PILLARS + 2 * k + 1) : 0.f;
   }
+  if constexpr (HAS_BTN) {
 #pragma unroll
-  for (int k = 0; k < SAG_MAX_BUTTONS; k++) {
-    stx[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k) : 0.f;
-    sty[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k + 1) : 0.f;
+    for (int k = 0; k < SAG_MAX_BUTTONS; k++) {
+      stx[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k) : 0.f;
+      sty[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k + 1) : 0.f;
+    }
   }
-  float hzx[SAG_MAX_HAZARDS], hzy[SAG_MAX_HAZARDS];
-#pragma unroll
-  for (int k = 0; k < SAG_MAX_HAZARDS; k++) {
-    hzx[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k) : 0.f;
-    hzy[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k + 1) : 0.f;
-  }
-  const float hsz = SF(SAG_F_HAZARD_SIZE);
-
   const int task = meta & 15, nH = meta >> 4 & 15, nV = meta >> 8 & 15, nP = meta >> 12 & 3,
-            nB = meta >> 14 & 7, box_kind = meta >> 17 & 3;
+            nB = HAS_BTN ? (meta >> 14 & 7) : 0, box_kind = HAS_TBOX ? (meta >> 17 & 3) : 0;
+  const bool has_box = HAS_TBOX && box_kind != SAG_BOX_NONE;
   int flags = 0;
 
   Rng rng;
@@ -487,20 +580,57 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
     }
   }
 
-  // ---- physics: nstep x (forward, integrate) + one forward at the final state ---
+  // ---- free-body constants ---------------------------------------------------------
   const float h = p.h;
   const float tc = fmaxf(0.02f, 2.0f * h);
-  const float bcoef = 2.0f / (SOL_D1 * tc), kcoef = 1.0f / (SOL_D1 * SOL_D1 * tc * tc);
-  const float vase_m = VASE_DENSITY * 8 * vsz * vsz * vsz;
-  const float vase_I = vase_m * (8 * vsz * vsz) / 12;
-  const float vase_r = vsz * 1.41421356237309504880f;
-  const float inv_vm = 1.0f / vase_m, inv_vI = 1.0f / vase_I;
+  Sol sol0; sol0.bcoef = 2.0f / (SOL_D1 * tc); sol0.kcoef = 1.0f / (SOL_D1 * SOL_D1 * tc * tc); sol0.mu = MU;
+  Sol solb = sol0;  // pairs that involve the task object (priority-1 geoms of rod / ball win)
+  if (box_kind == SAG_BOX_ROD || box_kind == SAG_BOX_BALL) solb.mu = 1.2f;
+  if (box_kind == SAG_BOX_BALL) {
+    const float tcb = fmaxf(0.018f, 2.0f * h);
+    solb.bcoef = 2.0f / (SOL_D1 * tcb); solb.kcoef = 1.0f / (SOL_D1 * SOL_D1 * tcb * tcb * 0.2f * 0.2f);
+  }
+  BodyK vk, bk;
+  vk.sh = SH_VASE; vk.m = VASE_DENSITY * 8 * vsz * vsz * vsz; vk.I = vk.m * (8 * vsz * vsz) / 12;
+  vk.reff = vsz * 1.41421356237309504880f;
+  bk.sh = SH_BOX; bk.m = 1; bk.I = 1; bk.reff = 0.2f * 1.41421356237309504880f;
+  if (box_kind == SAG_BOX_BOX) {
+    const float m0 = 0.001f * 0.064f, m1 = 0.001f * 0.016f;
+    bk.m = m0 + 4 * m1; bk.I = m0 * 0.32f / 12 + 4 * (m1 * 0.08f / 12 + m1 * 0.08f);
+  } else if (box_kind == SAG_BOX_ROD) {
+    bk.sh = SH_ROD; bk.m = 0.0005f * (3.14159265358979323846f * 0.08f * 0.08f * 0.6f);
+    bk.I = bk.m * (3 * 0.08f * 0.08f + 0.36f) / 12;
+  } else if (box_kind == SAG_BOX_BALL) {
+    bk.sh = SH_BALL; bk.m = 0.0005f * (4.0f / 3.0f * 3.14159265358979323846f * 0.14f * 0.14f * 0.14f);
+    bk.I = 0.4f * bk.m * 0.14f * 0.14f;
+  }
+  const float vase_r = vk.reff, box_r = shape_bound(bk.sh, vsz, 0);
+  // body view of free body k (positions from LDS, dynamics from the pool), its cos/sin
+  auto load_body = [&](const Dyn& dy, int k, BV& V, float& c, float& s) {
+    V.x = LP(LS_X, k); V.y = LP(LS_Y, k);
+    dy.get(k, V.vx, V.vy, V.w, V.ax, V.ay, V.aw);
+    sincosf(LP(LS_YAW, k), &s, &c);
+    V.dyn = 1; V.m1 = 0; V.m2 = 0; V.m4 = 0;
+    if (k != BOX_ID) { V.m0 = V.m3 = 1.0f / vk.m; V.m5 = 1.0f / vk.I; }
+    else {
+      V.m5 = 1.0f / bk.I;
+      if (bk.sh == SH_ROD) {  // rolls along local x (1.5 m), slides along its axis (m)
+        const float ix = 1.0f / (1.5f * bk.m), iy = 1.0f / bk.m;
+        V.m0 = c * c * ix + s * s * iy; V.m1 = c * s * (ix - iy); V.m3 = s * s * ix + c * c * iy;
+      } else if (bk.sh == SH_BALL) { V.m0 = V.m3 = 1.0f / (1.4f * bk.m); }
+      else { V.m0 = V.m3 = 1.0f / bk.m; }
+    }
+  };
+
+  // ---- physics: nstep x (forward, integrate) + one forward at the final state ---
   const int nsub = p.observe_only ? 0 : (ABL(ABL_NSUB1) ? 1 : p.nstep);
   // statics occupy [0, capP) and [SAG_MAX_PILLARS, SAG_MAX_PILLARS + capB) of stx/sty
   const int n_static = capB ? SAG_MAX_PILLARS + capB : capP;
-  const uint32_t vmask = (1u << nV) - 1;
-  awake &= vmask;
-  uint32_t dirty = 0;  // vases whose state changed during this step
+  const uint32_t fmask = ((1u << nV) - 1) | (has_box ? 1u << BOX_ID : 0u);
+  uint32_t awake = (tstate >> TS_AWAKE_SHIFT) & fmask;
+  Dyn dy; dy.lds = lds; dy.S = S; dy.G = p.G; dy.lane = lane; dy.N = N; dy.i = i; dy.dmap = 0; dy.ovf = 0; dy.nd = 0;
+  for (uint32_t m = awake; m; m &= m - 1) dy.ensure(__ffs(m) - 1, true);
+  uint32_t dirty = 0;  // bodies whose state changed during this step
   int cost_contacts = 0;
   uint32_t btn_mask = 0;
   float cy = 1, sy = 0;
@@ -529,17 +659,13 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
       R.ay = R.m1 * Fx + R.m3 * Fy + R.m4 * Tz;
       R.aw = R.m2 * Fx + R.m4 * Fy + R.m5 * Tz;
     }
-    const float arx = R.x + cy * 0.1f, ary = R.y + sy * 0.1f;  // arrow box centre
     cost_contacts = 0; btn_mask = 0;
-    // `active` = vases that can have a non-zero acceleration or velocity this substep.
-    // A sleeping vase (v = 0, untouched) overlaps nothing (invariant of sampled layouts, else
-    // META_FULL_PAIRS), so every pair test it would take part in is a no-op and is skipped;
-    // the pair ORDER of the specification is kept for the ones that run.
+    // `active` = bodies that can have a non-zero acceleration or velocity this substep.
+    // A sleeping body (v = 0, untouched) overlaps nothing, so every pair test it would take
+    // part in is a no-op and is skipped; the pair ORDER of the specification is kept for the
+    // pairs that run (oracle world_forward tests all of them).
     uint32_t active = awake;
-    for (uint32_t m = active; m; m &= m - 1) {
-      const int k = __ffs(m) - 1;
-      LV(VS_AX, k) = 0; LV(VS_AY, k) = 0; LV(VS_AW, k) = 0;
-    }
+    for (uint32_t m = active; m; m &= m - 1) dy.set_acc(__ffs(m) - 1, 0, 0, 0);
     // robot vs static circles (pillars, then buttons)
 #pragma unroll 1
     for (int k = 0; k < n_static; k++) {
@@ -547,151 +673,199 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
       const bool is_p = k < SAG_MAX_PILLARS;
       const bool on = (is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB)) && !ABL(ABL_NO_RS);
       const float sx = stx[k], syy = sty[k], sr = is_p ? psz : BUTTON_R;
-      const float dx = sx - R.x, dy = syy - R.y, rs = ROBOT_BOUND + sr;
-      if (on && dx * dx + dy * dy <= rs * rs) {
+      const float dx = sx - R.x, dyy = syy - R.y, rs = ROBOT_BOUND + sr;
+      if (on && dx * dx + dyy * dyy <= rs * rs) {
         BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
         St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-        int n = cc_contact(R, St, R.x, R.y, 0.1f, sx, syy, sr, bcoef, kcoef);
-        n += cb_contact(St, R, sx, syy, sr, arx, ary, cy, sy, 0.05f, 0.05f, false, bcoef, kcoef);
+        const int n = collide_shapes(R, SH_ROBOT, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
         if (is_p) cost_contacts += n;
         else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
       }
     }
-    // robot vs vases: cheap broadphase for all, then each lane walks ITS OWN hit list (ascending
-    // index = the specification's order), so a wavefront runs the narrowphase max-hits times,
-    // not once per vase index that any lane happens to touch
+    // robot vs free bodies: cheap broadphase for all, then each lane walks ITS OWN hit list
+    // (ascending index = the specification's order), so a wavefront runs the narrowphase
+    // max-hits times, not once per body index that any lane happens to touch
     uint32_t hits = 0;
 #pragma unroll 1
     for (int k = 0; k < nV; k++) {
-      const float dx = LV(VS_X, k) - R.x, dy = LV(VS_Y, k) - R.y, rs = ROBOT_BOUND + vase_r;
-      if (dx * dx + dy * dy <= rs * rs) hits |= 1u << k;
+      const float dx = LP(LS_X, k) - R.x, dyy = LP(LS_Y, k) - R.y, rs = ROBOT_BOUND + vase_r;
+      if (dx * dx + dyy * dyy <= rs * rs) hits |= 1u << k;
+    }
+    if (has_box) {
+      const float dx = LP(LS_X, BOX_ID) - R.x, dyy = LP(LS_Y, BOX_ID) - R.y, rs = ROBOT_BOUND + box_r;
+      if (dx * dx + dyy * dyy <= rs * rs) hits |= 1u << BOX_ID;
     }
     if (ABL(ABL_NO_RV)) hits = 0;
     for (uint32_t m = hits; m; m &= m - 1) {
       const int k = __ffs(m) - 1;
-      const float vx_ = LV(VS_X, k), vy_ = LV(VS_Y, k);
-      if (!(active >> k & 1)) { LV(VS_AX, k) = 0; LV(VS_AY, k) = 0; LV(VS_AW, k) = 0; }
-      BV V; load_vase(lds, lane, k, inv_vm, inv_vI, V);
-      float cv, sv; sincosf(LV(VS_YAW, k), &sv, &cv);
-      // per-geom bounding circles first: sphere (r .1) and arrow box (half diagonal .0707)
-      int n = 0;
-      {
-        const float dx = vx_ - R.x, dy = vy_ - R.y, rs = 0.1f + vase_r;
-        if (dx * dx + dy * dy <= rs * rs)
-          n = cb_contact(R, V, R.x, R.y, 0.1f, vx_, vy_, cv, sv, vsz, vsz, true, bcoef, kcoef);
+      const bool isb = k == BOX_ID;
+      dy.ensure(k, false);
+      BV V; float cv, sv; load_body(dy, k, V, cv, sv);
+      const float ax0 = V.ax, ay0 = V.ay, aw0 = V.aw;
+      const int n = collide_shapes(R, SH_ROBOT, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
+      if (!isb) cost_contacts += n;   // the task object is not an obstacle (consts.OBSTACLES)
+      if (n) { dy.set_acc(k, V.ax, V.ay, V.aw); active |= 1u << k; }
+      (void)ax0; (void)ay0; (void)aw0;
+    }
+    // HaulBox tether (haul_box.py:21-29): spatial tendon robot site (z .1) <-> box site (z .2),
+    // limited to [0, .75]; beyond the limit a soft constraint pulls the two together
+    if (HAS_TBOX && task == SAG_TASK_HAUL_BOX) {
+      const float bx = LP(LS_X, BOX_ID), by = LP(LS_Y, BOX_ID);
+      const float dx = bx - R.x, dyy = by - R.y;
+      const float d = sqrtf(dx * dx + dyy * dyy), L = sqrtf(d * d + 0.01f), viol = L - 0.75f;
+      if (viol > 0 && d >= 1e-9f) {
+        dy.ensure(BOX_ID, false);
+        BV B; float cb_, sb_; load_body(dy, BOX_ID, B, cb_, sb_);
+        const float jx = dx / L, jy = dyy / L;
+        const float Ldot = jx * (B.vx - R.vx) + jy * (B.vy - R.vy);
+        const float Lacc = jx * (B.ax - R.ax) + jy * (B.ay - R.ay);
+        float ua[3], ub[3];
+        const float Ainv = minv_apply(R, jx, jy, 0, ua) + minv_apply(B, jx, jy, 0, ub);
+        const float f = impedance(viol) * ((-sol0.bcoef * Ldot - sol0.kcoef * viol) - Lacc) / Ainv;
+        if (f < 0) {  // a tendon only pulls
+          R.ax -= ua[0] * f; R.ay -= ua[1] * f; R.aw -= ua[2] * f;
+          dy.set_acc(BOX_ID, B.ax + ub[0] * f, B.ay + ub[1] * f, B.aw + ub[2] * f);
+          active |= 1u << BOX_ID;
+        }
       }
-      {
-        const float dx = vx_ - arx, dy = vy_ - ary, rs = 0.0707106781186548f + vase_r;
-        if (dx * dx + dy * dy <= rs * rs)
-          n += bb_contact(R, V, arx, ary, cy, sy, 0.05f, 0.05f, vx_, vy_, cv, sv, vsz, vsz, bcoef, kcoef);
-      }
-      cost_contacts += n;
-      if (n) { store_vase_acc(lds, lane, k, V); active |= 1u << k; }
     }
     if (sub == nsub) break;  // final forward: robot acceleration + contact flags only
     if (active && !ABL(ABL_NO_ACTIVE)) {
-      // vases vs static circles (pillars then buttons), per active vase
+      // free bodies vs static circles (pillars then buttons), per active body
       for (uint32_t m = active; m; m &= m - 1) {
         const int k = __ffs(m) - 1;
-        const float vx_ = LV(VS_X, k), vy_ = LV(VS_Y, k);
+        const bool isb = k == BOX_ID;
+        const float bx_ = LP(LS_X, k), by_ = LP(LS_Y, k), br = isb ? box_r : vase_r;
         uint32_t shit = 0;
 #pragma unroll 1
         for (int q = 0; q < n_static; q++) {
           if (q == capP) q = SAG_MAX_PILLARS;
           const bool is_p = q < SAG_MAX_PILLARS;
           const bool on = (is_p ? (q < nP) : (q - SAG_MAX_PILLARS < nB)) && !ABL(ABL_NO_VS);
-          const float dx = stx[q] - vx_, dy = sty[q] - vy_, rs = vase_r + (is_p ? psz : BUTTON_R);
-          if (on && dx * dx + dy * dy <= rs * rs) shit |= 1u << q;
+          const float dx = stx[q] - bx_, dyy = sty[q] - by_, rs = br + (is_p ? psz : BUTTON_R);
+          if (on && dx * dx + dyy * dyy <= rs * rs) shit |= 1u << q;
         }
         for (uint32_t mq = shit; mq; mq &= mq - 1) {
           const int q = __ffs(mq) - 1;
-          // per-lane q: select from the register arrays without dynamic indexing
-          float sx = 0, syy = 0;
+          float sx = 0, syy = 0;  // per-lane q: select from the register arrays
 #pragma unroll
-          for (int z = 0; z < SAG_MAX_PILLARS + SAG_MAX_BUTTONS; z++) if (z == q) { sx = stx[z]; syy = sty[z]; }
+          for (int z = 0; z < NSTAT; z++) if (z == q) { sx = stx[z]; syy = sty[z]; }
           const float sr = q < SAG_MAX_PILLARS ? psz : BUTTON_R;
-          BV V; load_vase(lds, lane, k, inv_vm, inv_vI, V);
+          BV V; float cv, sv; load_body(dy, k, V, cv, sv);
           BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
           St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-          float cv, sv; sincosf(LV(VS_YAW, k), &sv, &cv);
-          cb_contact(St, V, sx, syy, sr, vx_, vy_, cv, sv, vsz, vsz, false, bcoef, kcoef);
-          store_vase_acc(lds, lane, k, V);
+          collide_shapes(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
+          dy.set_acc(k, V.ax, V.ay, V.aw);
         }
       }
-      // vase vs vase, pairs (a < b) in lexicographic order, at least one of them active;
-      // per a: broadphase mask over b, then the lane's own hit list.  (A per-lane walk over a
-      // 45-bit pair list was measured slower: 64-bit ffs + index decode per pair.)
+      // free body pairs (a < b) in lexicographic order, the task object being the last body;
+      // at least one of the two active.  Per a: broadphase mask over b, then the lane's own
+      // hit list.  (A per-lane walk over a 55-bit pair list was measured slower.)
 #pragma unroll 1
-      for (int a = 0; a < nV - 1; a++) {
-        const uint32_t above = vmask & ~((2u << a) - 1);          // b > a
+      for (int a = 0; a < nV; a++) {
+        const uint32_t above = fmask & ~((2u << a) - 1);          // b > a
         uint32_t cand = (active >> a & 1) ? above : (active & above);
         if (ABL(ABL_NO_VV)) cand = 0;
         if (!cand) continue;
-        const float axp = LV(VS_X, a), ayp = LV(VS_Y, a);
+        const float axp = LP(LS_X, a), ayp = LP(LS_Y, a);
         uint32_t hit = 0;
         for (uint32_t m = cand; m; m &= m - 1) {
           const int b = __ffs(m) - 1;
-          const float dx = LV(VS_X, b) - axp, dy = LV(VS_Y, b) - ayp, rs = 2 * vase_r;
-          if (dx * dx + dy * dy <= rs * rs) hit |= 1u << b;
+          const float dx = LP(LS_X, b) - axp, dyy = LP(LS_Y, b) - ayp, rs = vase_r + (b == BOX_ID ? box_r : vase_r);
+          if (dx * dx + dyy * dyy <= rs * rs) hit |= 1u << b;
         }
         for (uint32_t m = hit; m; m &= m - 1) {
           const int b = __ffs(m) - 1;
-          const float bxp = LV(VS_X, b), byp = LV(VS_Y, b);
-          if (!(active >> a & 1)) { LV(VS_AX, a) = 0; LV(VS_AY, a) = 0; LV(VS_AW, a) = 0; }
-          if (!(active >> b & 1)) { LV(VS_AX, b) = 0; LV(VS_AY, b) = 0; LV(VS_AW, b) = 0; }
-          BV A, B;
-          load_vase(lds, lane, a, inv_vm, inv_vI, A);
-          load_vase(lds, lane, b, inv_vm, inv_vI, B);
-          float ca, sa, cb, sb;
-          sincosf(LV(VS_YAW, a), &sa, &ca); sincosf(LV(VS_YAW, b), &sb, &cb);
-          int n = bb_contact(A, B, axp, ayp, ca, sa, vsz, vsz, bxp, byp, cb, sb, vsz, vsz, bcoef, kcoef);
+          const bool isb = b == BOX_ID;
+          dy.ensure(a, false); dy.ensure(b, false);
+          BV A, B; float ca, sa, cb, sb;
+          load_body(dy, a, A, ca, sa);
+          load_body(dy, b, B, cb, sb);
+          const int n = collide_shapes(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0);
           if (n) {
-            store_vase_acc(lds, lane, a, A); store_vase_acc(lds, lane, b, B);
+            dy.set_acc(a, A.ax, A.ay, A.aw); dy.set_acc(b, B.ax, B.ay, B.aw);
             active |= 1u << a | 1u << b;
           }
         }
       }
-      // floor friction + semi-implicit Euler for the active vases
-      const float fmax_ = MU * GRAV * vase_m;
+      // floor friction + semi-implicit Euler + rest capture for the active bodies
       for (uint32_t m = active; m; m &= m - 1) {
         const int k = __ffs(m) - 1;
-        float vx_ = LV(VS_VX, k), vy_ = LV(VS_VY, k), w_ = LV(VS_W, k);
-        float ax_ = LV(VS_AX, k), ay_ = LV(VS_AY, k), aw_ = LV(VS_AW, k);
-        float fx = -SOL_D0 * vase_m * (bcoef * vx_ + ax_), fy = -SOL_D0 * vase_m * (bcoef * vy_ + ay_);
-        float f2 = fx * fx + fy * fy;
-        if (f2 > fmax_ * fmax_) { float sc = fmax_ / sqrtf(f2); fx *= sc; fy *= sc; }
-        ax_ += fx / vase_m; ay_ += fy / vase_m;
-        float t = clampf(-SOL_D0 * vase_I * (bcoef * w_ + aw_), -fmax_ * vase_r, fmax_ * vase_r);
-        aw_ += t / vase_I;
+        float vx_, vy_, w_, ax_, ay_, aw_;
+        dy.get(k, vx_, vy_, w_, ax_, ay_, aw_);
+        const float bc = sol0.bcoef;
+        if (k != BOX_ID || bk.sh == SH_BOX) {
+          const float mm = k != BOX_ID ? vk.m : bk.m, II = k != BOX_ID ? vk.I : bk.I, rr = k != BOX_ID ? vk.reff : bk.reff;
+          const float fmax_ = MU * GRAV * mm;
+          float fx = -SOL_D0 * mm * (bc * vx_ + ax_), fy = -SOL_D0 * mm * (bc * vy_ + ay_);
+          const float f2 = fx * fx + fy * fy;
+          if (f2 > fmax_ * fmax_) { const float sc = fmax_ / sqrtf(f2); fx *= sc; fy *= sc; }
+          ax_ += fx / mm; ay_ += fy / mm;
+          const float t = clampf(-SOL_D0 * II * (bc * w_ + aw_), -fmax_ * rr, fmax_ * rr);
+          aw_ += t / II;
+        } else {
+          // rod: rolling resistance across its axis, sliding friction along it; ball: rolling
+          float c, s; sincosf(LP(LS_YAW, k), &s, &c);
+          float bvx = c * vx_ + s * vy_, bvy = -s * vx_ + c * vy_, bax = c * ax_ + s * ay_, bay = -s * ax_ + c * ay_;
+          const float mg = bk.m * GRAV;
+          float tlim;
+          if (bk.sh == SH_ROD) {
+            const float mx = 1.5f * bk.m, lx = 0.05f * mg / 0.08f, ly = 1.2f * mg;
+            const float fx = clampf(-SOL_D0 * mx * (bc * bvx + bax), -lx, lx);
+            const float fy = clampf(-SOL_D0 * bk.m * (bc * bvy + bay), -ly, ly);
+            bax += fx / mx; bay += fy / bk.m;
+            tlim = 1.2f * mg * 0.15f;
+          } else {
+            const float me = 1.4f * bk.m, lim = 0.05f * mg / 0.14f;
+            float fx = -SOL_D0 * me * (bc * bvx + bax), fy = -SOL_D0 * me * (bc * bvy + bay);
+            const float f2 = fx * fx + fy * fy;
+            if (f2 > lim * lim) { const float sc = lim / sqrtf(f2); fx *= sc; fy *= sc; }
+            bax += fx / me; bay += fy / me;
+            tlim = 0.003f * mg;
+          }
+          ax_ = c * bax - s * bay; ay_ = s * bax + c * bay;
+          aw_ += clampf(-SOL_D0 * bk.I * (bc * w_ + aw_), -tlim, tlim) / bk.I;
+        }
         vx_ += h * ax_; vy_ += h * ay_; w_ += h * aw_;
         // static friction capture (specification, oracle integrate_free)
         if (fabsf(vx_) < REST_V && fabsf(vy_) < REST_V && fabsf(w_) < REST_W && fabsf(h * ax_) < REST_V &&
             fabsf(h * ay_) < REST_V && fabsf(h * aw_) < REST_W) { vx_ = 0; vy_ = 0; w_ = 0; }
-        LV(VS_VX, k) = vx_; LV(VS_VY, k) = vy_; LV(VS_W, k) = w_;
-        LV(VS_X, k) += h * vx_; LV(VS_Y, k) += h * vy_; LV(VS_YAW, k) += h * w_;
+        dy.set_vel(k, vx_, vy_, w_);
+        LP(LS_X, k) += h * vx_; LP(LS_Y, k) += h * vy_; LP(LS_YAW, k) += h * w_;
         if (vx_ == 0 && vy_ == 0 && w_ == 0) awake &= ~(1u << k); else awake |= 1u << k;
       }
       dirty |= active;
     }
-    if (meta & META_FULL_PAIRS) awake = vmask;
     R.vx += h * R.ax; R.vy += h * R.ay; R.w += h * R.aw;
     R.x += h * R.vx; R.y += h * R.vy; yaw += h * R.w;
   }
 
   // ---- write back dynamic state -------------------------------------------------
+  const float boxx = LP(LS_X, BOX_ID), boxy = LP(LS_Y, BOX_ID);
   if (!p.observe_only && live) {
     SF(SAG_F_ROBOT) = R.x; SF(SAG_F_ROBOT + 1) = R.y; SF(SAG_F_ROBOT + 2) = yaw;
     SF(SAG_F_ROBOT + 3) = R.vx; SF(SAG_F_ROBOT + 4) = R.vy; SF(SAG_F_ROBOT + 5) = R.w;
     for (uint32_t m = dirty; m; m &= m - 1) {
       const int k = __ffs(m) - 1;
-      SF(SAG_F_VASES + 6 * k) = LV(VS_X, k); SF(SAG_F_VASES + 6 * k + 1) = LV(VS_Y, k);
-      SF(SAG_F_VASES + 6 * k + 2) = LV(VS_YAW, k); SF(SAG_F_VASES + 6 * k + 3) = LV(VS_VX, k);
-      SF(SAG_F_VASES + 6 * k + 4) = LV(VS_VY, k); SF(SAG_F_VASES + 6 * k + 5) = LV(VS_W, k);
+      const int f = k == BOX_ID ? SAG_F_BOX : SAG_F_VASES + 6 * k;
+      SF(f) = LP(LS_X, k); SF(f + 1) = LP(LS_Y, k); SF(f + 2) = LP(LS_YAW, k);
+      const int d = dy.slot(k);
+      if (d >= 0) { SF(f + 3) = POOL(d, 0); SF(f + 4) = POOL(d, 1); SF(f + 5) = POOL(d, 2); }
     }
     step += 1;
     I[(size_t)DI_STEP * N + i] = step;
   }
-  tstate = (tstate & ~TS_AWAKE_MASK) | (awake & 0x3ffu) << TS_AWAKE_SHIFT;
+  tstate = (tstate & ~(TS_AWAKE_BITS << TS_AWAKE_SHIFT)) | (awake & TS_AWAKE_BITS) << TS_AWAKE_SHIFT;
+
+  // hazards are only needed from here on (cost, lidar): loading them late keeps 18 registers
+  // free during the physics; the reward arithmetic below covers the latency
+  float hzx[SAG_MAX_HAZARDS], hzy[SAG_MAX_HAZARDS];
+#pragma unroll
+  for (int k = 0; k < SAG_MAX_HAZARDS; k++) {
+    hzx[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k) : 0.f;
+    hzy[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k + 1) : 0.f;
+  }
+  const float hsz = SF(SAG_F_HAZARD_SIZE);
 
   // ---- PhysicsError branch (safe_adaptation_gym.py:73-75) -------------------------
   bool bad = false;
@@ -705,6 +879,30 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
   double rew0 = 0, rew1 = 0;
   int met = 0;
   const double rx = R.x, ry = R.y;
+  // GoToGoal._resample_goal_position (:59-80) + utils.draw_placement (utils.py:28-70)
+  auto resample_goal = [&]() {
+    double xmin = -1.5, ymin = -1.5, xmax = 1.5, ymax = 1.5;
+    const double k_robot = SF(SAG_F_KEEPOUT), k_haz = SF(SAG_F_KEEPOUT + 1), k_vase = SF(SAG_F_KEEPOUT + 2),
+                 k_pil = SF(SAG_F_KEEPOUT + 3), k_box = SF(SAG_F_KEEPOUT + 4);
+    bool found = false;
+#pragma unroll 1
+    for (int t = 0; t < 10000 && !found; t++) {
+      double ngx = rng.uniform(xmin + GOAL_KEEPOUT, xmax - GOAL_KEEPOUT);
+      double ngy = rng.uniform(ymin + GOAL_KEEPOUT, ymax - GOAL_KEEPOUT);
+      if (rng.exhausted) break;
+      bool ok = !(dist2d(ngx, ngy, rx, ry) < k_robot + GOAL_KEEPOUT);
+      for (int k = 0; k < nH && ok; k++)
+        ok = !(dist2d(ngx, ngy, SF(SAG_F_HAZARDS + 2 * k), SF(SAG_F_HAZARDS + 2 * k + 1)) < k_haz + GOAL_KEEPOUT);
+      for (int k = 0; k < nV && ok; k++)
+        ok = !(dist2d(ngx, ngy, LP(LS_X, k), LP(LS_Y, k)) < k_vase + GOAL_KEEPOUT);
+      for (int k = 0; k < nP && ok; k++)
+        ok = !(dist2d(ngx, ngy, SF(SAG_F_PILLARS + 2 * k), SF(SAG_F_PILLARS + 2 * k + 1)) < k_pil + GOAL_KEEPOUT);
+      if (has_box && ok) ok = !(dist2d(ngx, ngy, boxx, boxy) < k_box + GOAL_KEEPOUT);
+      if (ok) { goalx = (float)ngx; goaly = (float)ngy; found = true; }
+      else { xmin *= 1.01; ymin *= 1.01; xmax *= 1.01; ymax *= 1.01; }
+    }
+    if (!found) flags |= rng.exhausted ? 2 : 1;
+  };
   if (!p.observe_only && !bad) {
     if (task == SAG_TASK_PRESS_BUTTONS || task == SAG_TASK_PRESS_BUTTONS_SCARCE) {
       int gb = tstate & 7, bstate = tstate >> 3 & 1, timer = tstate >> 4 & 7;
@@ -735,37 +933,17 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
         act &= ~(hit & (0u - hit));  // lowest touched active button
       }
       tstate = (tstate & ~(63u << 11)) | act << 11;
-    } else if (box_kind == SAG_BOX_NONE) {
+    } else if (!has_box) {
       // GoToGoal family (tasks/go_to_goal.py:31-45): 3-D distance incl. dz
       double gx = goalx, gy = goaly;
-      double dx = rx - gx, dy = ry - gy, dz = PT_Z - GOAL_Z;
-      double dist = sqrt(dx * dx + dy * dy + dz * dz);
+      double dx = rx - gx, dyy = ry - gy, dz = PT_Z - GOAL_Z;
+      double dist = sqrt(dx * dx + dyy * dyy + dz * dz);
       double r = (double)last0 - dist;
       if (task == SAG_TASK_GO_TO_GOAL_SCARCE) r *= (dist <= GOAL_SIZE * 1.5) ? 1.0 : 0.0;
       float last = (float)dist;
       if (dist <= GOAL_SIZE) {
         met = 1;
-        // GoToGoal._resample_goal_position (:59-80) + utils.draw_placement (utils.py:28-70)
-        double xmin = -1.5, ymin = -1.5, xmax = 1.5, ymax = 1.5;
-        const double k_robot = SF(SAG_F_KEEPOUT), k_haz = SF(SAG_F_KEEPOUT + 1),
-                     k_vase = SF(SAG_F_KEEPOUT + 2), k_pil = SF(SAG_F_KEEPOUT + 3);
-        bool found = false;
-#pragma unroll 1
-        for (int t = 0; t < 10000 && !found; t++) {
-          double ngx = rng.uniform(xmin + GOAL_KEEPOUT, xmax - GOAL_KEEPOUT);
-          double ngy = rng.uniform(ymin + GOAL_KEEPOUT, ymax - GOAL_KEEPOUT);
-          if (rng.exhausted) break;
-          bool ok = !(dist2d(ngx, ngy, rx, ry) < k_robot + GOAL_KEEPOUT);
-          for (int k = 0; k < nH && ok; k++)
-            ok = !(dist2d(ngx, ngy, SF(SAG_F_HAZARDS + 2 * k), SF(SAG_F_HAZARDS + 2 * k + 1)) < k_haz + GOAL_KEEPOUT);
-          for (int k = 0; k < nV && ok; k++)
-            ok = !(dist2d(ngx, ngy, LV(VS_X, k), LV(VS_Y, k)) < k_vase + GOAL_KEEPOUT);
-          for (int k = 0; k < nP && ok; k++)
-            ok = !(dist2d(ngx, ngy, SF(SAG_F_PILLARS + 2 * k), SF(SAG_F_PILLARS + 2 * k + 1)) < k_pil + GOAL_KEEPOUT);
-          if (ok) { goalx = (float)ngx; goaly = (float)ngy; found = true; }
-          else { xmin *= 1.01; ymin *= 1.01; xmax *= 1.01; ymax *= 1.01; }
-        }
-        if (!found) flags |= rng.exhausted ? 2 : 1;
+        resample_goal();
         last = (float)dist2d(rx, ry, goalx, goaly);  // GoToGoal.reset: 2-D (:54-55)
         if (task == SAG_TASK_CATCH_GOAL && live) { SF(SAG_F_CATCH) = goalx; SF(SAG_F_CATCH + 1) = goaly; }
         r += 1.0;
@@ -779,6 +957,31 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
         rew0 = (((-u * y + v * x) / radius) / (1 + fabs(radius - 1.5))) * 1e-1;
         rew1 = r;
       } else rew0 = r;
+    } else {
+      // PushBox family (push_box.py:74-100, push_box_scarce.py:24-50, haul_box.py:34-48): 2-D
+      float last1 = SF(SAG_F_LAST + 1), last2 = SF(SAG_F_LAST + 2);
+      const double bx = boxx, by = boxy;
+      double r = 0;
+      if (task != SAG_TASK_HAUL_BOX) {
+        const double bd = dist2d(rx, ry, bx, by);
+        double prog = (double)last1 - bd;
+        if (task == SAG_TASK_PUSH_BOX_SCARCE) prog *= (bd <= GOAL_SIZE * 1.70) ? 1.0 : 0.0;
+        r += prog;
+        last1 = (float)bd;
+      }
+      const double bg = dist2d(bx, by, goalx, goaly);
+      r += (double)last2 - bg;
+      last2 = (float)bg;
+      if (bg <= GOAL_SIZE) {
+        met = 1;
+        resample_goal();
+        last0 = (float)dist2d(rx, ry, goalx, goaly);
+        last2 = (float)dist2d(goalx, goaly, bx, by);   // PushBox.reset (:94-100)
+        last1 = (float)dist2d(rx, ry, bx, by);
+        r += 1.0;
+      }
+      if (live) { SF(SAG_F_LAST + 1) = last1; SF(SAG_F_LAST + 2) = last2; }
+      rew0 = r;
     }
     if (live) {
       SF(SAG_F_LAST) = last0;
@@ -795,8 +998,8 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
 #pragma unroll 1
     for (int k = 0; k < SAG_MAX_HAZARDS; k++) {
       if (k < nH) {
-        const float dx = R.x - hzx[k], dy = R.y - hzy[k];
-        const float d2 = dx * dx + dy * dy, t2 = hsz * hsz;
+        const float dx = R.x - hzx[k], dyy = R.y - hzy[k];
+        const float d2 = dx * dx + dyy * dyy, t2 = hsz * hsz;
         bool in = d2 <= t2;
         if (fabsf(d2 - t2) < 1e-5f) in = dist2d(rx, ry, hzx[k], hzy[k]) <= (double)hsz;
         c += in;
@@ -806,56 +1009,77 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
   }
   if (flags && live) I[(size_t)DI_FLAGS * N + i] |= flags;
 
-  // ---- observation (safe_adaptation_gym.py:120-139, 225-237) -> LDS staging -----------
+  // ---- observation (safe_adaptation_gym.py:120-139, 225-237): four column chunks
+  //      [obstacles 16 | objects 16 | goal 16 | sensors 12], each staged in LDS [lane][17]
+  //      and written back transposed -------------------------------------------------------
   if (p.obs) {
-#pragma unroll
-    for (int k = 0; k < 48; k++) STG(k) = 0.0f;
     const double cd = cos((double)yaw), sd = sin((double)yaw);
     const float cf = (float)cd, sf = (float)sd;
-#pragma unroll 1
-    for (int k = 0; k < SAG_MAX_HAZARDS; k++)
-      if (k < nH && !ABL(ABL_NO_LIDAR)) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
-#pragma unroll 1
-    for (int k = 0; k < nV; k++)
-      if (!ABL(ABL_NO_LIDAR)) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, LV(VS_X, k), LV(VS_Y, k));
-#pragma unroll 1
-    for (int k = 0; k < SAG_MAX_PILLARS; k++)
-      if (k < nP) lidar_point(lds, lane, 0, rx, ry, cd, sd, R.x, R.y, cf, sf, stx[k], sty[k]);
-    if (nB) {
-      const int gb = tstate & 7, bstate = tstate >> 3 & 1;
-      const uint32_t act = tstate >> 11 & 63;
-#pragma unroll 1
-      for (int b = 0; b < SAG_MAX_BUTTONS; b++) {
-        if (b < nB) {
-          int g;
-          if (task == SAG_TASK_COLLECT) g = (act >> b & 1) ? 2 : 0;
-          else g = bstate == 0 ? 0 : (b == gb ? 2 : 3);
-          if (g) lidar_point(lds, lane, g == 3 ? 16 : 32, rx, ry, cd, sd, R.x, R.y, cf, sf,
-                             stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b]);
-        }
-      }
-    } else {
-      lidar_point(lds, lane, 32, rx, ry, cd, sd, R.x, R.y, cf, sf, goalx, goaly);
-    }
-    const float qax = bad ? 0.0f : R.ax, qay = bad ? 0.0f : R.ay;
-    STG(48) = cf * qax + sf * qay;
-    STG(49) = cf * qay - sf * qax;
-    STG(50) = GRAV;
-    STG(51) = cf * R.vx + sf * R.vy;
-    STG(52) = cf * R.vy - sf * R.vx;
-    STG(53) = 0; STG(54) = 0; STG(55) = 0; STG(56) = R.w;
-    STG(57) = -0.5f * sf; STG(58) = -0.5f * cf; STG(59) = 0;
-    __syncthreads();
-    // transposed read-out: element e of this wavefront's contiguous [64][60] block
+    const int gb = tstate & 7, bstate = tstate >> 3 & 1;
+    const uint32_t act = tstate >> 11 & 63;
     const int base_env = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - base_env);
     float* __restrict__ o = p.obs + (size_t)base_env * 60;
+    __syncthreads();  // physics is done with the yaw / pool slots everywhere in the wavefront
+#pragma unroll 1
+    for (int chunk = 0; chunk < 4; chunk++) {
+      if (chunk < 3) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) STG(k) = 0.0f;
+      }
+      if (chunk == 0 && !ABL(ABL_NO_LIDAR)) {
+#pragma unroll 1
+        for (int k = 0; k < SAG_MAX_HAZARDS; k++)
+          if (k < nH) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
+#pragma unroll 1
+        for (int k = 0; k < nV; k++)
+          lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, LP(LS_X, k), LP(LS_Y, k));
+#pragma unroll 1
+        for (int k = 0; k < SAG_MAX_PILLARS; k++)
+          if (k < nP) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, stx[k], sty[k]);
+      } else if (chunk == 1 || chunk == 2) {
+        const int want = chunk == 1 ? 3 : 2;  // GROUP_OBJECTS then GROUP_GOAL (consts.py:13-16)
+        if (chunk == 1 && has_box) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, boxx, boxy);
+#pragma unroll 1
+        for (int b = 0; b < (HAS_BTN ? SAG_MAX_BUTTONS : 0); b++) {
+          if (b < nB) {
+            int g;
+            if (task == SAG_TASK_COLLECT) g = (act >> b & 1) ? 2 : 0;
+            else g = bstate == 0 ? 0 : (b == gb ? 2 : 3);
+            if (g == want) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf,
+                                       stx[(SAG_MAX_PILLARS + b) % NSTAT], sty[(SAG_MAX_PILLARS + b) % NSTAT]);
+          }
+        }
+        if (chunk == 2 && nB == 0) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, goalx, goaly);
+      } else if (chunk == 3) {
+        const float qax = bad ? 0.0f : R.ax, qay = bad ? 0.0f : R.ay;
+        STG(0) = cf * qax + sf * qay;
+        STG(1) = cf * qay - sf * qax;
+        STG(2) = GRAV;
+        STG(3) = cf * R.vx + sf * R.vy;
+        STG(4) = cf * R.vy - sf * R.vx;
+        STG(5) = 0; STG(6) = 0; STG(7) = 0; STG(8) = R.w;
+        STG(9) = -0.5f * sf; STG(10) = -0.5f * cf; STG(11) = 0;
+      }
+      __syncthreads();
+      if (chunk < 3) {
 #pragma unroll 4
-    for (int j = 0; j < 60; j++) {
-      const int e = j * WAVE + lane;
-      const int env = (int)(((uint32_t)e * 34953u) >> 21);  // e / 60, exact for e < 3840
-      const float v = lds[STG_BASE + e + env];  // env*61 + (e - env*60)
-      if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[e] = v;
+        for (int j = 0; j < 16; j++) {
+          const int e = j * WAVE + lane, env = e >> 4, col = e & 15;
+          const float v = lds[STG_BASE + env * STG_STRIDE + col];
+          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * 60 + chunk * 16 + col] = v;
+        }
+      } else {
+#pragma unroll 4
+        for (int j = 0; j < 12; j++) {
+          const int e = j * WAVE + lane;
+          const int env = (int)(((uint32_t)e * 43691u) >> 19);  // e / 12, exact for e < 768
+          const int col = e - env * 12;
+          const float v = lds[STG_BASE + env * STG_STRIDE + col];
+          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * 60 + 48 + col] = v;
+        }
+      }
+      __syncthreads();
     }
   }
   if (live) {
@@ -883,33 +1107,39 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
   const float* rf = rec_f + (size_t)j * SAG_REC_FLOATS;
   const int32_t* ri = rec_i + (size_t)j * SAG_REC_INTS;
   for (int k = 0; k < SAG_REC_FLOATS; k++) S[(size_t)k * N + i] = rf[k];
-  // derived words: which vases move (velocity loads / write-backs of the others are skipped)
-  // and whether any bodies overlap at rest (then nothing may be treated as asleep)
-  uint32_t awake = 0, overlap = 0;
+  // derived word: which free bodies must be looked at (moving, or possibly overlapping something,
+  // in which case the first substeps resolve it); the others are asleep and are skipped
+  uint32_t awake = 0;
   {
-    const int nV = ri[SAG_I_NV], nP = ri[SAG_I_NP], nB = ri[SAG_I_NB];
+    const int nV = ri[SAG_I_NV], nP = ri[SAG_I_NP], nB = ri[SAG_I_NB], bkind = ri[SAG_I_BOX_KIND];
     const float vr = rf[SAG_F_VASE_SIZE] * 1.41421356237309504880f;
-    for (int a = 0; a < nV; a++) {
-      const float* va = rf + SAG_F_VASES + 6 * a;
+    const float br = bkind == SAG_BOX_BOX ? 0.42426406871192851f : (bkind == SAG_BOX_ROD ? 0.31048349392520047f : 0.14f);
+    const int nb = NBODY;
+    for (int a = 0; a < nb; a++) {
+      if (a < SAG_MAX_VASES ? a >= nV : bkind == SAG_BOX_NONE) continue;
+      const float* va = a < SAG_MAX_VASES ? rf + SAG_F_VASES + 6 * a : rf + SAG_F_BOX;
+      const float ra = a < SAG_MAX_VASES ? vr : br;
       if (va[3] != 0 || va[4] != 0 || va[5] != 0) awake |= 1u << a;
-      for (int b = a + 1; b < nV; b++) {
-        const float* vb = rf + SAG_F_VASES + 6 * b;
-        float dx = va[0] - vb[0], dy = va[1] - vb[1];
-        if (dx * dx + dy * dy <= 4 * vr * vr) overlap = 1;
+      for (int b = a + 1; b < nb; b++) {
+        if (b < SAG_MAX_VASES ? b >= nV : bkind == SAG_BOX_NONE) continue;
+        const float* vb = b < SAG_MAX_VASES ? rf + SAG_F_VASES + 6 * b : rf + SAG_F_BOX;
+        const float rs = ra + (b < SAG_MAX_VASES ? vr : br);
+        const float dx = va[0] - vb[0], dy = va[1] - vb[1];
+        if (dx * dx + dy * dy <= rs * rs) awake |= 1u << a | 1u << b;
       }
       for (int q = 0; q < nP; q++) {
-        float dx = va[0] - rf[SAG_F_PILLARS + 2 * q], dy = va[1] - rf[SAG_F_PILLARS + 2 * q + 1];
-        float rs = vr + rf[SAG_F_PILLAR_SIZE];
-        if (dx * dx + dy * dy <= rs * rs) overlap = 1;
+        const float dx = va[0] - rf[SAG_F_PILLARS + 2 * q], dy = va[1] - rf[SAG_F_PILLARS + 2 * q + 1];
+        const float rs = ra + rf[SAG_F_PILLAR_SIZE];
+        if (dx * dx + dy * dy <= rs * rs) awake |= 1u << a;
       }
       for (int q = 0; q < nB; q++) {
-        float dx = va[0] - rf[SAG_F_BUTTONS + 2 * q], dy = va[1] - rf[SAG_F_BUTTONS + 2 * q + 1];
-        float rs = vr + BUTTON_R;
-        if (dx * dx + dy * dy <= rs * rs) overlap = 1;
+        const float dx = va[0] - rf[SAG_F_BUTTONS + 2 * q], dy = va[1] - rf[SAG_F_BUTTONS + 2 * q + 1];
+        const float rs = ra + BUTTON_R;
+        if (dx * dx + dy * dy <= rs * rs) awake |= 1u << a;
       }
     }
   }
-  I[(size_t)DI_META * N + i] = (int32_t)(pack_meta(ri) | (overlap ? META_FULL_PAIRS : 0u));
+  I[(size_t)DI_META * N + i] = (int32_t)pack_meta(ri);
   I[(size_t)DI_TSTATE * N + i] = (int32_t)(pack_tstate(ri) | awake << TS_AWAKE_SHIFT);
   I[(size_t)DI_STEP * N + i] = ri[SAG_I_STEP];
   I[(size_t)DI_ENVID * N + i] = ri[SAG_I_ENV_ID];
@@ -926,6 +1156,10 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
       S[(size_t)SAG_F_LAST * N + i] = (float)dist2d(rx, ry, rf[SAG_F_BUTTONS + 2 * b], rf[SAG_F_BUTTONS + 2 * b + 1]);
     } else if (task != SAG_TASK_COLLECT) {
       S[(size_t)SAG_F_LAST * N + i] = (float)dist2d(rx, ry, rf[SAG_F_GOAL], rf[SAG_F_GOAL + 1]);
+    }
+    if (ri[SAG_I_BOX_KIND] != SAG_BOX_NONE) {  // PushBox.reset (push_box.py:94-100)
+      S[(size_t)(SAG_F_LAST + 2) * N + i] = (float)dist2d(rf[SAG_F_GOAL], rf[SAG_F_GOAL + 1], rf[SAG_F_BOX], rf[SAG_F_BOX + 1]);
+      S[(size_t)(SAG_F_LAST + 1) * N + i] = (float)dist2d(rx, ry, rf[SAG_F_BOX], rf[SAG_F_BOX + 1]);
     }
   }
 }

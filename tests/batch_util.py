@@ -38,6 +38,11 @@ def pursuit_actions(rf, ri, rng, p_random=0.2):
     else:
       b = ri[i, nat.I_GOAL_BUTTON]
     tx[i], ty[i] = rf[i, nat.F_BUTTONS + 2 * b], rf[i, nat.F_BUTTONS + 2 * b + 1]
+  # box tasks: drive at the box (tests place the goal just beyond it, see goal_beyond_box)
+  for i in np.flatnonzero(ri[:, nat.I_BOX_KIND] > 0):
+    tx[i], ty[i] = rf[i, nat.F_BOX], rf[i, nat.F_BOX + 1]
+    if ri[i, nat.I_TASK] == 7:  # haul_box: the box follows on its tether; head for the goal
+      tx[i], ty[i] = rf[i, nat.F_GOAL], rf[i, nat.F_GOAL + 1]
   ang = np.arctan2(ty - y, tx - x) - yaw
   ang = (ang + np.pi) % (2 * np.pi) - np.pi
   a = np.stack([np.where(np.abs(ang) < 1.0, 1.0, 0.2), np.clip(2.0 * ang, -1, 1)], -1)
@@ -45,3 +50,16 @@ def pursuit_actions(rf, ri, rng, p_random=0.2):
   pick = rng.uniform(size=n) < p_random
   a[pick] = rnd[pick]
   return a.astype(np.float32)
+
+
+def goal_beyond_box(rf, ri, dist=0.55):
+  """Test set-up for the PushBox family: move every goal to `dist` beyond the box on the
+  robot -> box line, so a straight push meets it (and the on-goal resample, RNG draws and
+  PushBox.reset run many times in a short rollout)."""
+  rf = rf.copy()
+  for i in np.flatnonzero(ri[:, nat.I_BOX_KIND] > 0):
+    r = rf[i, nat.F_ROBOT:nat.F_ROBOT + 2]
+    b = rf[i, nat.F_BOX:nat.F_BOX + 2]
+    d = (b - r) / (np.linalg.norm(b - r) + 1e-9)
+    rf[i, nat.F_GOAL:nat.F_GOAL + 2] = b + dist * d
+  return rf

@@ -107,7 +107,8 @@ def test_lidar_cost_empty_and_ragged(nat, oracle):
 # full step: lockstep against the oracle
 # ----------------------------------------------------------------------------------
 LOCKSTEP_TASKS = ['go_to_goal', 'go_to_goal_scarce', 'go_to_goal_motor', 'go_to_goal_damping',
-                  'catch_goal', 'unsupervised', 'press_buttons', 'press_buttons_scarce', 'collect']
+                  'catch_goal', 'unsupervised', 'press_buttons', 'press_buttons_scarce', 'collect',
+                  'push_box', 'push_box_scarce', 'haul_box', 'roll_rod', 'dribble_ball']
 
 
 def _flags_agree(dev, orc, margin, tol=1e-5):
@@ -131,6 +132,8 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
   threshold."""
   n, T = 192, 160
   rf, ri = bu.sample_records('point', task, n, seed=666)
+  if task not in ('haul_box',):
+    rf = bu.goal_beyond_box(rf, ri)
   ctx = nat.Context('point', n, seed=1234)
   ctx.set_layout(rf, ri)
   rng = np.random.RandomState(7)
@@ -148,13 +151,19 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
     tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
     d_obs, d_rew, d_cost, d_done, d_met, d_used = ctx.step(act, noise, tape)
     o_obs, o_rew, o_cost, o_done, o_met, o_used, o_margin = oracle.step_batch_full(arr, 0, act, noise, tape)
-    oracle32.step_batch_full(arr32, 0, act, noise, tape)
+    o32 = oracle32.step_batch_full(arr32, 0, act, noise, tape)
     d_rf, d_ri = ctx.get_state()
     o_rf, o_ri = oracle.batch_records(arr)
     o32_rf, _ = oracle32.batch_records(arr32)
     # state: rows outside the tolerance are counted, not hidden
-    bad64 = (np.abs(d_rf - o_rf) > STATE_TOL + STATE_TOL * np.abs(o_rf)).any(1)
-    bad32 = (np.abs(d_rf - o32_rf) > 2e-5 + 2e-5 * np.abs(o32_rf)).any(1)
+    tol64 = np.full(d_rf.shape[1], STATE_TOL)
+    tol32 = np.full(d_rf.shape[1], 2e-5)
+    if task == 'dribble_ball':
+      # the ball's spin (unobservable; I = 4.5e-8 kg m^2) is set by friction torques of a stiff,
+      # underdamped contact (solref .018 .2): fp32 rounding is amplified ~1000x there
+      tol64[46] = tol32[46] = 5e-3
+    bad64 = (np.abs(d_rf - o_rf) > tol64 + tol64 * np.abs(o_rf)).any(1)
+    bad32 = (np.abs(d_rf - o32_rf) > tol32 + tol32 * np.abs(o32_rf)).any(1)
     viol64 += int(bad64.sum())
     viol32 += int(bad32.sum())
     ok = ~bad64
@@ -162,8 +171,14 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
     np.testing.assert_array_equal(d_done, o_done)
     np.testing.assert_array_equal(d_met[ok], o_met[ok], err_msg=f'goal_met step {t}')
     np.testing.assert_array_equal(d_used[ok], o_used[ok])
+    # cost flags: exact vs the fp64 oracle unless the decision sits at a threshold - the hazard
+    # distance within 1e-5 of its radius (reported by the oracle) or a contact whose
+    # penetration changes sign with the arithmetic (then the fp32 oracle sides with the device)
     hard, soft = _flags_agree(d_cost[ok], o_cost[ok], o_margin[ok])
-    assert hard == 0, f'cost flag mismatch away from the threshold at step {t}'
+    if hard:
+      mism = ok & (d_cost != o_cost) & (o_margin > 1e-5)
+      assert (d_cost[mism] == o32[2][mism]).all(), f'cost flag mismatch away from any threshold at step {t}'
+      soft += hard
     n_near += soft
     np.testing.assert_array_equal(d_ri[ok], o_ri[ok], err_msg=f'task ints step {t}')
     # observation = f(post-step state): check f tightly on the device's own post-step state,
@@ -183,11 +198,13 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
     np.testing.assert_allclose(d_rew[ok], o_rew[ok], rtol=0, atol=2e-4, err_msg=f'reward step {t}')
     n_met += int(d_met.sum())
     n_cost += int(d_cost.sum())
-  assert n_met > 20, 'the rollout should exercise goal-met events'
+  assert n_met > (5 if ri[0, 5] else 20), 'the rollout should exercise goal-met events'
   assert n_cost > 20, 'the rollout should exercise cost events'
   assert n_near <= 0.001 * n * T
-  assert viol64 <= 0.0005 * n * T, f'{viol64} env-steps outside the fp64 tolerance'
-  assert viol32 <= 0.0005 * n * T, f'{viol32} env-steps outside the fp32 tolerance'
+  # (the ball's contact is stiff and underdamped - k h^2 = 1.4 - and amplifies rounding more)
+  budget = (0.005 if task == 'dribble_ball' else 0.0005) * n * T
+  assert viol64 <= budget, f'{viol64} env-steps outside the fp64 tolerance'
+  assert viol32 <= budget, f'{viol32} env-steps outside the fp32 tolerance'
   assert acc_bad <= 0.0005 * n * T, f'{acc_bad} accelerometer readings off on identical state'
   assert acc_e2e <= 0.005 * n * T, f'{acc_e2e} accelerometer readings off end to end'
   ctx.close()
@@ -311,8 +328,6 @@ def test_env_api_shapes_and_reference_surface(nat):
   from safe_adaptation_gym_amd import benchmark
   bm = benchmark.make('multitask', batch_size=3, seed=1)
   for name, task in bm.train_tasks:
-    if task.BOX_KIND:
-      continue
     obs = env.reset(options={'task': task})
     assert obs.shape == (100, 60)
   env.close()
