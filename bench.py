@@ -132,6 +132,17 @@ def timed(run, steps, warmup, barrier):
   return time.perf_counter() - t0
 
 
+def traffic_per_launch(envs):
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
+  FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs of this same command), scaled to
+  this launch's env count.  None if no profile has been committed."""
+  try:
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    return t['bytes_per_env_step'] * envs
+  except (OSError, KeyError, ValueError):
+    return None
+
+
 def cpu_baseline(task, seconds=12.0):
   """The CPU oracle (oracle/sag_oracle.c, fp64, OpenMP over envs) on this host: same
   layouts, same counter-based actions/noise.  A reported baseline, not the target."""
@@ -257,7 +268,7 @@ def main(argv=None, run_factory=None, emit=print):
           'peak': HBM_PEAK_GBS,
           'unit': 'GB/s',
           'frac': achieved / HBM_PEAK_GBS,
-          'traffic': None,
+          'traffic': traffic_per_launch(args.envs),
           'kernel': 'sag::k_step_point',
           'kernel_ms': k_ms,
           'launches_timed': k_n,
