@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAG_ABI_VERSION 1
+#define SAG_ABI_VERSION 2
 
 /* ---- capacities (maxima over the reference's task set: Task.obstacles) ---- */
 #define SAG_MAX_HAZARDS 9  /* tasks/go_to_goal.py:83-84  [9,10,0,1]          */
@@ -98,7 +98,10 @@ enum sag_rec_float {
   SAG_F_PILLARS = 65,     /* (x, y) * SAG_MAX_PILLARS                                 */
   SAG_F_BUTTONS = 69,     /* (x, y) * SAG_MAX_BUTTONS                                 */
   SAG_F_VASES = 81,       /* (x, y, yaw, vx, vy, w) * SAG_MAX_VASES                   */
-  SAG_REC_FLOATS = 144    /* 141 used, padded                                          */
+  SAG_F_ROBOT_EXT = 144,  /* robot DoF beyond the planar base. car (car.xml:21-32): wheel rates left,
+                           * right (rad/s about the axle); rear ball: angular velocity x,y,z
+                           * (relative to the base, base frame); ball quaternion w,x,y,z           */
+  SAG_REC_FLOATS = 160
 };
 
 enum sag_rec_int {

@@ -290,7 +290,7 @@ typedef struct Body_ {
   real ax, ay, aw;             /* accumulated acceleration this substep */
   real minv[6];                /* symmetric inverse inertia: xx, xy, xw, yy, yw, ww (0 for static) */
   int ngeom;
-  Geom g[5];
+  Geom g[8];
   int dynamic;
   /* contact material (MuJoCo geom friction[0], priority, solref): the higher priority geom's
    * values win, equal priority takes max friction / equal solref (all defaults are equal) */
@@ -537,6 +537,8 @@ typedef struct {
   real vase_m, vase_I, vase_reff;
   real box_m, box_I;
   int nV, nP, nB, box_kind, haul;
+  int robot_id;
+  real ext[16], ext_acc[5]; /* car: wheel rates L,R; ball rate x,y,z; ball quat w,x,y,z */
 } World;
 
 static void material_default(Body* b) { b->mu = (real)FRICTION_MU; b->tc = (real)SOL_TC; b->dr = 1; b->prio = 0; }
@@ -669,8 +671,11 @@ static void point_minv(Body* b, real damp, real h) {
   b->minv[5] = (m * m) * id;           /* ww */
 }
 
-static void world_from_env(const OEnv* e, World* w) {
+static void car_body(Body* r);
+static void world_from_env_r(const OEnv* e, World* w, int robot) {
   memset(w, 0, sizeof(*w));
+  w->robot_id = robot;
+  for (int k = 0; k < 16; k++) w->ext[k] = e->f[SAG_F_ROBOT_EXT + k];
   const real* f = e->f;
   Body* r = &w->robot;
   r->x = f[SAG_F_ROBOT]; r->y = f[SAG_F_ROBOT + 1]; r->yaw = f[SAG_F_ROBOT + 2];
@@ -679,6 +684,7 @@ static void world_from_env(const OEnv* e, World* w) {
   material_default(r);
   r->g[0].type = 0; r->g[0].a = (real)0.1;                       /* point.xml:18 */
   r->g[1].type = 1; r->g[1].ox = (real)0.1; r->g[1].a = (real)0.05; r->g[1].b = (real)0.05; /* :19 */
+  if (robot == SAG_ROBOT_CAR) car_body(r);
   w->r_robot = bound_radius(r);
   w->nV = e->i[SAG_I_NV]; w->nP = e->i[SAG_I_NP]; w->nB = e->i[SAG_I_NB];
   real vs = f[SAG_F_VASE_SIZE];
@@ -712,6 +718,7 @@ static void world_from_env(const OEnv* e, World* w) {
 static void world_to_env(const World* w, OEnv* e) {
   real* f = e->f;
   const Body* r = &w->robot;
+  for (int k = 0; k < 16; k++) f[SAG_F_ROBOT_EXT + k] = w->ext[k];
   f[SAG_F_ROBOT] = r->x; f[SAG_F_ROBOT + 1] = r->y; f[SAG_F_ROBOT + 2] = r->yaw;
   f[SAG_F_ROBOT + 3] = r->vx; f[SAG_F_ROBOT + 4] = r->vy; f[SAG_F_ROBOT + 5] = r->w;
   for (int k = 0; k < w->nV; k++) {
@@ -764,6 +771,144 @@ static void point_smooth(Body* r, const real ctrl[2], real gear, real damp, real
   r->aw = m[2] * Fx + m[4] * Fy + m[5] * Tz;
 }
 
+
+/* ------------------------------------------------------------------------ */
+/* Car robot (assets/xmls/car.xml) - planar reduction        */
+/* ------------------------------------------------------------------------ */
+/* SPECIFICATION.  The MJCF car is a free-joint base on two driven wheels (hinge about the
+ * body x axis, armature 2.5e-4, motor gear 1, force range +-.02) and a rear ball caster.  Its
+ * three floor contacts hold height, pitch and roll; those three stiff DoF are frozen here and
+ * the remaining eight are integrated: base (x, y, yaw), the two wheel rates and the ball's
+ * angular velocity (plus the ball quaternion, which the observation needs).  Floor contact is
+ * reduced to regularised Coulomb friction at the three contact points under their static
+ * normal loads, with the same soft-constraint reference (b = 2 / (dmax tc)) as body contacts:
+ * wheels resist lateral slip and couple longitudinal slip to the wheel rate (radius .05); the
+ * ball couples both slip components to its spin.  Geoms keep their planar footprints. */
+#define CAR_DENS 5.0
+#define CAR_RW 0.05
+#define CAR_ARMATURE 0.00025
+#define CAR_JDAMP 0.001
+#define CAR_FLIM 0.02
+typedef struct { real m, Io, ox, oy, Iw, Ib, N[3]; } CarK;
+
+static void car_body(Body* r) {
+  /* car.xml:16-32: footprints of the eight geoms in the base frame */
+  static const real G[8][5] = {/* type, ox, oy, a, b */
+      {1, 0, 0, 0.1, 0.1},        {1, 0, 0.15, 0.1, 0.01},     {1, 0, 0.125, 0.01, 0.025},
+      {1, 0, -0.165, 0.05, 0.01}, {1, 0, -0.13, 0.05, 0.03},   {1, -0.13, 0.1, 0.025, 0.05},
+      {1, 0.13, 0.1, 0.025, 0.05}, {0, 0, -0.1, 0.05, 0}};
+  r->ngeom = 8;
+  for (int k = 0; k < 8; k++) {
+    r->g[k].type = (int)G[k][0]; r->g[k].ox = G[k][1]; r->g[k].oy = G[k][2];
+    r->g[k].a = G[k][3]; r->g[k].b = G[k][4];
+  }
+}
+
+static CarK car_constants(void) {
+  /* masses from the 3-D geoms (density 5): boxes 8 hx hy hz, wheels pi r^2 L, ball 4/3 pi r^3 */
+  static const double HZ[5] = {0.05, 0.05, 0.03, 0.05, 0.01};
+  Body b; memset(&b, 0, sizeof(b)); car_body(&b);
+  double m = 0, mx = 0, my = 0, Io = 0;
+  for (int k = 0; k < 8; k++) {
+    const Geom* g = &b.g[k];
+    double mk, Ik;
+    if (k < 5) { mk = CAR_DENS * 8 * g->a * g->b * HZ[k]; Ik = mk * (g->a * g->a + g->b * g->b) / 3; }
+    else if (k < 7) { mk = CAR_DENS * PI * 0.05 * 0.05 * 0.05; Ik = mk * (3 * 0.05 * 0.05 + 0.05 * 0.05) / 12; }
+    else { mk = CAR_DENS * 4.0 / 3.0 * PI * 0.05 * 0.05 * 0.05; Ik = 0.4 * mk * 0.05 * 0.05; }
+    m += mk; mx += mk * g->ox; my += mk * g->oy;
+    Io += Ik + mk * (g->ox * g->ox + g->oy * g->oy);
+  }
+  CarK c;
+  c.m = (real)m; c.Io = (real)Io; c.ox = (real)(mx / m); c.oy = (real)(my / m);
+  double mw = CAR_DENS * PI * 0.05 * 0.05 * 0.05, mb = CAR_DENS * 4.0 / 3.0 * PI * 0.05 * 0.05 * 0.05;
+  c.Iw = (real)(0.5 * mw * 0.05 * 0.05 + CAR_ARMATURE);
+  c.Ib = (real)(0.4 * mb * 0.05 * 0.05);
+  /* static loads on (left, right, caster) at y = .1, .1, -.1, x = -.13, .13, 0 */
+  double W = m * GRAVITY, yc = my / m;
+  double NL = W * (0.1 + yc) / 0.4;
+  c.N[0] = (real)NL; c.N[1] = (real)NL; c.N[2] = (real)(W - 2 * NL);
+  return c;
+}
+
+void sago_car_constants(double out[9]) {
+  CarK c = car_constants();
+  out[0] = c.m; out[1] = c.Io; out[2] = c.ox; out[3] = c.oy; out[4] = c.Iw; out[5] = c.Ib;
+  out[6] = c.N[0]; out[7] = c.N[1]; out[8] = c.N[2];
+}
+
+/* one regularised friction direction at a contact point of the base, optionally coupled to a
+ * spinning part (wheel / ball) through lever `rw` and inertia `Ispin` */
+static real car_friction(Body* r, real dx, real dy, real rx, real ry, real spin_rate, real* spin_acc,
+                         real rw, real Ispin, real limit, real bcoef) {
+  real u[3];
+  real A = minv_apply(r, dx, dy, rx * dy - ry * dx, u);
+  real slip = (r->vx - r->w * ry) * dx + (r->vy + r->w * rx) * dy + rw * spin_rate;
+  real sacc = (r->ax - r->aw * ry) * dx + (r->ay + r->aw * rx) * dy + rw * (spin_acc ? *spin_acc : 0);
+  if (spin_acc) A += rw * rw / Ispin;
+  real f = clampr((real)SOL_D0 * (-bcoef * slip - sacc) / A, -limit, limit);
+  r->ax += u[0] * f; r->ay += u[1] * f; r->aw += u[2] * f;
+  if (spin_acc) *spin_acc += rw * f / Ispin;
+  return f;
+}
+
+static void car_smooth(World* w, const real ctrl[2], const Sol* sol) {
+  Body* r = &w->robot;
+  const CarK k = car_constants();
+  real h = sol->h;
+  real c = R_COS(r->yaw), s = R_SIN(r->yaw);
+  /* COM offset in world axes, M = [[m,0,-m oy],[0,m,m ox],[.,.,Io]], bias = -m w^2 o */
+  real ox = c * k.ox - s * k.oy, oy = s * k.ox + c * k.oy;
+  real a = -k.m * oy, b = k.m * ox, m = k.m, I = k.Io;
+  real id = 1 / (m * (m * I - a * a - b * b));
+  r->minv[0] = (m * I - b * b) * id; r->minv[1] = (a * b) * id; r->minv[2] = (-a * m) * id;
+  r->minv[3] = (m * I - a * a) * id; r->minv[4] = (-b * m) * id; r->minv[5] = (m * m) * id;
+  real Fx = k.m * r->w * r->w * ox, Fy = k.m * r->w * r->w * oy;
+  r->ax = r->minv[0] * Fx + r->minv[1] * Fy; r->ay = r->minv[1] * Fx + r->minv[3] * Fy;
+  r->aw = r->minv[2] * Fx + r->minv[4] * Fy;
+  /* wheels: motor torque clip(ctrl, +-.02) (gear 1), joint damping implicit */
+  real Iw = k.Iw + h * (real)CAR_JDAMP, Ib = k.Ib + h * (real)CAR_JDAMP;
+  real* acc = w->ext_acc;
+  for (int i = 0; i < 2; i++)
+    acc[i] = (clampr(ctrl[i], -(real)CAR_FLIM, (real)CAR_FLIM) - (real)CAR_JDAMP * w->ext[i]) / Iw;
+  for (int i = 0; i < 3; i++) acc[2 + i] = -(real)CAR_JDAMP * w->ext[2 + i] / Ib;
+  /* floor friction: left, right (longitudinal = body y, coupled to the wheel; lateral = body x),
+   * then the caster (x coupled to -ball_y spin, y to +ball_x spin) */
+  static const real PX[3] = {-0.13, 0.13, 0}, PY[3] = {0.1, 0.1, -0.1};
+  real xbx = c, xby = s, ybx = -s, yby = c;
+  for (int i = 0; i < 3; i++) {
+    real rx = c * PX[i] - s * PY[i], ry = s * PX[i] + c * PY[i];
+    real lim = (real)FRICTION_MU * k.N[i];
+    if (i < 2) {
+      car_friction(r, ybx, yby, rx, ry, w->ext[i], &acc[i], (real)CAR_RW, Iw, lim, sol->bcoef);
+      car_friction(r, xbx, xby, rx, ry, 0, NULL, 0, 1, lim, sol->bcoef);
+    } else {
+      /* x slip = v.x - r * ball_y  -> spin variable -ball_y;  y slip = v.y + r * ball_x */
+      real sy_rate = -w->ext[3], sy_acc = -acc[3];
+      car_friction(r, xbx, xby, rx, ry, sy_rate, &sy_acc, (real)CAR_RW, Ib, lim, sol->bcoef);
+      acc[3] = -sy_acc;
+      car_friction(r, ybx, yby, rx, ry, w->ext[2], &acc[2], (real)CAR_RW, Ib, lim, sol->bcoef);
+    }
+  }
+}
+
+static void car_integrate_ext(World* w, real h) {
+  for (int i = 0; i < 5; i++) w->ext[i] += h * w->ext_acc[i];
+  /* ball quaternion: rate is relative to the base, in base (parent) axes: q <- exp(h W / 2) q */
+  real wx = w->ext[2], wy = w->ext[3], wz = w->ext[4];
+  real n = R_SQRT(wx * wx + wy * wy + wz * wz);
+  if (n > 0) {
+    real half = (real)0.5 * h * n, sn = R_SIN(half) / n, cs = R_COS(half);
+    real dw = cs, dx = sn * wx, dy = sn * wy, dz = sn * wz;
+    real* q = &w->ext[5];
+    real qw = dw * q[0] - dx * q[1] - dy * q[2] - dz * q[3];
+    real qx = dw * q[1] + dx * q[0] + dy * q[3] - dz * q[2];
+    real qy = dw * q[2] - dx * q[3] + dy * q[0] + dz * q[1];
+    real qz = dw * q[3] + dx * q[2] - dy * q[1] + dz * q[0];
+    real qn = R_SQRT(qw * qw + qx * qx + qy * qy + qz * qz);
+    q[0] = qw / qn; q[1] = qx / qn; q[2] = qy / qn; q[3] = qz / qn;
+  }
+}
+
 /* One forward-dynamics evaluation: accelerations of every body at the current
  * state.  Fixed pair order (specification):
  *   robot-pillars, robot-buttons, robot-vases, robot-box, haul tendon,
@@ -773,7 +918,8 @@ static void point_smooth(Body* r, const real ctrl[2], real gear, real damp, real
  * with prefixes consts.OBSTACLES; the box is not an obstacle) and the button contact mask. */
 static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol* sol,
                          uint32_t* btn_mask) {
-  point_smooth(&w->robot, ctrl, e->f[SAG_F_GEAR], e->f[SAG_F_DAMP], sol->h);
+  if (w->robot_id == SAG_ROBOT_CAR) car_smooth(w, ctrl, sol);
+  else point_smooth(&w->robot, ctrl, e->f[SAG_F_GEAR], e->f[SAG_F_DAMP], sol->h);
   for (int k = 0; k < w->nV; k++) { w->vase[k].ax = w->vase[k].ay = w->vase[k].aw = 0; }
   w->box.ax = w->box.ay = w->box.aw = 0;
   if (w->box_kind == SAG_BOX_ROD) { /* orientation-dependent inverse inertia */
@@ -852,18 +998,20 @@ static void integrate_free(Body* b, real h) {
 }
 
 /* nstep x mj_step (safe_adaptation_gym.py:72) */
-void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) {
+static void substeps_r(OEnv* e, const real ctrl[2], int nstep, double h, int robot) {
   World w;
-  world_from_env(e, &w);
+  world_from_env_r(e, &w, robot);
   Sol sol = make_sol(h);
   for (int s = 0; s < nstep; s++) {
     world_forward(&w, e, ctrl, &sol, NULL);
     integrate(&w.robot, sol.h);
+    if (robot == SAG_ROBOT_CAR) car_integrate_ext(&w, sol.h);
     for (int k = 0; k < w.nV; k++) integrate_free(&w.vase[k], sol.h);
     if (w.box_kind != SAG_BOX_NONE) integrate_free(&w.box, sol.h);
   }
   world_to_env(&w, e);
 }
+void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) { substeps_r(e, ctrl, nstep, h, SAG_ROBOT_POINT); }
 
 /* ------------------------------------------------------------------------ */
 /* goal resampling: tasks/go_to_goal.py:59-80 + utils.py:22-70                */
@@ -1091,7 +1239,7 @@ static int has_goal_body(int task) {
 /* ------------------------------------------------------------------------ */
 /* observation: safe_adaptation_gym.py:120-139,225-237 (Point: 48 + 12)       */
 /* ------------------------------------------------------------------------ */
-static void observe(const OEnv* e, const real qacc[3], real* obs) {
+static void observe(const OEnv* e, int robot, const real qacc[3], real* obs) {
   const real* f = e->f;
   double lid[48];
   for (int k = 0; k < 48; k++) lid[k] = 0;
@@ -1124,6 +1272,18 @@ static void observe(const OEnv* e, const real qacc[3], real* obs) {
   obs[57] = (real)(-0.5 * s);
   obs[58] = (real)(-0.5 * c);
   obs[59] = 0;
+  if (robot == SAG_ROBOT_CAR) {
+    /* car.xml:37-38 via safe_adaptation_gym.py:228-236: ballangvel_rear (joint rate in the ball's
+     * own frame), then the 3x3 of ballquat_rear, row-major (utils.py:110-116) */
+    const real* q = f + SAG_F_ROBOT_EXT + 5;
+    double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    double R[9] = {qw * qw + qx * qx - qy * qy - qz * qz, 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                   2 * (qx * qy + qw * qz), qw * qw - qx * qx + qy * qy - qz * qz, 2 * (qy * qz - qw * qx),
+                   2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), qw * qw - qx * qx - qy * qy + qz * qz};
+    double W[3] = {f[SAG_F_ROBOT_EXT + 2], f[SAG_F_ROBOT_EXT + 3], f[SAG_F_ROBOT_EXT + 4]};
+    for (int k = 0; k < 3; k++) obs[60 + k] = (real)(R[k] * W[0] + R[3 + k] * W[1] + R[6 + k] * W[2]);
+    for (int k = 0; k < 9; k++) obs[63 + k] = (real)R[k];
+  }
 }
 
 /* hazard part of World.compute_cost (world.py:147-153), fp64 on the stored poses */
@@ -1175,18 +1335,18 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   /* World.set_mocaps (:71): only CatchGoal acts; uses time BEFORE the step */
   double time = (double)e->i[SAG_I_STEP] * NSTEP[robot] * h;
   if (e->i[SAG_I_TASK] == SAG_TASK_CATCH_GOAL) catch_goal_mocap(e, &g, time);
-  sago_substeps(e, ctrl, nstep, h);
+  substeps_r(e, ctrl, nstep, h, robot);
   e->i[SAG_I_STEP] += 1;
   if (state_bad(e)) { /* PhysicsError branch (:73-75) */
     real z[3] = {0, 0, 0};
-    observe(e, z, out->obs);
+    observe(e, robot, z, out->obs);
     out->reward[0] = -10; out->done = 1; out->cost = 0;
     out->tape_used = g.pos;
     return;
   }
   /* mj_forward at the final state (:76): contacts + qacc */
   World w;
-  world_from_env(e, &w);
+  world_from_env_r(e, &w, robot);
   Sol sol = make_sol(h);
   uint32_t mask = 0;
   int cc = world_forward(&w, e, ctrl, &sol, &mask);
@@ -1198,7 +1358,7 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   int cost = cc + hazard_cost(e, &margin);      /* :78, world.py:144-155 */
   out->cost = cost > 0;
   out->cost_margin = (real)margin;
-  observe(e, out->qacc, out->obs);              /* :80 */
+  observe(e, robot, out->qacc, out->obs);       /* :80 */
   out->tape_used = g.pos;
 }
 
@@ -1206,12 +1366,12 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
 void sago_observe(OEnv* e, int robot, OOut* out) {
   memset(out, 0, sizeof(*out));
   World w;
-  world_from_env(e, &w);
+  world_from_env_r(e, &w, robot);
   Sol sol = make_sol(DT[robot]);
   real ctrl[SAG_MAX_NU] = {0};
   world_forward(&w, e, ctrl, &sol, &out->btn_contact_mask);
   out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
-  observe(e, out->qacc, out->obs);
+  observe(e, robot, out->qacc, out->obs);
 }
 
 /* task.reset as run by World.reset right after rebuild (world.py:167-170):

@@ -11,15 +11,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SAG_LIB overrides the library file (A/B builds of the same ABI during kernel tuning)
 LIB_PATH = os.environ.get('SAG_LIB') or os.path.join(_HERE, 'libsag.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_HAZARDS, MAX_VASES, MAX_PILLARS, MAX_BUTTONS, MAX_NU = 9, 10, 2, 6, 12
-REC_FLOATS, REC_INTS = 144, 16
+REC_FLOATS, REC_INTS = 160, 16
 
 # record field offsets (enum sag_rec_float / sag_rec_int)
 F_ROBOT, F_ROBOT0, F_GEAR, F_DAMP, F_ACTION_NOISE, F_CTRL_SCALE = 0, 6, 9, 10, 11, 12
 F_HAZARD_SIZE, F_VASE_SIZE, F_PILLAR_SIZE, F_KEEPOUT = 24, 25, 26, 27
 F_GOAL, F_CATCH, F_LAST, F_BOX = 32, 34, 38, 41
 F_HAZARDS, F_PILLARS, F_BUTTONS, F_VASES = 47, 65, 69, 81
+F_ROBOT_EXT = 144
 (I_TASK, I_NH, I_NV, I_NP, I_NB, I_BOX_KIND, I_GOAL_BUTTON, I_BTN_STATE, I_BTN_TIMER,
  I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS) = range(14)
 

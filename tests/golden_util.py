@@ -115,6 +115,7 @@ def base_record(task, names, keepouts, env_id=0):
   rf[F_KEEPOUT + 3] = keepouts.get('pillars0', 0.3)
   rf[F_KEEPOUT + 4] = keepouts.get('box', 0.5)
   rf[F_CATCH + 2], rf[F_CATCH + 3] = 1.0, 0.2  # catch_goal.py:15-16
+  rf[144 + 5] = 1.0  # car rear-ball quaternion w
   return rf, ri
 
 

@@ -48,6 +48,7 @@ def test_record_offsets_match_header():
                   ('F_KEEPOUT', 'SAG_F_KEEPOUT'), ('F_GOAL', 'SAG_F_GOAL'), ('F_CATCH', 'SAG_F_CATCH'),
                   ('F_LAST', 'SAG_F_LAST'), ('F_BOX', 'SAG_F_BOX'), ('F_HAZARDS', 'SAG_F_HAZARDS'),
                   ('F_PILLARS', 'SAG_F_PILLARS'), ('F_BUTTONS', 'SAG_F_BUTTONS'), ('F_VASES', 'SAG_F_VASES'),
+                  ('F_ROBOT_EXT', 'SAG_F_ROBOT_EXT'),
                   ('REC_FLOATS', 'SAG_REC_FLOATS'), ('REC_INTS', 'SAG_REC_INTS'),
                   ('I_TASK', 'SAG_I_TASK'), ('I_NB', 'SAG_I_NB'), ('I_BOX_KIND', 'SAG_I_BOX_KIND'),
                   ('I_GOAL_BUTTON', 'SAG_I_GOAL_BUTTON'), ('I_ACTIVE_MASK', 'SAG_I_ACTIVE_MASK'),

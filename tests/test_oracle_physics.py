@@ -219,3 +219,97 @@ def test_haul_tendon_limits_the_distance(oracle):
   assert f[F_ROBOT] < -0.5, 'robot keeps moving'
   assert L < 0.76, f'tendon stretched to {L}'
   assert f[F_BOX] < 0.55, 'box is hauled along'
+
+
+# ---------------------------------------------------------------------------
+# Car robot: planar reduction of car.xml (specification)
+# ---------------------------------------------------------------------------
+F_EXT = 144
+
+
+def car_run(oracle, rf, ri, action, steps):
+  e = oracle.env(rf, ri)
+  outs = []
+  for _ in range(steps):
+    outs.append(oracle.step(e, 1, action, noise=(0., 0.), tape=np.zeros(8, np.uint32)))
+  return e, outs
+
+
+def test_car_straight_line_force_balance(oracle):
+  """Full throttle: the wheels do not saturate their friction, the rear ball does (its joint
+  damping .001 N m s is large for a 2.6 g ball), so the terminal state is the balance
+  2 (tau - d w_wheel) / r = mu N_caster, moving along the body's -y with no lateral slip."""
+  rf, ri = empty_world()
+  rf[F_ROBOT + 2] = 0.3
+  e, outs = car_run(oracle, rf, ri, [1.0, 1.0], 250)
+  f, _ = oracle.record(e)
+  yaw = f[F_ROBOT + 2]
+  v = f[F_ROBOT + 3:F_ROBOT + 5]
+  fwd = np.array([np.sin(yaw), -np.cos(yaw)])          # -y_body in world axes
+  speed = np.dot(v, fwd)
+  assert 0.6 < speed < 1.0
+  assert abs(np.dot(v, [np.cos(yaw), np.sin(yaw)])) < 5e-3, 'no sideways slip'
+  assert abs(yaw - 0.3) < 0.08, 'sequential friction sweep: only a slow heading drift'
+  import ctypes as C
+  k = (C.c_double * 9)(); oracle.lib.sago_car_constants(k)
+  drive = sum((0.02 - 0.001 * f[F_EXT + i]) / 0.05 for i in range(2))
+  assert abs(drive - 1.0 * k[8]) < 0.02 * k[8], 'wheel drive balances the sliding caster'
+  assert 0.05 * f[F_EXT] > speed, 'driven wheels slip forward a little'
+  assert 0 < 0.05 * f[F_EXT + 2] < speed, 'the ball under-rotates (it slides)'
+  q = f[F_EXT + 5:F_EXT + 9]
+  assert abs(np.linalg.norm(q) - 1) < 1e-9
+  o = np.array(outs[-1].obs[:72])
+  np.testing.assert_allclose(o[63:72].reshape(3, 3) @ o[63:72].reshape(3, 3).T, np.eye(3), atol=1e-9)
+  assert abs(o[50] - 9.81) < 1e-12 and abs(o[52] + speed) < 1e-3   # accelerometer z, velocimeter y
+
+
+def test_car_differential_drive_turns_in_place(oracle):
+  rf, ri = empty_world()
+  e, _ = car_run(oracle, rf, ri, [1.0, -1.0], 100)
+  f, _ = oracle.record(e)
+  assert abs(f[F_ROBOT + 5]) > 1.0, 'opposite wheel torques spin the car'
+  assert np.hypot(f[F_ROBOT + 3], f[F_ROBOT + 4]) < 0.3
+  assert np.hypot(f[F_ROBOT], f[F_ROBOT + 1]) < 0.2
+  assert f[F_EXT] > 0 > f[F_EXT + 1]
+
+
+def test_car_wheels_resist_sideways_motion(oracle):
+  rf, ri = empty_world()
+  rf[F_ROBOT + 3] = 0.5    # along body x (yaw 0): sideways for the wheels
+  e, _ = car_run(oracle, rf, ri, [0.0, 0.0], 6)
+  f, _ = oracle.record(e)
+  assert abs(f[F_ROBOT + 3]) < 0.05
+  # along the rolling direction, wheels and ball already rolling (v_y + r w = 0): it coasts,
+  # slowed only by the joint damping (the wheels' armature is a 0.2 kg-equivalent flywheel)
+  rf[F_ROBOT + 3], rf[F_ROBOT + 4] = 0.0, -0.5
+  rf[F_EXT], rf[F_EXT + 1], rf[F_EXT + 2] = 10.0, 10.0, 10.0
+  e, _ = car_run(oracle, rf, ri, [0.0, 0.0], 1)
+  f, _ = oracle.record(e)
+  # joint damping (2 x .001 x 10 / .05 = .4 N) + sliding caster (.14 N) on .03 + .2 kg: -2.3 m/s^2
+  assert abs(f[F_ROBOT + 4] - (-0.5 + 2.3 * 0.08)) < 0.05
+  rf[F_ROBOT + 3], rf[F_ROBOT + 4] = 0.5, 0.0
+  e, _ = car_run(oracle, rf, ri, [0.0, 0.0], 1)
+  assert abs(oracle.record(e)[0][F_ROBOT + 3]) < 0.05, 'sideways: stopped within one step'
+
+
+def test_car_stops_at_pillar_with_cost(oracle):
+  rf, ri = empty_world()
+  ri[I_NP] = 1
+  rf[F_ROBOT + 2] = np.pi / 2         # -y_body = +x world
+  rf[F_PILLARS:F_PILLARS + 2] = [1.0, 0.0]
+  e, outs = car_run(oracle, rf, ri, [1.0, 1.0], 150)
+  f, _ = oracle.record(e)
+  # front bumper face at .175 ahead of the origin, pillar surface at x = .8
+  assert 0.8 - 0.175 - 2e-3 < f[F_ROBOT] < 0.8 - 0.175 + 2e-3
+  assert outs[-1].cost == 1 and outs[0].cost == 0
+  assert np.isfinite(oracle.record(e)[0]).all()
+
+
+def test_car_constants(oracle):
+  import ctypes as C
+  out = (C.c_double * 9)()
+  oracle.lib.sago_car_constants(out)
+  m, Io, ox, oy, Iw, Ib, NL, NR, NC = list(out)
+  assert abs(m - 0.030445) < 1e-5 and abs(ox) < 1e-15 and abs(oy - 0.0074) < 1e-4
+  assert abs(Iw - 2.5245e-4) < 1e-7 and abs(Ib - 2.618e-6) < 1e-8
+  assert abs(NL + NR + NC - m * 9.81) < 1e-12 and NL == NR and NC > NL
