@@ -1105,7 +1105,7 @@ static void catch_goal_mocap(OEnv* e, Rng* g, double time) {
 /* ------------------------------------------------------------------------ */
 /* per-task reward (tasks/<task>.py compute_reward)                                */
 /* ------------------------------------------------------------------------ */
-static void task_reward(OEnv* e, Rng* g, uint32_t btn_mask, OOut* out) {
+static void task_reward(OEnv* e, int robot, Rng* g, uint32_t btn_mask, OOut* out) {
   real* f = e->f;
   int task = e->i[SAG_I_TASK];
   double rx = f[SAG_F_ROBOT], ry = f[SAG_F_ROBOT + 1];
@@ -1135,10 +1135,13 @@ static void task_reward(OEnv* e, Rng* g, uint32_t btn_mask, OOut* out) {
       }
       if (task == SAG_TASK_UNSUPERVISED) { /* tasks/unsupervised.py:48-67 */
         double c = cos((double)f[SAG_F_ROBOT + 2]), s = sin((double)f[SAG_F_ROBOT + 2]);
-        double off = PT_MC / PT_MASS; /* subtree COM offset along local +x */
-        double x = rx + c * off, y = ry + s * off;
+        /* subtree COM in body axes: point (mc/m, 0) along +x; car (0, oy) */
+        double bx = PT_MC / PT_MASS, by = 0;
+        if (robot == SAG_ROBOT_CAR) { CarK k = car_constants(); bx = k.ox; by = k.oy; }
+        double lx = c * bx - s * by, ly = s * bx + c * by;
+        double x = rx + lx, y = ry + ly;
         double w = f[SAG_F_ROBOT + 5];
-        double u = f[SAG_F_ROBOT + 3] - w * (s * off), v = f[SAG_F_ROBOT + 4] + w * (c * off);
+        double u = f[SAG_F_ROBOT + 3] - w * ly, v = f[SAG_F_ROBOT + 4] + w * lx;
         double radius = sqrt(x * x + y * y);
         out->reward[0] = (real)((((-u * y + v * x) / radius) / (1 + fabs(radius - 1.5))) * 1e-1);
         out->reward[1] = (real)r;
@@ -1353,7 +1356,7 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   if (ext_cost_contacts >= 0) { cc = ext_cost_contacts; mask = ext_btn_mask; }
   out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
   out->btn_contact_mask = mask;
-  task_reward(e, &g, mask, out);                /* :77 */
+  task_reward(e, robot, &g, mask, out);         /* :77 */
   double margin = 1e30;
   int cost = cc + hazard_cost(e, &margin);      /* :78, world.py:144-155 */
   out->cost = cost > 0;

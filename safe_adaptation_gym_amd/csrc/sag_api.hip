@@ -111,8 +111,8 @@ void drain_events(sag_ctx* c) {
 int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint32_t* d_tape,
                 int tape_len, int nstep, float* d_obs, float* d_rew, uint8_t* d_cost,
                 uint8_t* d_done, uint8_t* d_met, int32_t* d_used, int observe_only) {
-  if (c->cfg.robot != SAG_ROBOT_POINT)
-    return fail(c, SAG_ERR_UNSUPPORTED, "only the Point robot has a device integrator in this build");
+  if (c->cfg.robot == SAG_ROBOT_DOGGO)
+    return fail(c, SAG_ERR_UNSUPPORTED, "the Doggo robot has no device integrator in this build");
   StepArgs a;
   a.S = c->S; a.I = c->I; a.N = c->N;
   a.actions = d_act; a.noise = d_noise; a.tape = d_tape; a.tape_len = tape_len;
@@ -144,10 +144,16 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
   const bool btn = c->cfg.max_buttons > 0, tbox = c->cfg.has_box != 0;
-  if (!btn && !tbox) hipLaunchKernelGGL((k_step_point<false, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
-  else if (btn && !tbox) hipLaunchKernelGGL((k_step_point<true, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
-  else if (!btn && tbox) hipLaunchKernelGGL((k_step_point<false, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
-  else hipLaunchKernelGGL((k_step_point<true, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a);
+#define SAG_LAUNCH(ROB)                                                                               \
+  do {                                                                                                \
+    if (!btn && !tbox) hipLaunchKernelGGL((k_step<ROB, false, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a); \
+    else if (btn && !tbox) hipLaunchKernelGGL((k_step<ROB, true, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a); \
+    else if (!btn && tbox) hipLaunchKernelGGL((k_step<ROB, false, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a); \
+    else hipLaunchKernelGGL((k_step<ROB, true, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a);   \
+  } while (0)
+  if (c->cfg.robot == SAG_ROBOT_POINT) SAG_LAUNCH(SAG_ROBOT_POINT);
+  else SAG_LAUNCH(SAG_ROBOT_CAR);
+#undef SAG_LAUNCH
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipGetLastError());
   return 0;

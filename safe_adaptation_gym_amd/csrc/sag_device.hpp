@@ -84,6 +84,26 @@ constexpr float BUTTON_R = 0.1f, VASE_DENSITY = 0.001f;
 constexpr float REST_V = 1e-5f, REST_W = 1e-4f;
 constexpr float ROBOT_BOUND = 0.15811388300841897f;  // arrow corner (0.15, 0.05)
 
+// ---- constants of the Car robot (assets/xmls/car.xml, density 5) -------------------
+// masses: boxes 8 hx hy hz rho; wheels pi r^2 L rho; rear ball 4/3 pi r^3 rho
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float CAR_MB0 = 5 * 8 * 0.1f * 0.1f * 0.05f, CAR_MB1 = 5 * 8 * 0.1f * 0.01f * 0.05f,
+                CAR_MB2 = 5 * 8 * 0.01f * 0.025f * 0.03f, CAR_MB3 = 5 * 8 * 0.05f * 0.01f * 0.05f,
+                CAR_MB4 = 5 * 8 * 0.05f * 0.03f * 0.01f, CAR_MW = 5 * PI_F * 0.05f * 0.05f * 0.05f,
+                CAR_MBALL = 5 * 4.0f / 3.0f * PI_F * 0.05f * 0.05f * 0.05f;
+constexpr float CAR_M = CAR_MB0 + CAR_MB1 + CAR_MB2 + CAR_MB3 + CAR_MB4 + 2 * CAR_MW + CAR_MBALL;
+constexpr float CAR_OY = (CAR_MB1 * 0.15f + CAR_MB2 * 0.125f - CAR_MB3 * 0.165f - CAR_MB4 * 0.13f +
+                          2 * CAR_MW * 0.1f - CAR_MBALL * 0.1f) / CAR_M;
+// yaw inertia about the base origin: own (box m (a^2+b^2)/3, cylinder-on-its-side m (3r^2+L^2)/12,
+// sphere 2/5 m r^2) + m d^2
+constexpr float CAR_IO =
+    CAR_MB0 * (0.01f + 0.01f) / 3 + CAR_MB1 * ((0.01f + 0.0001f) / 3 + 0.15f * 0.15f) +
+    CAR_MB2 * ((0.0001f + 0.000625f) / 3 + 0.125f * 0.125f) + CAR_MB3 * ((0.0025f + 0.0001f) / 3 + 0.165f * 0.165f) +
+    CAR_MB4 * ((0.0025f + 0.0009f) / 3 + 0.13f * 0.13f) +
+    2 * CAR_MW * ((3 * 0.0025f + 0.0025f) / 12 + 0.13f * 0.13f + 0.01f) + CAR_MBALL * (0.4f * 0.0025f + 0.01f);
+constexpr float CAR_IW = 0.5f * CAR_MW * 0.0025f + 0.00025f;  // axle inertia + armature (car.xml:22,26)
+constexpr float CAR_IB = 0.4f * CAR_MBALL * 0.0025f;
+
 // ---- counter-based generator ------------------------------------------------
 __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -276,10 +296,10 @@ __device__ inline double dist2d(double ax, double ay, double bx, double by) {
 // Shape codes: the robot, a vase, the PushBox-family task object (box / rod / ball), a static
 // circle.  Values follow point.xml:18-19, primitive_objects.py, push_box.py:28-72,
 // roll_rod.py:19-43, dribble_ball.py:18-41.
-enum { SH_ROBOT = 0, SH_VASE = 1, SH_BOX = 2, SH_ROD = 3, SH_BALL = 4, SH_STATIC = 5 };
+enum { SH_ROBOT = 0, SH_VASE = 1, SH_BOX = 2, SH_ROD = 3, SH_BALL = 4, SH_STATIC = 5, SH_CAR = 6 };
 struct Geom { int box; float ox, oy, a, b; };  // box ? half extents (a, b) : radius a
 
-__device__ inline int shape_ngeom(int sh) { return sh == SH_ROBOT ? 2 : (sh == SH_BOX ? 5 : 1); }
+__device__ inline int shape_ngeom(int sh) { return sh == SH_ROBOT ? 2 : (sh == SH_BOX ? 5 : (sh == SH_CAR ? 8 : 1)); }
 
 __device__ inline Geom shape_geom(int sh, int g, float vsz, float rstatic) {
   Geom q; q.ox = 0; q.oy = 0; q.b = 0;
@@ -293,6 +313,14 @@ __device__ inline Geom shape_geom(int sh, int g, float vsz, float rstatic) {
       break;
     case SH_ROD: q.box = 1; q.a = 0.08f; q.b = 0.3f; break;
     case SH_BALL: q.box = 0; q.a = 0.14f; break;
+    case SH_CAR:  // car.xml:16-32 footprints: base, back bumper/connector, front bumper/connector,
+                  // left/right wheel (cylinders along x), rear ball
+      q.box = g < 7;
+      q.ox = g == 5 ? -0.13f : (g == 6 ? 0.13f : 0.f);
+      q.oy = g == 1 ? 0.15f : (g == 2 ? 0.125f : (g == 3 ? -0.165f : (g == 4 ? -0.13f : (g == 7 ? -0.1f : (g >= 5 ? 0.1f : 0.f)))));
+      q.a = g == 0 || g == 1 ? 0.1f : (g == 2 ? 0.01f : (g == 5 || g == 6 ? 0.025f : 0.05f));
+      q.b = g == 0 ? 0.1f : (g == 1 || g == 3 ? 0.01f : (g == 2 ? 0.025f : (g == 4 ? 0.03f : 0.05f)));
+      break;
     default: q.box = 0; q.a = rstatic; break;
   }
   return q;
@@ -305,6 +333,7 @@ __device__ inline float shape_bound(int sh, float vsz, float rstatic) {
     case SH_BOX: return 0.42426406871192851f;   // column corner (0.3, 0.3)
     case SH_ROD: return 0.31048349392520047f;   // sqrt(.08^2 + .3^2)
     case SH_BALL: return 0.14f;
+    case SH_CAR: return 0.21569654610114636f;  // wheel corner (.155, .15)
     default: return rstatic;
   }
 }
@@ -353,8 +382,7 @@ constexpr int DPOOL = 3;
 enum { LS_X = 0, LS_Y = NBODY, LS_YAW = 2 * NBODY, LS_POOL = 3 * NBODY };
 constexpr int LDS_SLOTS = LS_POOL + 6 * DPOOL;
 constexpr int LDS_FLOATS = LDS_SLOTS * WAVE;
-constexpr int STG_BASE = LS_YAW * WAVE, STG_STRIDE = 17;
-static_assert(STG_BASE + WAVE * STG_STRIDE <= LDS_FLOATS, "staging tile must fit");
+constexpr int STG_BASE = LS_YAW * WAVE;
 
 // timing-only ablations (tools/ablate.py): -DSAG_ABLATE=<mask>; results are wrong by design
 #ifndef SAG_ABLATE
@@ -366,7 +394,7 @@ enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL
 #define SF(k) S[(size_t)(k) * N + i]
 #define LP(base, k) lds[((base) + (k)) * WAVE + lane]
 #define POOL(d, c) lds[(LS_POOL + (d) * 6 + (c)) * WAVE + lane]
-#define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]
+#define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]  // STG_STRIDE: constexpr of the enclosing kernel
 
 // tstate bits 17..27: body k has non-zero velocity or may overlap something (derived at
 // install); lets the kernel skip the loads, pair tests and write-back of sleeping bodies.
@@ -441,6 +469,7 @@ __device__ __attribute__((noinline)) LidarHit lidar_exact(double rx, double ry, 
   return h;
 }
 
+template <int STG_STRIDE>
 __device__ inline void lidar_point(float* lds, int lane, double rx, double ry, double cd, double sd,
                                    float rxf, float ryf, float cf, float sf, float px, float py) {
   const float w0 = px - rxf, w1 = py - ryf;
@@ -472,9 +501,15 @@ __device__ inline void lidar_point(float* lds, int lane, double rx, double ry, d
 // HAS_BTN / HAS_TBOX: compile-time knowledge that the context holds no buttons / no task object
 // (capacities of sag_create); the specialised instances drop those arrays, loops and the box
 // shapes altogether.  <true, true> serves mixed (multitask) batches.
-template <bool HAS_BTN, bool HAS_TBOX>
-__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArgs p) {
+template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
+__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
   constexpr int NSTAT = SAG_MAX_PILLARS + (HAS_BTN ? SAG_MAX_BUTTONS : 0);
+  constexpr bool CAR = ROBOT == SAG_ROBOT_CAR;
+  constexpr int SH_ME = CAR ? SH_CAR : SH_ROBOT;
+  constexpr int OBS_DIM = CAR ? 72 : 60, NSENS = OBS_DIM - 48;
+  constexpr int STG_STRIDE = CAR ? 25 : 17;
+  static_assert(STG_BASE + WAVE * STG_STRIDE <= LDS_FLOATS, "staging tile must fit");
+  const float my_bound = shape_bound(SH_ME, 0.f, 0.f);
   __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
   const int lane = threadIdx.x;
   const int N = p.N;
@@ -498,6 +533,12 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
   R.ax = R.ay = R.aw = 0; R.dyn = 1;
   const float gear = SF(SAG_F_GEAR), damp = SF(SAG_F_DAMP);
   const float vsz = SF(SAG_F_VASE_SIZE), psz = SF(SAG_F_PILLAR_SIZE);
+  // car: wheel rates L, R; rear ball rate x, y, z (base axes); ball quaternion w, x, y, z
+  float ext[9] = {0, 0, 0, 0, 0, 1, 0, 0, 0}, eacc[5] = {0, 0, 0, 0, 0};
+  if constexpr (CAR) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) ext[k] = SF(SAG_F_ROBOT_EXT + k);
+  }
   float goalx = SF(SAG_F_GOAL), goaly = SF(SAG_F_GOAL + 1);
   float last0 = SF(SAG_F_LAST);
   float a0 = 0, a1 = 0, n0 = 0, n1 = 0;
@@ -638,6 +679,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
 #pragma unroll 1
   for (int sub = 0; sub <= nsub; sub++) {
     sincosf(yaw, &sy, &cy);
+    if constexpr (!CAR) {
     // robot smooth dynamics (point.xml)
     {
       float f0 = gear * clampf(ctrl0, -PT_FLIM, PT_FLIM);
@@ -659,6 +701,49 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
       R.ay = R.m1 * Fx + R.m3 * Fy + R.m4 * Tz;
       R.aw = R.m2 * Fx + R.m4 * Fy + R.m5 * Tz;
     }
+    } else {
+      // Car (car.xml; DESIGN.md "Car"): planar base with COM offset, two driven wheels and a
+      // rear ball; floor contact = regularised Coulomb friction at the three contact points
+      constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CIW = CAR_IW, CIB = CAR_IB, CJD = 0.001f, CRW = 0.05f;
+      constexpr float CNL = CM * GRAV * (0.1f + COY) / 0.4f, CNC = CM * GRAV - 2 * CNL;
+      const float ox = -sy * COY, oy = cy * COY;
+      {
+        const float a = -CM * oy, b = CM * ox;
+        const float id = 1.0f / (CM * (CM * CIO - a * a - b * b));
+        R.m0 = (CM * CIO - b * b) * id; R.m1 = (a * b) * id; R.m2 = (-a * CM) * id;
+        R.m3 = (CM * CIO - a * a) * id; R.m4 = (-b * CM) * id; R.m5 = (CM * CM) * id;
+        const float Fx = CM * R.w * R.w * ox, Fy = CM * R.w * R.w * oy;
+        R.ax = R.m0 * Fx + R.m1 * Fy; R.ay = R.m1 * Fx + R.m3 * Fy; R.aw = R.m2 * Fx + R.m4 * Fy;
+      }
+      const float Iw = CIW + h * CJD, Ib = CIB + h * CJD;
+      eacc[0] = (clampf(ctrl0, -0.02f, 0.02f) - CJD * ext[0]) / Iw;
+      eacc[1] = (clampf(ctrl1, -0.02f, 0.02f) - CJD * ext[1]) / Iw;
+      eacc[2] = -CJD * ext[2] / Ib; eacc[3] = -CJD * ext[3] / Ib; eacc[4] = -CJD * ext[4] / Ib;
+      // one friction direction d at lever (rx, ry), optionally coupled to a spinning part
+      auto fric = [&](float dx, float dy, float rx, float ry, float rate, float* sacc, float Isp, float lim) {
+        float u[3];
+        float A = minv_apply(R, dx, dy, rx * dy - ry * dx, u);
+        const float slip = (R.vx - R.w * ry) * dx + (R.vy + R.w * rx) * dy + (sacc ? CRW * rate : 0.f);
+        const float sa = (R.ax - R.aw * ry) * dx + (R.ay + R.aw * rx) * dy + (sacc ? CRW * *sacc : 0.f);
+        if (sacc) A += CRW * CRW / Isp;
+        const float f = clampf(SOL_D0 * (-sol0.bcoef * slip - sa) / A, -lim, lim);
+        R.ax += u[0] * f; R.ay += u[1] * f; R.aw += u[2] * f;
+        if (sacc) *sacc += CRW * f / Isp;
+      };
+      {
+        float rx = cy * -0.13f - sy * 0.1f, ry = sy * -0.13f + cy * 0.1f;   // left wheel
+        fric(-sy, cy, rx, ry, ext[0], &eacc[0], Iw, MU * CNL);
+        fric(cy, sy, rx, ry, 0.f, nullptr, 1.f, MU * CNL);
+        rx = cy * 0.13f - sy * 0.1f; ry = sy * 0.13f + cy * 0.1f;           // right wheel
+        fric(-sy, cy, rx, ry, ext[1], &eacc[1], Iw, MU * CNL);
+        fric(cy, sy, rx, ry, 0.f, nullptr, 1.f, MU * CNL);
+        rx = sy * 0.1f; ry = -cy * 0.1f;                                    // rear ball (0, -.1)
+        float syacc = -eacc[3];
+        fric(cy, sy, rx, ry, -ext[3], &syacc, Ib, MU * CNC);                // x slip <-> -ball_y
+        eacc[3] = -syacc;
+        fric(-sy, cy, rx, ry, ext[2], &eacc[2], Ib, MU * CNC);              // y slip <-> +ball_x
+      }
+    }
     cost_contacts = 0; btn_mask = 0;
     // `active` = bodies that can have a non-zero acceleration or velocity this substep.
     // A sleeping body (v = 0, untouched) overlaps nothing, so every pair test it would take
@@ -673,11 +758,11 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
       const bool is_p = k < SAG_MAX_PILLARS;
       const bool on = (is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB)) && !ABL(ABL_NO_RS);
       const float sx = stx[k], syy = sty[k], sr = is_p ? psz : BUTTON_R;
-      const float dx = sx - R.x, dyy = syy - R.y, rs = ROBOT_BOUND + sr;
+      const float dx = sx - R.x, dyy = syy - R.y, rs = my_bound + sr;
       if (on && dx * dx + dyy * dyy <= rs * rs) {
         BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
         St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-        const int n = collide_shapes(R, SH_ROBOT, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
+        const int n = collide_shapes(R, SH_ME, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
         if (is_p) cost_contacts += n;
         else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
       }
@@ -688,11 +773,11 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
     uint32_t hits = 0;
 #pragma unroll 1
     for (int k = 0; k < nV; k++) {
-      const float dx = LP(LS_X, k) - R.x, dyy = LP(LS_Y, k) - R.y, rs = ROBOT_BOUND + vase_r;
+      const float dx = LP(LS_X, k) - R.x, dyy = LP(LS_Y, k) - R.y, rs = my_bound + vase_r;
       if (dx * dx + dyy * dyy <= rs * rs) hits |= 1u << k;
     }
     if (has_box) {
-      const float dx = LP(LS_X, BOX_ID) - R.x, dyy = LP(LS_Y, BOX_ID) - R.y, rs = ROBOT_BOUND + box_r;
+      const float dx = LP(LS_X, BOX_ID) - R.x, dyy = LP(LS_Y, BOX_ID) - R.y, rs = my_bound + box_r;
       if (dx * dx + dyy * dyy <= rs * rs) hits |= 1u << BOX_ID;
     }
     if (ABL(ABL_NO_RV)) hits = 0;
@@ -702,7 +787,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
       dy.ensure(k, false);
       BV V; float cv, sv; load_body(dy, k, V, cv, sv);
       const float ax0 = V.ax, ay0 = V.ay, aw0 = V.aw;
-      const int n = collide_shapes(R, SH_ROBOT, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
+      const int n = collide_shapes(R, SH_ME, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
       if (!isb) cost_contacts += n;   // the task object is not an obstacle (consts.OBSTACLES)
       if (n) { dy.set_acc(k, V.ax, V.ay, V.aw); active |= 1u << k; }
       (void)ax0; (void)ay0; (void)aw0;
@@ -838,6 +923,24 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
     }
     R.vx += h * R.ax; R.vy += h * R.ay; R.w += h * R.aw;
     R.x += h * R.vx; R.y += h * R.vy; yaw += h * R.w;
+    if constexpr (CAR) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) ext[k] += h * eacc[k];
+      // ball quaternion: rate relative to the base, in base axes: q <- exp(h W / 2) q
+      const float wx = ext[2], wy = ext[3], wz = ext[4];
+      const float n = sqrtf(wx * wx + wy * wy + wz * wz);
+      if (n > 0) {
+        float sn, cs; sincosf(0.5f * h * n, &sn, &cs);
+        sn /= n;
+        const float dw = cs, dx = sn * wx, dy_ = sn * wy, dz = sn * wz;
+        const float qw = dw * ext[5] - dx * ext[6] - dy_ * ext[7] - dz * ext[8];
+        const float qx = dw * ext[6] + dx * ext[5] + dy_ * ext[8] - dz * ext[7];
+        const float qy = dw * ext[7] - dx * ext[8] + dy_ * ext[5] + dz * ext[6];
+        const float qz = dw * ext[8] + dx * ext[7] - dy_ * ext[6] + dz * ext[5];
+        const float qn = 1.0f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+        ext[5] = qw * qn; ext[6] = qx * qn; ext[7] = qy * qn; ext[8] = qz * qn;
+      }
+    }
   }
 
   // ---- write back dynamic state -------------------------------------------------
@@ -845,6 +948,10 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
   if (!p.observe_only && live) {
     SF(SAG_F_ROBOT) = R.x; SF(SAG_F_ROBOT + 1) = R.y; SF(SAG_F_ROBOT + 2) = yaw;
     SF(SAG_F_ROBOT + 3) = R.vx; SF(SAG_F_ROBOT + 4) = R.vy; SF(SAG_F_ROBOT + 5) = R.w;
+    if constexpr (CAR) {
+#pragma unroll
+      for (int k = 0; k < 9; k++) SF(SAG_F_ROBOT_EXT + k) = ext[k];
+    }
     for (uint32_t m = dirty; m; m &= m - 1) {
       const int k = __ffs(m) - 1;
       const int f = k == BOX_ID ? SAG_F_BOX : SAG_F_VASES + 6 * k;
@@ -950,9 +1057,12 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
       }
       last0 = last;
       if (task == SAG_TASK_UNSUPERVISED) {  // tasks/unsupervised.py:48-67
-        double c = cos((double)yaw), s = sin((double)yaw), off = (double)PT_MC / (double)PT_MASS;
-        double x = rx + c * off, y = ry + s * off, w = R.w;
-        double u = (double)R.vx - w * (s * off), v = (double)R.vy + w * (c * off);
+        // subtree COM of the robot in body axes: point (mc/m, 0); car (0, .0074)
+        const double c = cos((double)yaw), s = sin((double)yaw);
+        const double bx_ = CAR ? 0.0 : (double)PT_MC / (double)PT_MASS, by_ = CAR ? (double)CAR_OY : 0.0;
+        const double lx = c * bx_ - s * by_, ly = s * bx_ + c * by_;
+        double x = rx + lx, y = ry + ly, w = R.w;
+        double u = (double)R.vx - w * ly, v = (double)R.vy + w * lx;
         double radius = sqrt(x * x + y * y);
         rew0 = (((-u * y + v * x) / radius) / (1 + fabs(radius - 1.5))) * 1e-1;
         rew1 = r;
@@ -1019,7 +1129,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
     const uint32_t act = tstate >> 11 & 63;
     const int base_env = blockIdx.x * WAVE;
     const int nvalid = min(WAVE, N - base_env);
-    float* __restrict__ o = p.obs + (size_t)base_env * 60;
+    float* __restrict__ o = p.obs + (size_t)base_env * OBS_DIM;
     __syncthreads();  // physics is done with the yaw / pool slots everywhere in the wavefront
 #pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
@@ -1030,27 +1140,27 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
       if (chunk == 0 && !ABL(ABL_NO_LIDAR)) {
 #pragma unroll 1
         for (int k = 0; k < SAG_MAX_HAZARDS; k++)
-          if (k < nH) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
+          if (k < nH) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
 #pragma unroll 1
         for (int k = 0; k < nV; k++)
-          lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, LP(LS_X, k), LP(LS_Y, k));
+          lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, LP(LS_X, k), LP(LS_Y, k));
 #pragma unroll 1
         for (int k = 0; k < SAG_MAX_PILLARS; k++)
-          if (k < nP) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, stx[k], sty[k]);
+          if (k < nP) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, stx[k], sty[k]);
       } else if (chunk == 1 || chunk == 2) {
         const int want = chunk == 1 ? 3 : 2;  // GROUP_OBJECTS then GROUP_GOAL (consts.py:13-16)
-        if (chunk == 1 && has_box) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, boxx, boxy);
+        if (chunk == 1 && has_box) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, boxx, boxy);
 #pragma unroll 1
         for (int b = 0; b < (HAS_BTN ? SAG_MAX_BUTTONS : 0); b++) {
           if (b < nB) {
             int g;
             if (task == SAG_TASK_COLLECT) g = (act >> b & 1) ? 2 : 0;
             else g = bstate == 0 ? 0 : (b == gb ? 2 : 3);
-            if (g == want) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf,
+            if (g == want) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf,
                                        stx[(SAG_MAX_PILLARS + b) % NSTAT], sty[(SAG_MAX_PILLARS + b) % NSTAT]);
           }
         }
-        if (chunk == 2 && nB == 0) lidar_point(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, goalx, goaly);
+        if (chunk == 2 && nB == 0) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, goalx, goaly);
       } else if (chunk == 3) {
         const float qax = bad ? 0.0f : R.ax, qay = bad ? 0.0f : R.ay;
         STG(0) = cf * qax + sf * qay;
@@ -1060,6 +1170,17 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
         STG(4) = cf * R.vy - sf * R.vx;
         STG(5) = 0; STG(6) = 0; STG(7) = 0; STG(8) = R.w;
         STG(9) = -0.5f * sf; STG(10) = -0.5f * cf; STG(11) = 0;
+        if constexpr (CAR) {
+          // ballangvel_rear in the ball's own frame, then the 3x3 of ballquat_rear, row-major
+          const float qw = ext[5], qx = ext[6], qy = ext[7], qz = ext[8];
+          const float Rm[9] = {qw * qw + qx * qx - qy * qy - qz * qz, 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy),
+                               2 * (qx * qy + qw * qz), qw * qw - qx * qx + qy * qy - qz * qz, 2 * (qy * qz - qw * qx),
+                               2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), qw * qw - qx * qx - qy * qy + qz * qz};
+#pragma unroll
+          for (int k = 0; k < 3; k++) STG(12 + k) = Rm[k] * ext[2] + Rm[3 + k] * ext[3] + Rm[6 + k] * ext[4];
+#pragma unroll
+          for (int k = 0; k < 9; k++) STG(15 + k) = Rm[k];
+        }
       }
       __syncthreads();
       if (chunk < 3) {
@@ -1067,16 +1188,17 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_point(StepArg
         for (int j = 0; j < 16; j++) {
           const int e = j * WAVE + lane, env = e >> 4, col = e & 15;
           const float v = lds[STG_BASE + env * STG_STRIDE + col];
-          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * 60 + chunk * 16 + col] = v;
+          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * OBS_DIM + chunk * 16 + col] = v;
         }
       } else {
 #pragma unroll 4
-        for (int j = 0; j < 12; j++) {
+        for (int j = 0; j < NSENS; j++) {
           const int e = j * WAVE + lane;
-          const int env = (int)(((uint32_t)e * 43691u) >> 19);  // e / 12, exact for e < 768
-          const int col = e - env * 12;
+          // e / 12 (e < 768) or e / 24 (e < 1536), exact
+          const int env = (int)(((uint32_t)e * 43691u) >> (NSENS == 12 ? 19 : 20));
+          const int col = e - env * NSENS;
           const float v = lds[STG_BASE + env * STG_STRIDE + col];
-          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * 60 + 48 + col] = v;
+          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * OBS_DIM + 48 + col] = v;
         }
       }
       __syncthreads();

@@ -23,7 +23,7 @@ def sample_records(robot_name, task_name, n, seed=666, config=None):
   return rf, ri
 
 
-def pursuit_actions(rf, ri, rng, p_random=0.2):
+def pursuit_actions(rf, ri, rng, p_random=0.2, robot='point'):
   """A policy that drives Point robots towards their current target with noise, so
   goals are met and obstacles are hit: u0 = forward, u1 = turn rate command."""
   n = len(rf)
@@ -43,9 +43,15 @@ def pursuit_actions(rf, ri, rng, p_random=0.2):
     tx[i], ty[i] = rf[i, nat.F_BOX], rf[i, nat.F_BOX + 1]
     if ri[i, nat.I_TASK] == 7:  # haul_box: the box follows on its tether; head for the goal
       tx[i], ty[i] = rf[i, nat.F_GOAL], rf[i, nat.F_GOAL + 1]
-  ang = np.arctan2(ty - y, tx - x) - yaw
+  heading = yaw if robot == 'point' else yaw - np.pi / 2   # the car drives along its -y axis
+  ang = np.arctan2(ty - y, tx - x) - heading
   ang = (ang + np.pi) % (2 * np.pi) - np.pi
-  a = np.stack([np.where(np.abs(ang) < 1.0, 1.0, 0.2), np.clip(2.0 * ang, -1, 1)], -1)
+  if robot == 'point':
+    a = np.stack([np.where(np.abs(ang) < 1.0, 1.0, 0.2), np.clip(2.0 * ang, -1, 1)], -1)
+  else:
+    # wheel torques saturate at |u| = .02 (car.xml:7): steer by easing one wheel; left faster = CCW
+    turn = np.clip(1.5 * ang, -1, 1)
+    a = 0.02 * np.stack([1 + 2 * np.minimum(turn, 0), 1 - 2 * np.maximum(turn, 0)], -1)
   rnd = rng.uniform(-1, 1, (n, 2))
   pick = rng.uniform(size=n) < p_random
   a[pick] = rnd[pick]

@@ -117,8 +117,11 @@ def _flags_agree(dev, orc, margin, tol=1e-5):
   return int(bad.sum()), int((dev != orc).sum())
 
 
-@pytest.mark.parametrize('task', LOCKSTEP_TASKS)
-def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
+CAR_TASKS = ['go_to_goal', 'push_box', 'press_buttons', 'unsupervised', 'catch_goal', 'haul_box']
+
+
+@pytest.mark.parametrize('robot,task', [('point', t) for t in LOCKSTEP_TASKS] + [('car', t) for t in CAR_TASKS])
+def test_step_lockstep_vs_oracle(nat, oracle, oracle32, robot, task):
   """Every step: take the device state, advance the device AND both oracle builds (fp64 =
   the specification, fp32 = same source in the device's precision) from it with identical
   action / noise / random tape, compare outputs and next state, continue from the device.
@@ -131,27 +134,29 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
   cost flags are exact except where the oracle reports the decision within 1e-5 of its
   threshold."""
   n, T = 192, 160
-  rf, ri = bu.sample_records('point', task, n, seed=666)
+  rid = {'point': 0, 'car': 1}[robot]
+  od = 60 if robot == 'point' else 72
+  rf, ri = bu.sample_records(robot, task, n, seed=666)
   if task not in ('haul_box',):
     rf = bu.goal_beyond_box(rf, ri)
-  ctx = nat.Context('point', n, seed=1234)
+  ctx = nat.Context(robot, n, seed=1234)
   ctx.set_layout(rf, ri)
   rng = np.random.RandomState(7)
   mt = np.random.RandomState(99)
   obs0 = ctx.observe()
   rf, ri = ctx.get_state()
   arr = oracle.make_batch(rf, ri)
-  np.testing.assert_allclose(obs0, oracle.observe_batch(arr, 0), rtol=0, atol=OBS_TOL)
+  np.testing.assert_allclose(obs0, oracle.observe_batch(arr, rid, od), rtol=0, atol=OBS_TOL)
   n_met = n_cost = n_near = viol64 = viol32 = acc_bad = acc_e2e = 0
   for t in range(T):
     rf, ri = ctx.get_state()
     arr, arr32 = oracle.make_batch(rf, ri), oracle32.make_batch(rf, ri)
-    act = bu.pursuit_actions(rf, ri, rng)
+    act = bu.pursuit_actions(rf, ri, rng, robot=robot)
     noise = mt.normal(size=(n, 2)).astype(np.float32)
     tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
     d_obs, d_rew, d_cost, d_done, d_met, d_used = ctx.step(act, noise, tape)
-    o_obs, o_rew, o_cost, o_done, o_met, o_used, o_margin = oracle.step_batch_full(arr, 0, act, noise, tape)
-    o32 = oracle32.step_batch_full(arr32, 0, act, noise, tape)
+    o_obs, o_rew, o_cost, o_done, o_met, o_used, o_margin = oracle.step_batch_full(arr, rid, act, noise, tape, obs_dim=od)
+    o32 = oracle32.step_batch_full(arr32, rid, act, noise, tape, obs_dim=od)
     d_rf, d_ri = ctx.get_state()
     o_rf, o_ri = oracle.batch_records(arr)
     o32_rf, _ = oracle32.batch_records(arr32)
@@ -184,7 +189,7 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
     # observation = f(post-step state): check f tightly on the device's own post-step state,
     # and the end-to-end values loosely (they inherit the one-step state tolerance; the lidar
     # amplifies bearing errors by 16/2pi per radian)
-    f_obs = oracle.observe_batch(oracle.make_batch(d_rf, d_ri), 0)
+    f_obs = oracle.observe_batch(oracle.make_batch(d_rf, d_ri), rid, od)
     np.testing.assert_allclose(d_obs[:, :48], f_obs[:, :48], rtol=0, atol=OBS_TOL, err_msg=f'lidar step {t}')
     np.testing.assert_allclose(d_obs[:, 50:], f_obs[:, 50:], rtol=0, atol=1e-5, err_msg=f'sensors step {t}')
     np.testing.assert_allclose(d_obs[ok, :48], o_obs[ok, :48], rtol=0, atol=1e-3, err_msg=f'lidar e2e step {t}')
@@ -192,7 +197,7 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
     # accelerometer = forward dynamics at the post-step state incl. stiff contact forces
     # (k = 2770 /s^2 per metre of penetration, b = 105 /s per m/s): checked as a function of
     # the device's own post-step state; end to end it is only counted
-    f_acc = oracle.step_batch_full(oracle.make_batch(d_rf, d_ri), 0, act, noise, tape, nstep=0)[0][:, 48:50]
+    f_acc = oracle.step_batch_full(oracle.make_batch(d_rf, d_ri), rid, act, noise, tape, nstep=0, obs_dim=od)[0][:, 48:50]
     acc_bad += int((np.abs(d_obs[:, 48:50] - f_acc) > 2e-2 + 2e-3 * np.abs(f_acc)).any(1).sum())
     acc_e2e += int((np.abs(d_obs[:, 48:50] - o_obs[:, 48:50]) > 2e-2 + 5e-3 * np.abs(o_obs[:, 48:50])).any(1).sum())
     np.testing.assert_allclose(d_rew[ok], o_rew[ok], rtol=0, atol=2e-4, err_msg=f'reward step {t}')
@@ -202,7 +207,8 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, task):
   assert n_cost > 20, 'the rollout should exercise cost events'
   assert n_near <= 0.001 * n * T
   # (the ball's contact is stiff and underdamped - k h^2 = 1.4 - and amplifies rounding more)
-  budget = (0.005 if task == 'dribble_ball' else 0.0005) * n * T
+  # (the car has 8 geoms and a 2x longer step: proportionally more contact onsets per env-step)
+  budget = (0.005 if task == 'dribble_ball' else (0.0015 if robot == 'car' else 0.0005)) * n * T
   assert viol64 <= budget, f'{viol64} env-steps outside the fp64 tolerance'
   assert viol32 <= budget, f'{viol32} env-steps outside the fp32 tolerance'
   assert acc_bad <= 0.0005 * n * T, f'{acc_bad} accelerometer readings off on identical state'
