@@ -35,18 +35,18 @@ N_LAYOUTS = 4096       # distinct sampled layouts, tiled over the batch
 N_ACTION_BUFS = 8
 
 
-def build_records(task, envs_per_gpu, rank, seed=666):
+def build_records(task, envs_per_gpu, rank, seed=666, robot='point'):
   """Layouts with the reference sampler semantics: global env g uses the layout drawn
   with RandomState(seed + g % N_LAYOUTS); env ids (RNG streams) are globally unique."""
   import batch_util as bu
   from safe_adaptation_gym_amd import _native as nat
-  cache = os.path.join(ROOT, 'gpurun_out', f'layouts_{task}_{seed}_{N_LAYOUTS}.npz')
+  cache = os.path.join(ROOT, 'gpurun_out', f'layouts_{robot}_{task}_{seed}_{N_LAYOUTS}.npz')
   n = min(N_LAYOUTS, envs_per_gpu * max(1, int(os.environ.get('WORLD_SIZE', '1'))))
   if os.path.exists(cache):
     z = np.load(cache)
     rf, ri = z['rf'], z['ri']
   else:
-    rf, ri = bu.sample_records('point', task, n, seed=seed)
+    rf, ri = bu.sample_records(robot, task, n, seed=seed)
     try:
       os.makedirs(os.path.dirname(cache), exist_ok=True)
       np.savez(cache + f'.{os.getpid()}.tmp.npz', rf=rf, ri=ri)
@@ -63,13 +63,14 @@ def build_records(task, envs_per_gpu, rank, seed=666):
 class DeviceRun:
   """Everything resident on the GPU: world, action buffers, output buffers."""
 
-  def __init__(self, task, envs, device, rank, seed=666):
+  def __init__(self, task, envs, device, rank, seed=666, robot='point'):
     from safe_adaptation_gym_amd import _native as nat
     self.nat = nat
-    rf, ri = build_records(task, envs, rank, seed)
+    rf, ri = build_records(task, envs, rank, seed, robot)
     has_btn = int(ri[:, nat.I_NB].max()) > 0
-    self.ctx = nat.Context('point', envs, device=device, seed=seed,
-                           max_buttons=nat.MAX_BUTTONS if has_btn else 0, has_box=False)
+    has_box = int(ri[:, nat.I_BOX_KIND].max()) > 0
+    self.ctx = nat.Context(robot, envs, device=device, seed=seed,
+                           max_buttons=nat.MAX_BUTTONS if has_btn else 0, has_box=has_box)
     self.ctx.set_layout(rf, ri)
     self.envs = envs
     od = self.ctx.info['obs_dim']
@@ -113,7 +114,7 @@ class DeviceRun:
   def stats(self):
     cost = self.ctx.dev_download(self.d_cost, (self.envs,), np.uint8)
     done = self.ctx.dev_download(self.d_done, (self.envs,), np.uint8)
-    obs = self.ctx.dev_download(self.d_obs, (min(self.envs, 4096) * 60,), np.float32)
+    obs = self.ctx.dev_download(self.d_obs, (min(self.envs, 4096) * self.ctx.info['obs_dim'],), np.float32)
     return float(cost.mean()), int(done.sum()), bool(np.isfinite(obs).all())
 
   def close(self):
@@ -293,6 +294,19 @@ def main(argv=None, run_factory=None, emit=print):
           'note': 'BASELINE config-2 batch size (4096 envs on one GPU): launch/latency bound, 64 wavefronts'
       }
       c2.close()
+    if not args.no_c2:
+      # BASELINE config 3 (Car / push_box), 4096 envs and a loaded batch; 804 algorithmic B/env-step
+      c3 = {}
+      for n_c3 in (4096, 1 << 18):
+        r3 = DeviceRun('push_box', n_c3, device, 0, robot='car')
+        r3.burn_in(60)
+        r3.timing(True)
+        t = timed(r3, 100, 10, lambda: None)
+        ms, _ = r3.kernel_time_ms()
+        c3[str(n_c3)] = {'value': n_c3 * 100 / t, 'kernel_ms': ms,
+                         'roofline_frac': 804 * n_c3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        r3.close()
+      res['c3_car_push_box'] = c3
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(args.task)
   if rank == 0:
