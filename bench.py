@@ -31,33 +31,20 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 # goal xy 88 + task scalars r/w 16 + obs 240 + reward 4 + cost 4 + done 4
 ALG_BYTES_PER_ENV_STEP = 892
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-N_LAYOUTS = 4096       # distinct sampled layouts, tiled over the batch
 N_ACTION_BUFS = 8
 
 
 def build_records(task, envs_per_gpu, rank, seed=666, robot='point'):
-  """Layouts with the reference sampler semantics: global env g uses the layout drawn
-  with RandomState(seed + g % N_LAYOUTS); env ids (RNG streams) are globally unique."""
-  import batch_util as bu
+  """Layouts with the reference sampler semantics (native sampler, exact numpy-legacy stream):
+  global env g is drawn with RandomState(seed + g) exactly as make(robot, task, seed + g)
+  would, and g is also its RNG stream id on the device."""
   from safe_adaptation_gym_amd import _native as nat
-  cache = os.path.join(ROOT, 'gpurun_out', f'layouts_{robot}_{task}_{seed}_{N_LAYOUTS}.npz')
-  n = min(N_LAYOUTS, envs_per_gpu * max(1, int(os.environ.get('WORLD_SIZE', '1'))))
-  if os.path.exists(cache):
-    z = np.load(cache)
-    rf, ri = z['rf'], z['ri']
-  else:
-    rf, ri = bu.sample_records(robot, task, n, seed=seed)
-    try:
-      os.makedirs(os.path.dirname(cache), exist_ok=True)
-      np.savez(cache + f'.{os.getpid()}.tmp.npz', rf=rf, ri=ri)
-      os.replace(cache + f'.{os.getpid()}.tmp.npz', cache)
-    except OSError:
-      pass
-  g = rank * envs_per_gpu + np.arange(envs_per_gpu)
-  idx = g % len(rf)
-  out_f, out_i = rf[idx].copy(), ri[idx].copy()
-  out_i[:, nat.I_ENV_ID] = g
-  return out_f, out_i
+  from safe_adaptation_gym_amd import benchmark
+  g0 = rank * envs_per_gpu
+  rf, ri, status = nat.sample_layouts(robot, seed + g0 + np.arange(envs_per_gpu, dtype=np.int64),
+                                      benchmark.TASKS[task].TASK_ID, env_id0=g0)
+  assert not status.any(), 'layout sampling failed'
+  return rf, ri
 
 
 class DeviceRun:
@@ -256,7 +243,7 @@ def main(argv=None, run_factory=None, emit=print):
       'data': 'synthetic',
       'config': {
           'workload': f'point/{args.task} full step() (5 substeps + contact + reward + cost + lidar + obs), '
-                      f'fixed layouts sampled with the reference sampler (seeds 666+i, {N_LAYOUTS} distinct, tiled), '
+                      f'one layout per env from the reference sampler semantics (env i <- RandomState(666 + i)), '
                       f'{args.envs} envs per GPU, counter-based actions U(-1,1) and noise 0.01 on device',
           'envs_per_gpu': args.envs,
           'global_envs': world * args.envs,

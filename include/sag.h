@@ -98,6 +98,7 @@ enum sag_rec_float {
   SAG_F_PILLARS = 65,     /* (x, y) * SAG_MAX_PILLARS                                 */
   SAG_F_BUTTONS = 69,     /* (x, y) * SAG_MAX_BUTTONS                                 */
   SAG_F_VASES = 81,       /* (x, y, yaw, vx, vy, w) * SAG_MAX_VASES                   */
+  SAG_F_BOUND = 141,      /* info['bound'] (world.py:75-78); carried, not used on the device */
   SAG_F_ROBOT_EXT = 144,  /* robot DoF beyond the planar base. car (car.xml:21-32): wheel rates left,
                            * right (rad/s about the axle); rear ball: angular velocity x,y,z
                            * (relative to the base, base frame); ball quaternion w,x,y,z           */
@@ -228,6 +229,30 @@ int sag_kernel_time_ms(sag_ctx* ctx, int32_t reset, double* mean_ms, int64_t* la
 int sag_enable_timing(sag_ctx* ctx, int32_t on);
 
 int sag_device_count(void);
+
+/* ---- native reset path ------------------------------------------------
+ * World.DEFAULT (world.py:17-34), the keys that influence sampling or the installed record. */
+typedef struct sag_world_config {
+  double placements_margin, robot_keepout, hazards_size, vases_size, pillars_size;
+  double hazards_keepout, vases_keepout, pillars_keepout;
+  double robot_ctrl_range_scale, action_noise, max_bound;
+  int32_t random_bound, reserved;
+} sag_world_config;
+void sag_world_config_default(sag_world_config* cfg);
+
+/* Replaces World.__init__ + sample_layout + _build_world_config + World.reset's host draws
+ * (world.py:36-137,172-217; tasks' setup_placements/build_world_config/reset) for n envs on the
+ * host cores.  Env j owns np.random.RandomState(seeds[j]) (exact legacy MT19937 stream, the
+ * reference's draw order) and yields record j of include/sag.h, env id env_id0 + j.
+ * first_episode != 0: the Task object is new (Cauchy ctrl-scale draw, world.py:72-73), else the
+ * World persists (safe_adaptation_gym.py:105-106).  mt_* (each may be NULL) return the generator
+ * after the draws (key [n][624], pos, has_gauss, gauss) so a parity harness can continue the
+ * same stream in numpy.  status[j] (may be NULL): 0 ok, <0 ResamplingError.  Returns the number
+ * of envs that failed, or a negative sag_status.  No GPU involved. */
+int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const int32_t* task_ids,
+                       const sag_world_config* cfg, int32_t first_episode, int32_t env_id0,
+                       float* rec_f, int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos,
+                       int32_t* mt_has_gauss, double* mt_gauss, int32_t* status, int32_t nthreads);
 
 #ifdef __cplusplus
 }

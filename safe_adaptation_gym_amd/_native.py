@@ -21,6 +21,7 @@ F_HAZARD_SIZE, F_VASE_SIZE, F_PILLAR_SIZE, F_KEEPOUT = 24, 25, 26, 27
 F_GOAL, F_CATCH, F_LAST, F_BOX = 32, 34, 38, 41
 F_HAZARDS, F_PILLARS, F_BUTTONS, F_VASES = 47, 65, 69, 81
 F_ROBOT_EXT = 144
+F_BOUND = 141
 (I_TASK, I_NH, I_NV, I_NP, I_NB, I_BOX_KIND, I_GOAL_BUTTON, I_BTN_STATE, I_BTN_TIMER,
  I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS) = range(14)
 
@@ -31,7 +32,7 @@ EXPORTS = [
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
     'sag_observe', 'sag_lidar_cost', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
     'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing',
-    'sag_device_count'
+    'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts'
 ]
 
 
@@ -44,6 +45,14 @@ class _Config(C.Structure):
               ('device', C.c_int32), ('max_hazards', C.c_int32), ('max_vases', C.c_int32),
               ('max_pillars', C.c_int32), ('max_buttons', C.c_int32), ('has_box', C.c_int32),
               ('reserved0', C.c_int32), ('seed', C.c_uint64)]
+
+
+class WorldConfig(C.Structure):
+  _fields_ = [(k, C.c_double) for k in ('placements_margin', 'robot_keepout', 'hazards_size',
+                                         'vases_size', 'pillars_size', 'hazards_keepout',
+                                         'vases_keepout', 'pillars_keepout',
+                                         'robot_ctrl_range_scale', 'action_noise', 'max_bound')] + [
+                                             ('random_bound', C.c_int32), ('reserved', C.c_int32)]
 
 
 _lib = None
@@ -82,6 +91,10 @@ def load():
   lib.sag_dev_fill_actions.argtypes = [vp, vp, C.c_uint32]
   lib.sag_kernel_time_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
   lib.sag_enable_timing.argtypes = [vp, C.c_int32]
+  lib.sag_world_config_default.argtypes = [C.POINTER(WorldConfig)]
+  lib.sag_world_config_default.restype = None
+  lib.sag_sample_layouts.argtypes = [C.c_int32, C.c_int32, up, ip, C.POINTER(WorldConfig), C.c_int32,
+                                     C.c_int32, fp, ip, up, ip, ip, C.POINTER(C.c_double), ip, C.c_int32]
   _lib = lib
   return lib
 
@@ -94,6 +107,45 @@ def robot_info(robot):
   if rc:
     raise SagError(f'sag_robot_info failed ({rc})')
   return dict(nu=out[0], obs_dim=out[1], nstep=out[2], nq=out[3], nv=out[4], dt=dt.value)
+
+
+def sample_layouts(robot, seeds, task_ids, config=None, first_episode=True, env_id0=0,
+                   want_rng=False, nthreads=None):
+  """Native reset path: records for len(seeds) envs, env j drawn with
+  np.random.RandomState(seeds[j]) semantics.  config: dict over World.DEFAULT keys.
+  Returns (rec_f, rec_i, status[, rng states as numpy RandomState set_state tuples])."""
+  lib = load()
+  seeds = np.ascontiguousarray(np.asarray(seeds, np.int64) % 2**32, np.uint32)
+  n = len(seeds)
+  tids = np.ascontiguousarray(np.broadcast_to(np.asarray(task_ids, np.int32), (n,)))
+  cfg = WorldConfig()
+  lib.sag_world_config_default(C.byref(cfg))
+  for k, v in (config or {}).items():
+    if k in ('gremlins_size', 'gremlins_keepout', 'gremlins_travel', 'obstacles_size_noise_scale'):
+      continue  # accepted by the reference, without effect (no task spawns gremlins)
+    if not hasattr(cfg, k):
+      raise KeyError(f'unknown world config key {k!r}')
+    setattr(cfg, k, int(v) if k == 'random_bound' else float(v))
+  rf = np.zeros((n, REC_FLOATS), np.float32)
+  ri = np.zeros((n, REC_INTS), np.int32)
+  status = np.zeros(n, np.int32)
+  key = np.zeros((n, 624), np.uint32) if want_rng else None
+  pos = np.zeros(n, np.int32) if want_rng else None
+  hg = np.zeros(n, np.int32) if want_rng else None
+  g = np.zeros(n, np.float64) if want_rng else None
+  if nthreads is None:
+    nthreads = min(len(os.sched_getaffinity(0)), 16)
+  rc = lib.sag_sample_layouts(ROBOT_IDS[robot] if isinstance(robot, str) else robot, n,
+                              _ptr(seeds, C.c_uint32), _ptr(tids, C.c_int32), C.byref(cfg),
+                              int(first_episode), env_id0, _ptr(rf, C.c_float), _ptr(ri, C.c_int32),
+                              _ptr(key, C.c_uint32), _ptr(pos, C.c_int32), _ptr(hg, C.c_int32),
+                              _ptr(g, C.c_double), _ptr(status, C.c_int32), nthreads)
+  if rc < 0:
+    raise SagError(f'sag_sample_layouts failed ({rc})')
+  if want_rng:
+    states = [('MT19937', key[j], int(pos[j]), int(hg[j]), float(g[j])) for j in range(n)]
+    return rf, ri, status, states
+  return rf, ri, status
 
 
 def device_count():

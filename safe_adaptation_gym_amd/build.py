@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsag.so')
-SOURCES = ['sag_api.hip']
+SOURCES = ['sag_api.hip', 'sag_sampler.cpp']
 HEADERS = ['sag_device.hpp', os.path.join('..', '..', 'include', 'sag.h')]
 
 
@@ -31,7 +31,7 @@ def build(force=False, verbose=False, extra=()):
     return LIB
   cmd = [
       hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
-      '-fno-fast-math', '-ffp-contract=off', '-Wall', '-Wno-unused-function', *extra, '-o', LIB
+      '-fno-fast-math', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-pthread', *extra, '-o', LIB
   ] + [os.path.join(CSRC, s) for s in SOURCES]
   if verbose:
     print(' '.join(cmd))

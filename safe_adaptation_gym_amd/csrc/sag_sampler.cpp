@@ -1,0 +1,309 @@
+// sag_sampler.cpp - native reset path: what the reference does at World construction and
+// reset time (world.py:36-137,172-217; tasks' setup_placements / build_world_config / reset),
+// for a batch of environments on the host cores.
+//
+// Every environment owns one generator with the exact stream of numpy's legacy
+// `np.random.RandomState(seed)` (MT19937, init_genrand seeding, 53-bit random_sample, polar
+// gauss with its cache, masked-rejection bounded integers), and the draws happen in the
+// reference's order, so a seed gives the reference's layout bit for bit
+// (pinned by tests/golden/resets.json.gz).  The Python World in world.py implements the same
+// logic with numpy itself; this file exists because a Python loop needs 3.6 ms per env.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/sag.h"
+
+namespace {
+
+// ---- numpy legacy RandomState --------------------------------------------------------
+struct MT {
+  uint32_t key[624];
+  int pos;
+  int has_gauss;
+  double gauss;
+
+  void seed(uint32_t s) {  // mt19937_seed (init_genrand)
+    for (int i = 0; i < 624; i++) {
+      key[i] = s;
+      s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
+    }
+    pos = 624; has_gauss = 0; gauss = 0.0;
+  }
+  void gen() {
+    const uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, MAT = 0x9908b0dfu;
+    int i;
+    uint32_t y;
+    for (i = 0; i < 624 - 397; i++) {
+      y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+      key[i] = key[i + 397] ^ (y >> 1) ^ ((y & 1) ? MAT : 0u);
+    }
+    for (; i < 623; i++) {
+      y = (key[i] & UPPER) | (key[i + 1] & LOWER);
+      key[i] = key[i + (397 - 624)] ^ (y >> 1) ^ ((y & 1) ? MAT : 0u);
+    }
+    y = (key[623] & UPPER) | (key[0] & LOWER);
+    key[623] = key[396] ^ (y >> 1) ^ ((y & 1) ? MAT : 0u);
+    pos = 0;
+  }
+  uint32_t next32() {
+    if (pos == 624) gen();
+    uint32_t y = key[pos++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  }
+  double sample() {  // random_sample
+    uint32_t a = next32() >> 5, b = next32() >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+  }
+  double uniform(double lo, double hi) { return lo + (hi - lo) * sample(); }
+  double legacy_gauss() {
+    if (has_gauss) { has_gauss = 0; double t = gauss; gauss = 0.0; return t; }
+    double f, x1, x2, r2;
+    do {
+      x1 = 2.0 * sample() - 1.0;
+      x2 = 2.0 * sample() - 1.0;
+      r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = std::sqrt(-2.0 * std::log(r2) / r2);
+    gauss = f * x1; has_gauss = 1;
+    return f * x2;
+  }
+  double standard_cauchy() {  // legacy_gauss() / legacy_gauss(), numerator drawn first
+    double a = legacy_gauss();
+    double b = legacy_gauss();
+    return a / b;
+  }
+  uint32_t bounded(uint32_t max) {  // masked rejection, values in [0, max]
+    if (max == 0) return 0;
+    uint32_t mask = max;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    while ((v = (next32() & mask)) > max) {}
+    return v;
+  }
+};
+
+// ---- task tables (tasks/*.py: obstacles, placement_extents, setup_placements) ----------------
+struct TaskDef {
+  int nH, nV, nP;
+  double ext;        // placement_extents = (-ext, -ext, ext, ext)
+  bool goal;
+  int box_kind;      // enum sag_box_kind
+  double box_keepout;
+  double box_rect;   // > 0: fixed rectangle (+-rect) for the box (PushBoxScarce), else the extents
+  bool box_yaw;      // build_world_config draws a yaw for the box
+  int nB;
+  double btn_rect;
+  double gear, damp;
+};
+
+const TaskDef TASKS[SAG_NUM_TASKS] = {
+    /* catch_goal           */ {9, 10, 1, 2.0, true, 0, 0, 0, false, 0, 0, 0.3, 0.01},
+    /* collect              */ {6, 8, 0, 2.25, false, 0, 0, 0, false, 6, 1.5, 0.3, 0.01},
+    /* dribble_ball         */ {2, 3, 1, 1.75, true, SAG_BOX_BALL, 0.2, 0, false, 0, 0, 0.3, 0.01},
+    /* go_to_goal           */ {9, 10, 1, 2.0, true, 0, 0, 0, false, 0, 0, 0.3, 0.01},
+    /* go_to_goal_damping   */ {9, 10, 1, 2.0, true, 0, 0, 0, false, 0, 0, 0.3, 0.001},
+    /* go_to_goal_motor     */ {9, 10, 1, 2.0, true, 0, 0, 0, false, 0, 0, 3.0, 0.01},
+    /* go_to_goal_scarce    */ {9, 10, 1, 2.0, true, 0, 0, 0, false, 0, 0, 0.3, 0.01},
+    /* haul_box             */ {2, 3, 1, 1.75, true, SAG_BOX_BOX, 0.5, 0, true, 0, 0, 0.3, 0.01},
+    /* press_buttons        */ {6, 8, 0, 2.0, false, 0, 0, 0, false, 4, 1.35, 0.3, 0.01},
+    /* press_buttons_scarce */ {6, 8, 0, 2.0, false, 0, 0, 0, false, 4, 1.75, 0.3, 0.01},
+    /* push_box             */ {2, 3, 1, 1.75, true, SAG_BOX_BOX, 0.5, 0, true, 0, 0, 0.3, 0.01},
+    /* push_box_scarce      */ {2, 3, 1, 1.75, true, SAG_BOX_BOX, 0.55, 2.25, true, 0, 0, 0.3, 0.01},
+    /* roll_rod             */ {2, 3, 1, 1.75, true, SAG_BOX_ROD, 0.7, 0, false, 0, 0, 0.3, 0.01},
+    /* unsupervised         */ {5, 6, 1, 2.0, true, 0, 0, 0, false, 0, 0, 0.3, 0.01},
+};
+
+constexpr double GOAL_KEEPOUT = 0.4, GOAL_RECT = 1.5, BUTTONS_KEEPOUT = 0.2;
+constexpr int MAX_ITEMS = 1 + SAG_MAX_HAZARDS + SAG_MAX_VASES + SAG_MAX_PILLARS + 2 + SAG_MAX_BUTTONS;
+
+struct Item {
+  double x, y, keepout;
+  double rect;   // > 0: own rectangle +-rect; 0: the task extents
+  int kind;      // 0 robot 1 hazard 2 vase 3 pillar 4 goal 5 box 6 button
+};
+
+// utils.draw_placement with one rectangle (no task has several): two uniforms
+inline void draw_xy(MT& rs, double half, double keepout, double& x, double& y) {
+  const double lo = -half + keepout, hi = half - keepout;
+  x = rs.uniform(lo, hi);
+  y = rs.uniform(lo, hi);
+}
+
+// World._sample_layout (world.py:191-217)
+bool try_layout(MT& rs, Item* it, int n, double ext, double margin) {
+  for (int k = 0; k < n; k++) {
+    bool placed = false;
+    for (int t = 0; t < 1000 && !placed; t++) {
+      double x, y;
+      draw_xy(rs, it[k].rect > 0 ? it[k].rect : ext, it[k].keepout, x, y);
+      bool ok = true;
+      for (int j = 0; j < k && ok; j++) {
+        const double dx = x - it[j].x, dy = y - it[j].y;
+        if (std::sqrt(dx * dx + dy * dy) < it[j].keepout + margin + it[k].keepout) ok = false;
+      }
+      if (ok) { it[k].x = x; it[k].y = y; placed = true; }
+    }
+    if (!placed) return false;
+  }
+  return true;
+}
+
+int sample_one(int robot, int task_id, uint32_t seed, const sag_world_config& cfg, int first_episode,
+               int env_id, float* rf, int32_t* ri, MT& rs) {
+  const TaskDef& T = TASKS[task_id];
+  const int nu = robot == SAG_ROBOT_DOGGO ? 12 : 2;
+  rs.seed(seed);
+  // World.__init__ (world.py:72-76): Cauchy ctrl scale, once per Task instance
+  double ctrl_scale[SAG_MAX_NU];
+  for (int k = 0; k < SAG_MAX_NU; k++) ctrl_scale[k] = 1.0;
+  if (first_episode) {
+    for (int k = 0; k < nu; k++) ctrl_scale[k] = rs.standard_cauchy() * cfg.robot_ctrl_range_scale + 1.0;
+  }
+  double bound = cfg.max_bound;
+  if (first_episode && cfg.random_bound) bound = rs.uniform(0.0, cfg.max_bound);
+  const double margin = cfg.placements_margin + (robot == SAG_ROBOT_DOGGO ? 0.165 : 0.0);
+  const double k_haz = std::fmax(cfg.hazards_keepout, cfg.hazards_size),
+               k_vase = std::fmax(cfg.vases_keepout, cfg.vases_size),
+               k_pil = std::fmax(cfg.pillars_keepout, cfg.pillars_size);
+  // placements in the reference's dict order: robot, hazards, vases, pillars, task bodies
+  Item it[MAX_ITEMS];
+  int n = 0;
+  it[n++] = {0, 0, cfg.robot_keepout, 0, 0};
+  for (int k = 0; k < T.nH; k++) it[n++] = {0, 0, k_haz, 0, 1};
+  for (int k = 0; k < T.nV; k++) it[n++] = {0, 0, k_vase, 0, 2};
+  for (int k = 0; k < T.nP; k++) it[n++] = {0, 0, k_pil, 0, 3};
+  int i_goal = -1, i_box = -1, i_btn = -1;
+  if (T.goal) { i_goal = n; it[n++] = {0, 0, GOAL_KEEPOUT, GOAL_RECT, 4}; }
+  if (T.box_kind) { i_box = n; it[n++] = {0, 0, T.box_keepout, T.box_rect, 5}; }
+  if (T.nB) { i_btn = n; for (int k = 0; k < T.nB; k++) it[n++] = {0, 0, BUTTONS_KEEPOUT, T.btn_rect, 6}; }
+  bool ok = false;
+  for (int a = 0; a < 10000 && !ok; a++) ok = try_layout(rs, it, n, T.ext, margin);
+  if (!ok) return -1;  // ResamplingError
+  // _build_world_config (world.py:108-137): yaw draws
+  const double two_pi = 2 * 3.14159265358979323846;
+  const double robot_rot = rs.uniform(0, two_pi);
+  double yaw[MAX_ITEMS];
+  for (int k = 0; k < n; k++) yaw[k] = 0;
+  for (int k = 1; k < n; k++)
+    if (it[k].kind >= 1 && it[k].kind <= 3) yaw[k] = rs.uniform(0, two_pi);
+  if (task_id == SAG_TASK_HAUL_BOX) {  // haul_box.py:17-18: box 3 box sizes ahead (world +x)
+    it[i_box].x = it[0].x + 0.2 * 3.0;
+    it[i_box].y = it[0].y;
+  }
+  if (i_goal >= 0) yaw[i_goal] = rs.uniform(0, two_pi);
+  if (i_box >= 0 && T.box_yaw) yaw[i_box] = rs.uniform(0, two_pi);
+  for (int k = 0; k < T.nB; k++) yaw[i_btn + k] = rs.uniform(0, two_pi);
+  // task.reset (App. B.5)
+  int goal_button = 0, btn_timer = 0;
+  uint32_t active_mask = 0;
+  if (i_goal >= 0) {  // GoToGoal._resample_goal_position (go_to_goal.py:59-80)
+    double half = GOAL_RECT;
+    bool found = false;
+    for (int t = 0; t < 10000 && !found; t++) {
+      double gx, gy;
+      draw_xy(rs, half, GOAL_KEEPOUT, gx, gy);
+      bool good = true;
+      for (int j = 0; j < n && good; j++) {
+        if (j == i_goal) continue;
+        const double dx = gx - it[j].x, dy = gy - it[j].y;
+        if (std::sqrt(dx * dx + dy * dy) < it[j].keepout + GOAL_KEEPOUT) good = false;
+      }
+      if (good) { it[i_goal].x = gx; it[i_goal].y = gy; found = true; }
+      else half *= 1.01;
+    }
+    if (!found) return -2;
+  }
+  if (task_id == SAG_TASK_PRESS_BUTTONS || task_id == SAG_TASK_PRESS_BUTTONS_SCARCE) {
+    goal_button = (int)rs.bounded(3);  // rs.choice(4)
+    btn_timer = 5;
+  }
+  if (task_id == SAG_TASK_COLLECT) active_mask = (1u << T.nB) - 1;
+  // ---- record (same as World.record) -------------------------------------------------------
+  for (int k = 0; k < SAG_REC_FLOATS; k++) rf[k] = 0.f;
+  for (int k = 0; k < SAG_REC_INTS; k++) ri[k] = 0;
+  ri[SAG_I_TASK] = task_id; ri[SAG_I_NH] = T.nH; ri[SAG_I_NV] = T.nV; ri[SAG_I_NP] = T.nP;
+  ri[SAG_I_NB] = T.nB; ri[SAG_I_BOX_KIND] = T.box_kind; ri[SAG_I_ENV_ID] = env_id;
+  ri[SAG_I_GOAL_BUTTON] = goal_button; ri[SAG_I_BTN_STATE] = 1; ri[SAG_I_BTN_TIMER] = btn_timer;
+  ri[SAG_I_ACTIVE_MASK] = (int32_t)active_mask;
+  rf[SAG_F_ROBOT] = (float)it[0].x; rf[SAG_F_ROBOT + 1] = (float)it[0].y; rf[SAG_F_ROBOT + 2] = (float)robot_rot;
+  for (int k = 0; k < 3; k++) rf[SAG_F_ROBOT0 + k] = rf[SAG_F_ROBOT + k];
+  rf[SAG_F_ROBOT_EXT + 5] = 1.0f;
+  rf[SAG_F_GEAR] = (float)T.gear; rf[SAG_F_DAMP] = (float)T.damp;
+  rf[SAG_F_ACTION_NOISE] = (float)cfg.action_noise;
+  for (int k = 0; k < SAG_MAX_NU; k++) rf[SAG_F_CTRL_SCALE + k] = (float)ctrl_scale[k];
+  rf[SAG_F_HAZARD_SIZE] = (float)cfg.hazards_size; rf[SAG_F_VASE_SIZE] = (float)cfg.vases_size;
+  rf[SAG_F_PILLAR_SIZE] = (float)cfg.pillars_size;
+  rf[SAG_F_KEEPOUT] = (float)cfg.robot_keepout; rf[SAG_F_KEEPOUT + 1] = (float)k_haz;
+  rf[SAG_F_KEEPOUT + 2] = (float)k_vase; rf[SAG_F_KEEPOUT + 3] = (float)k_pil;
+  rf[SAG_F_KEEPOUT + 4] = (float)T.box_keepout;
+  rf[SAG_F_CATCH + 2] = 1.0f; rf[SAG_F_CATCH + 3] = 0.2f;
+  rf[SAG_F_BOUND] = (float)bound;
+  int h = 0, v = 0, p = 0, b = 0;
+  for (int k = 1; k < n; k++) {
+    const float x = (float)it[k].x, y = (float)it[k].y;
+    switch (it[k].kind) {
+      case 1: rf[SAG_F_HAZARDS + 2 * h] = x; rf[SAG_F_HAZARDS + 2 * h + 1] = y; h++; break;
+      case 2: rf[SAG_F_VASES + 6 * v] = x; rf[SAG_F_VASES + 6 * v + 1] = y; rf[SAG_F_VASES + 6 * v + 2] = (float)yaw[k]; v++; break;
+      case 3: rf[SAG_F_PILLARS + 2 * p] = x; rf[SAG_F_PILLARS + 2 * p + 1] = y; p++; break;
+      case 4:
+        rf[SAG_F_GOAL] = x; rf[SAG_F_GOAL + 1] = y;
+        if (task_id == SAG_TASK_CATCH_GOAL) { rf[SAG_F_CATCH] = x; rf[SAG_F_CATCH + 1] = y; }
+        break;
+      case 5: rf[SAG_F_BOX] = x; rf[SAG_F_BOX + 1] = y; rf[SAG_F_BOX + 2] = (float)yaw[k]; break;
+      case 6: rf[SAG_F_BUTTONS + 2 * b] = x; rf[SAG_F_BUTTONS + 2 * b + 1] = y; b++; break;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sag_world_config_default(sag_world_config* c) {
+  // World.DEFAULT (world.py:17-34)
+  c->placements_margin = 0.0; c->robot_keepout = 0.4; c->hazards_size = 0.2; c->vases_size = 0.1;
+  c->pillars_size = 0.2; c->hazards_keepout = 0.18; c->vases_keepout = 0.15; c->pillars_keepout = 0.3;
+  c->robot_ctrl_range_scale = 0.0; c->action_noise = 0.01; c->max_bound = 25.0; c->random_bound = 0;
+  c->reserved = 0;
+}
+
+int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const int32_t* task_ids,
+                       const sag_world_config* cfg, int32_t first_episode, int32_t env_id0, float* rec_f,
+                       int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos, int32_t* mt_has_gauss,
+                       double* mt_gauss, int32_t* status, int32_t nthreads) {
+  if (robot < 0 || robot > 2 || n <= 0 || !seeds || !task_ids || !rec_f || !rec_i) return SAG_ERR_ARG;
+  for (int i = 0; i < n; i++)
+    if (task_ids[i] < 0 || task_ids[i] >= SAG_NUM_TASKS) return SAG_ERR_ARG;
+  sag_world_config c;
+  if (cfg) c = *cfg; else sag_world_config_default(&c);
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n;
+  std::vector<int> fails(nthreads, 0);
+  auto work = [&](int t) {
+    MT rs;
+    for (int i = t; i < n; i += nthreads) {
+      int rc = sample_one(robot, task_ids[i], seeds[i], c, first_episode, env_id0 + i,
+                          rec_f + (size_t)i * SAG_REC_FLOATS, rec_i + (size_t)i * SAG_REC_INTS, rs);
+      if (status) status[i] = rc;
+      if (rc) fails[t]++;
+      if (mt_key) std::memcpy(mt_key + (size_t)i * 624, rs.key, sizeof(rs.key));
+      if (mt_pos) mt_pos[i] = rs.pos;
+      if (mt_has_gauss) mt_has_gauss[i] = rs.has_gauss;
+      if (mt_gauss) mt_gauss[i] = rs.gauss;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  int nf = 0;
+  for (int f : fails) nf += f;
+  return nf;  // number of envs whose sampling failed (ResamplingError), 0 = all good
+}
+
+}  // extern "C"

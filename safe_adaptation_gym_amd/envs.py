@@ -11,6 +11,7 @@ import numpy as np
 from safe_adaptation_gym_amd import _native as nat
 from safe_adaptation_gym_amd.robot import Robot
 from safe_adaptation_gym_amd.tasks.task import Task
+from safe_adaptation_gym_amd.utils import ResamplingError
 from safe_adaptation_gym_amd.world import World
 
 TAPE_WORDS = 1024  # raw generator words offered to the device per env per step (parity mode)
@@ -66,7 +67,7 @@ class BatchedSafeAdaptationGym:
         for (s, e), d in zip(self._ranges, self.devices)
     ]
     self._pool = ThreadPoolExecutor(len(self._ctx)) if len(self._ctx) > 1 else None
-    self._worlds = [None] * self.n_envs
+    self._tasks = None
     self._episode = 0
     self._base_seed = int(np.random.randint(2**31))
     self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
@@ -92,22 +93,19 @@ class BatchedSafeAdaptationGym:
     self._base_seed = int(np.random.randint(2**31)) if seed is None else int(seed)
     self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
     self.rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
-    for w, rs in zip(self._worlds, self.rs):
-      if w is not None:
-        w.rs = rs
 
   def set_task(self, task):
     """A Task instance / class (every env gets its own instance of that class) or a
     sequence of n_envs instances (heterogeneous batch)."""
-    tasks = self._expand_tasks(task)
-    self._worlds = [
-        World(rs, t, self.robot, self.base_config) for rs, t in zip(self.rs, tasks)
-    ]
-    self._reward_dim = max(t.REWARD_DIM for t in tasks)
-    self._build_world()
+    self._tasks = self._expand_tasks(task)
+    World(np.random.RandomState(0), self._tasks[0], self.robot, self.base_config)  # validates config keys
+    self._task_ids = np.array([t.TASK_ID for t in self._tasks], np.int32)
+    self._reward_dim = max(t.REWARD_DIM for t in self._tasks)
+    self._persist = None  # task attributes that outlive an episode (filled by _pull_task_state)
+    self._build_world(first_episode=True)
 
   def reset(self, *, seed=None, return_info=False, options=None):
-    assert self._worlds[0] is not None or (options is not None and 'task' in options), (
+    assert self._tasks is not None or (options is not None and 'task' in options), (
         'A task should be first set before reset.')
     if seed is not None:
       self._seeds = int(seed) + np.arange(self.n_envs, dtype=np.int64)
@@ -120,9 +118,7 @@ class BatchedSafeAdaptationGym:
       self.set_task(options['task'])
       return self._observe()
     self._pull_task_state()
-    for w, rs in zip(self._worlds, self.rs):
-      w.rs = rs
-    self._build_world()
+    self._build_world(first_episode=False)
     return self._observe()
 
   def step(self, action):
@@ -184,14 +180,30 @@ class BatchedSafeAdaptationGym:
       return [fn(c, s, e) for c, (s, e) in jobs]
     return list(self._pool.map(lambda j: fn(j[0], j[1][0], j[1][1]), jobs))
 
-  def _build_world(self):
-    rf = np.zeros((self.n_envs, nat.REC_FLOATS), np.float32)
-    ri = np.zeros((self.n_envs, nat.REC_INTS), np.int32)
-    for i, w in enumerate(self._worlds):
-      w.sample_layout()
-      w.reset()
-      rf[i], ri[i] = w.record(env_id=i)
-    self._bounds = np.array([w.bound for w in self._worlds], np.float32)
+  def _build_world(self, first_episode):
+    """World.sample_layout + World.reset for every env (safe_adaptation_gym.py:170-172) on the
+    native sampler: env i draws from RandomState(seed_i) in the reference's order."""
+    rf, ri, status, states = nat.sample_layouts(self.robot.name, self._seeds, self._task_ids,
+                                                config=self.base_config, first_episode=first_episode,
+                                                want_rng=True)
+    if status.any():
+      bad = np.flatnonzero(status)
+      raise ResamplingError(f'Failed to generate layout for envs {bad[:8].tolist()} (seeds '
+                            f'{self._seeds[bad[:8]].tolist()})')
+    if self.parity_rng:  # continue the same streams on the host (noise, in-step draws)
+      for rs, st in zip(self.rs, states):
+        rs.set_state(st)
+    cs = slice(nat.F_CTRL_SCALE, nat.F_CTRL_SCALE + nat.MAX_NU)
+    if first_episode:  # drawn once per Task object (tasks/task.py:85-94), kept across resets
+      self._ctrl_scale, self._bound0 = rf[:, cs].copy(), rf[:, nat.F_BOUND].copy()
+    else:
+      rf[:, cs], rf[:, nat.F_BOUND] = self._ctrl_scale, self._bound0
+    if self._persist is not None:
+      ri[:, nat.I_BTN_STATE] = self._persist['btn_state']
+      ri[:, nat.I_CATCH_TIMER] = self._persist['catch_timer']
+      rf[:, nat.F_CATCH + 2] = self._persist['catch_cur']
+      rf[:, nat.F_CATCH + 3] = self._persist['catch_next']
+    self._bounds = rf[:, nat.F_BOUND].copy()
     self._map(lambda c, s, e: c.set_layout(rf[s:e], ri[s:e]))
 
   def _pull_task_state(self):
@@ -199,12 +211,12 @@ class BatchedSafeAdaptationGym:
     the Task object, not in the simulator: PressButtons._state (press_buttons.py:23),
     CatchGoal radii and timer (catch_goal.py:14-18)."""
     rf, ri = self.get_state()
-    for i, w in enumerate(self._worlds):
-      st = w.task_state
-      st['btn_state'] = int(ri[i, nat.I_BTN_STATE])
-      st['catch_timer'] = int(ri[i, nat.I_CATCH_TIMER])
-      st['catch_cur'] = float(rf[i, nat.F_CATCH + 2])
-      st['catch_next'] = float(rf[i, nat.F_CATCH + 3])
+    self._persist = {
+        'btn_state': ri[:, nat.I_BTN_STATE].copy(),
+        'catch_timer': ri[:, nat.I_CATCH_TIMER].copy(),
+        'catch_cur': rf[:, nat.F_CATCH + 2].copy(),
+        'catch_next': rf[:, nat.F_CATCH + 3].copy(),
+    }
 
   def _observe(self):
     return np.concatenate(self._map(lambda c, s, e: c.observe()))

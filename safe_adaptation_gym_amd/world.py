@@ -121,6 +121,7 @@ class World:
     rf[nat.F_ROBOT + 2] = self.robot_rot
     rf[nat.F_ROBOT0:nat.F_ROBOT0 + 3] = rf[nat.F_ROBOT:nat.F_ROBOT + 3]
     rf[nat.F_ROBOT_EXT + 5] = 1.0  # car: rear ball quaternion (w, x, y, z) = identity
+    rf[nat.F_BOUND] = self.bound
     rf[nat.F_GEAR], rf[nat.F_DAMP] = t.GEAR, t.DAMPING
     rf[nat.F_ACTION_NOISE] = cfg.action_noise
     rf[nat.F_CTRL_SCALE:nat.F_CTRL_SCALE + nat.MAX_NU] = 1.0
