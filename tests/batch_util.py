@@ -8,6 +8,17 @@ from safe_adaptation_gym_amd.robot import Robot
 from safe_adaptation_gym_amd.world import World
 
 
+def sample_records_native(robot_name, task_names, n, seed=666, config=None):
+  """Same through the native sampler; task_names may be one name or a per-env list."""
+  if isinstance(task_names, str):
+    tids = benchmark.TASKS[task_names].TASK_ID
+  else:
+    tids = np.array([benchmark.TASKS[t].TASK_ID for t in task_names], np.int32)
+  rf, ri, st = nat.sample_layouts(robot_name, seed + np.arange(n), tids, config=config)
+  assert not st.any()
+  return rf, ri
+
+
 def sample_records(robot_name, task_name, n, seed=666, config=None):
   """n records: env i sampled with RandomState(seed + i) exactly as make() would."""
   robot = Robot(f'xmls/{robot_name}.xml')
