@@ -9,6 +9,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -56,6 +57,8 @@ struct sag_ctx {
   size_t ev_used = 0;
   double ev_ms = 0; int64_t ev_n = 0;
   bool timing = false;
+  int phase = 0;       // busy-bit copy read by the next step launch
+  bool split = true;   // QUIET + BUSY launches (SAG_SPLIT=0 in the environment selects the single form)
   std::string err;
 };
 
@@ -124,8 +127,9 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   a.has_box = c->cfg.has_box; a.G = c->G;
+  a.phase = c->phase;
+  if (!observe_only) c->phase ^= 1;
   const int blocks = (c->N + WAVE - 1) / WAVE;
-  const size_t lds = 0;  // static __shared__ in the kernel
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing && !observe_only) {
     if (c->ev_used == c->ev_pool.size()) {
@@ -144,16 +148,30 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
   const bool btn = c->cfg.max_buttons > 0, tbox = c->cfg.has_box != 0;
-#define SAG_LAUNCH(ROB)                                                                               \
-  do {                                                                                                \
-    if (!btn && !tbox) hipLaunchKernelGGL((k_step<ROB, false, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a); \
-    else if (btn && !tbox) hipLaunchKernelGGL((k_step<ROB, true, false>), dim3(blocks), dim3(WAVE), lds, c->stream, a); \
-    else if (!btn && tbox) hipLaunchKernelGGL((k_step<ROB, false, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a); \
-    else hipLaunchKernelGGL((k_step<ROB, true, true>), dim3(blocks), dim3(WAVE), lds, c->stream, a);   \
+  const int bblocks = (c->N + BUSY_NBH - 1) / BUSY_NBH;
+  // split form: QUIET kernel over every env whose busy bit is clear, then BUSY kernel over the
+  // rest (compacted per 256-env neighbourhood).  observe() and SAG_SPLIT=0 use the single form.
+  const bool split = c->split && !observe_only;
+#define SAG_LAUNCH3(ROB, B_, X_)                                                                         \
+  do {                                                                                                  \
+    if (split) {                                                                                        \
+      hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);       \
+      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3(bblocks), dim3(WAVE), 0, c->stream, a);       \
+    } else {                                                                                            \
+      hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);             \
+    }                                                                                                   \
+  } while (0)
+#define SAG_LAUNCH(ROB)                            \
+  do {                                             \
+    if (!btn && !tbox) SAG_LAUNCH3(ROB, false, false); \
+    else if (btn && !tbox) SAG_LAUNCH3(ROB, true, false); \
+    else if (!btn && tbox) SAG_LAUNCH3(ROB, false, true); \
+    else SAG_LAUNCH3(ROB, true, true);             \
   } while (0)
   if (c->cfg.robot == SAG_ROBOT_POINT) SAG_LAUNCH(SAG_ROBOT_POINT);
   else SAG_LAUNCH(SAG_ROBOT_CAR);
 #undef SAG_LAUNCH
+#undef SAG_LAUNCH3
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -197,6 +215,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
     return fail(nullptr, SAG_ERR_NODEVICE, "device %d out of range (%d visible)", cfg->device, ndev);
   sag_ctx* c = new sag_ctx();
   c->cfg = *cfg; c->rb = ROBOTS[cfg->robot]; c->N = cfg->n_envs;
+  if (const char* e = getenv("SAG_SPLIT")) c->split = atoi(e) != 0;
   const size_t N = (size_t)c->N;
 #define CREATE_CHK(call)                                                                         \
   do {                                                                                           \

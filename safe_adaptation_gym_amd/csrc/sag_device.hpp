@@ -66,6 +66,7 @@ struct StepArgs {
   int32_t* tape_used;
   int32_t max_vases, max_hazards, max_pillars, max_buttons;  // context capacities (load bounds)
   int32_t has_box;
+  int32_t phase;          // which copy of the busy bit this launch reads (0 / 1)
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
 };
@@ -501,21 +502,33 @@ __device__ inline void lidar_point(float* lds, int lane, double rx, double ry, d
 // HAS_BTN / HAS_TBOX: compile-time knowledge that the context holds no buttons / no task object
 // (capacities of sag_create); the specialised instances drop those arrays, loops and the box
 // shapes altogether.  <true, true> serves mixed (multitask) batches.
-template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
-__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
+// MODE: how a launch covers the batch.
+//  ALL    every env of the wavefront's 64-env slice, full physics (single-launch form);
+//  QUIET  the envs whose `busy` bit is clear: nothing can touch the robot or move during this
+//         step (classified conservatively at the end of the previous step), so all contact code
+//         is compiled out: small, high-occupancy, close to the memory roofline;
+//  BUSY   the envs whose bit is set, compacted per 256-env neighbourhood into full wavefronts,
+//         full physics.  QUIET + BUSY together do exactly what ALL does (tests compare them).
+enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2 };
+// two copies of the busy bit, used alternately (StepArgs::phase): a launch reads bit 28 + phase and
+// writes bit 28 + (phase ^ 1), so the QUIET launch cannot re-flag an env for the BUSY launch of
+// the same step
+constexpr uint32_t TS_BUSY_BIT = 1u << 28;
+constexpr int BUSY_NBH = 256;  // envs per BUSY-mode wavefront (expected busy share ~ 1/4)
+
+template <int ROBOT, bool HAS_BTN, bool HAS_TBOX, int MODE>
+__device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const int lane, const int i,
+                                          const bool live, const int base_env, const int nvalid,
+                                          const uint64_t skip_mask, const int* rows) {
   constexpr int NSTAT = SAG_MAX_PILLARS + (HAS_BTN ? SAG_MAX_BUTTONS : 0);
   constexpr bool CAR = ROBOT == SAG_ROBOT_CAR;
+  constexpr bool QUIET = MODE == MODE_QUIET;
   constexpr int SH_ME = CAR ? SH_CAR : SH_ROBOT;
   constexpr int OBS_DIM = CAR ? 72 : 60, NSENS = OBS_DIM - 48;
   constexpr int STG_STRIDE = CAR ? 25 : 17;
   static_assert(STG_BASE + WAVE * STG_STRIDE <= LDS_FLOATS, "staging tile must fit");
   const float my_bound = shape_bound(SH_ME, 0.f, 0.f);
-  __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
-  const int lane = threadIdx.x;
   const int N = p.N;
-  const int gi = blockIdx.x * WAVE + lane;
-  const bool live = gi < N;
-  const int i = live ? gi : N - 1;  // idle lanes shadow the last env; they never store
   float* __restrict__ S = p.S;
   int32_t* __restrict__ I = p.I;
   const int capV = p.max_vases, capH = p.max_hazards, capP = p.max_pillars, capB = HAS_BTN ? p.max_buttons : 0;
@@ -670,6 +683,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
   const uint32_t fmask = ((1u << nV) - 1) | (has_box ? 1u << BOX_ID : 0u);
   uint32_t awake = (tstate >> TS_AWAKE_SHIFT) & fmask;
   Dyn dy; dy.lds = lds; dy.S = S; dy.G = p.G; dy.lane = lane; dy.N = N; dy.i = i; dy.dmap = 0; dy.ovf = 0; dy.nd = 0;
+  if constexpr (QUIET) awake = 0;  // a quiet env has no moving body (classification)
   for (uint32_t m = awake; m; m &= m - 1) dy.ensure(__ffs(m) - 1, true);
   uint32_t dirty = 0;  // bodies whose state changed during this step
   int cost_contacts = 0;
@@ -745,6 +759,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
       }
     }
     cost_contacts = 0; btn_mask = 0;
+    if constexpr (!QUIET) {
     // `active` = bodies that can have a non-zero acceleration or velocity this substep.
     // A sleeping body (v = 0, untouched) overlaps nothing, so every pair test it would take
     // part in is a no-op and is skipped; the pair ORDER of the specification is kept for the
@@ -921,6 +936,9 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
       }
       dirty |= active;
     }
+    } else {
+      if (sub == nsub) break;
+    }
     R.vx += h * R.ax; R.vy += h * R.ay; R.w += h * R.aw;
     R.x += h * R.vx; R.y += h * R.vy; yaw += h * R.w;
     if constexpr (CAR) {
@@ -963,6 +981,35 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
     I[(size_t)DI_STEP * N + i] = step;
   }
   tstate = (tstate & ~(TS_AWAKE_BITS << TS_AWAKE_SHIFT)) | (awake & TS_AWAKE_BITS) << TS_AWAKE_SHIFT;
+  // ---- classification for the NEXT step (QUIET / BUSY split): busy unless provably nothing can
+  //      touch the robot or move.  Reach of the robot within one step from the final state:
+  //      |v| T + a_max T^2 (drive + contact-free dynamics only raise |v| by at most a_max T)
+  if (!p.observe_only) {
+    const float T = p.nstep_table * h;
+    const float amax = CAR ? GRAV : 1.05f * gear * PT_FLIM / PT_MASS;
+    const float reach = sqrtf(R.vx * R.vx + R.vy * R.vy) * T + amax * T * T + 0.005f;
+    bool busy = awake != 0 || (HAS_TBOX && task == SAG_TASK_HAUL_BOX);
+    const float rr = my_bound + reach;
+#pragma unroll 1
+    for (int k = 0; k < nV; k++) {
+      const float dx = LP(LS_X, k) - R.x, dyy = LP(LS_Y, k) - R.y, rs = rr + vase_r;
+      busy |= dx * dx + dyy * dyy <= rs * rs;
+    }
+    if (has_box) {
+      const float dx = LP(LS_X, BOX_ID) - R.x, dyy = LP(LS_Y, BOX_ID) - R.y, rs = rr + box_r;
+      busy |= dx * dx + dyy * dyy <= rs * rs;
+    }
+#pragma unroll 1
+    for (int k = 0; k < n_static; k++) {
+      if (k == capP) k = SAG_MAX_PILLARS;
+      const bool is_p = k < SAG_MAX_PILLARS;
+      const bool on = is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB);
+      const float dx = stx[k] - R.x, dyy = sty[k] - R.y, rs = rr + (is_p ? psz : BUTTON_R);
+      busy |= on && dx * dx + dyy * dyy <= rs * rs;
+    }
+    const uint32_t nbit = TS_BUSY_BIT << (p.phase ^ 1);
+    tstate = busy ? (tstate | nbit) : (tstate & ~nbit);
+  }
 
   // hazards are only needed from here on (cost, lidar): loading them late keeps 18 registers
   // free during the physics; the reward arithmetic below covers the latency
@@ -1127,9 +1174,11 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
     const float cf = (float)cd, sf = (float)sd;
     const int gb = tstate & 7, bstate = tstate >> 3 & 1;
     const uint32_t act = tstate >> 11 & 63;
-    const int base_env = blockIdx.x * WAVE;
-    const int nvalid = min(WAVE, N - base_env);
-    float* __restrict__ o = p.obs + (size_t)base_env * OBS_DIM;
+    float* __restrict__ o = p.obs;
+    // row of staging slot e: contiguous slice (ALL / QUIET) or the compacted list (BUSY);
+    // slots of envs this launch does not own are skipped
+    auto row_ok = [&](int e) { return e < nvalid && !(skip_mask >> e & 1ull); };
+    auto row_of = [&](int e) { return (size_t)(MODE == MODE_BUSY ? rows[e] : base_env + e); };
     __syncthreads();  // physics is done with the yaw / pool slots everywhere in the wavefront
 #pragma unroll 1
     for (int chunk = 0; chunk < 4; chunk++) {
@@ -1188,7 +1237,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
         for (int j = 0; j < 16; j++) {
           const int e = j * WAVE + lane, env = e >> 4, col = e & 15;
           const float v = lds[STG_BASE + env * STG_STRIDE + col];
-          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * OBS_DIM + chunk * 16 + col] = v;
+          if (row_ok(env) && !ABL(ABL_NO_OBS_STORE)) o[row_of(env) * OBS_DIM + chunk * 16 + col] = v;
         }
       } else {
 #pragma unroll 4
@@ -1198,7 +1247,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
           const int env = (int)(((uint32_t)e * 43691u) >> (NSENS == 12 ? 19 : 20));
           const int col = e - env * NSENS;
           const float v = lds[STG_BASE + env * STG_STRIDE + col];
-          if (env < nvalid && !ABL(ABL_NO_OBS_STORE)) o[env * OBS_DIM + 48 + col] = v;
+          if (row_ok(env) && !ABL(ABL_NO_OBS_STORE)) o[row_of(env) * OBS_DIM + 48 + col] = v;
         }
       }
       __syncthreads();
@@ -1214,6 +1263,54 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
     if (p.done) p.done[i] = bad ? 1 : 0;
     if (p.goal_met) p.goal_met[i] = (uint8_t)met;
     if (p.tape_used) p.tape_used[i] = rng.pos;
+  }
+}
+
+// ---- the three launch forms ------------------------------------------------------------
+template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
+__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
+  __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
+  const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
+  const bool live = gi < p.N;
+  step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_ALL>(p, lds, lane, live ? gi : p.N - 1, live, base,
+                                                 min(WAVE, p.N - base), 0ull, nullptr);
+}
+
+template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
+__global__ __launch_bounds__(WAVE, 4) void k_step_quiet(StepArgs p) {
+  __shared__ float lds[LDS_FLOATS];
+  const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
+  const bool in = gi < p.N;
+  const bool busy = in && ((uint32_t)p.I[(size_t)DI_TSTATE * p.N + gi] & (TS_BUSY_BIT << p.phase));
+  const uint64_t skip = __ballot(busy || !in);
+  if (skip == ~0ull) return;  // wave-uniform: nothing quiet here
+  const bool live = in && !busy;
+  step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_QUIET>(p, lds, lane, in ? gi : p.N - 1, live, base,
+                                                   min(WAVE, p.N - base), skip, nullptr);
+}
+
+template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
+__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
+  __shared__ float lds[LDS_FLOATS];
+  __shared__ int rows[BUSY_NBH];
+  const int lane = threadIdx.x, nb0 = blockIdx.x * BUSY_NBH;
+  int count = 0;
+#pragma unroll
+  for (int j = 0; j < BUSY_NBH / WAVE; j++) {
+    const int e = nb0 + j * WAVE + lane;
+    const bool b = e < p.N && ((uint32_t)p.I[(size_t)DI_TSTATE * p.N + e] & (TS_BUSY_BIT << p.phase));
+    const uint64_t m = __ballot(b);
+    if (b) rows[count + __popcll(m & ((1ull << lane) - 1))] = e;
+    count += __popcll(m);
+  }
+  if (count == 0) return;
+  __syncthreads();
+  for (int c0 = 0; c0 < count; c0 += WAVE) {
+    const int nval = min(WAVE, count - c0);
+    const bool live = lane < nval;
+    step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_BUSY>(p, lds, lane, rows[c0 + (live ? lane : 0)], live, 0, nval,
+                                                    0ull, rows + c0);
+    __syncthreads();
   }
 }
 
@@ -1262,7 +1359,8 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
     }
   }
   I[(size_t)DI_META * N + i] = (int32_t)pack_meta(ri);
-  I[(size_t)DI_TSTATE * N + i] = (int32_t)(pack_tstate(ri) | awake << TS_AWAKE_SHIFT);
+  // the first step after an install runs in BUSY mode (nothing has been classified yet)
+  I[(size_t)DI_TSTATE * N + i] = (int32_t)(pack_tstate(ri) | awake << TS_AWAKE_SHIFT | TS_BUSY_BIT | TS_BUSY_BIT << 1);
   I[(size_t)DI_STEP * N + i] = ri[SAG_I_STEP];
   I[(size_t)DI_ENVID * N + i] = ri[SAG_I_ENV_ID];
   I[(size_t)DI_FLAGS * N + i] = ri[SAG_I_FLAGS];

@@ -353,6 +353,42 @@ def test_env_api_shapes_and_reference_surface(nat):
   env.close()
 
 
+@pytest.mark.parametrize('robot,task', [('point', 'go_to_goal'), ('point', MIXED), ('car', 'push_box'),
+                                        ('point', 'haul_box')])
+def test_split_launch_equals_single_launch(nat, monkeypatch, robot, task):
+  """QUIET + BUSY launches (envs classified at the end of the previous step) must reproduce the
+  single full-physics launch bit for bit: state, observations, rewards, flags, over a rollout
+  long enough for goals, contacts and resting bodies to occur."""
+  n, T = 1500, 120   # not a multiple of 64 nor of the 256-env neighbourhood
+  if task == MIXED:
+    from safe_adaptation_gym_amd import benchmark
+    names = [nm for nm, _ in benchmark.make('multitask', batch_size=n, seed=5).train_tasks]
+    rf, ri = bu.sample_records_native(robot, names, n, seed=4000)
+  else:
+    rf, ri = bu.sample_records_native(robot, task, n, seed=4000)
+  rf = bu.goal_beyond_box(rf, ri) if task != 'haul_box' else rf
+  ctxs = []
+  for flag in ('0', '1'):
+    monkeypatch.setenv('SAG_SPLIT', flag)
+    c = nat.Context(robot, n, seed=77)
+    c.set_layout(rf, ri)
+    ctxs.append(c)
+  rng = np.random.RandomState(3)
+  busy_share = []
+  for t in range(T):
+    s_rf, s_ri = ctxs[0].get_state()
+    act = bu.pursuit_actions(s_rf, s_ri, rng, robot=robot)
+    outs = [c.step(act) for c in ctxs]          # counter-based noise: same key, env id, step
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+      np.testing.assert_array_equal(a, b, err_msg=f'step {t}')
+    sa, sb = ctxs[0].get_state(), ctxs[1].get_state()
+    np.testing.assert_array_equal(sa[0], sb[0], err_msg=f'state step {t}')
+    np.testing.assert_array_equal(sa[1], sb[1])
+  assert outs[0][2].sum() > 0
+  for c in ctxs:
+    c.close()
+
+
 def test_car_env_api(nat):
   """BASELINE config 3 through the front end: Car / push_box, obs 72 (48 lidar + 12 + 3 + 9)."""
   import safe_adaptation_gym_amd as sag
