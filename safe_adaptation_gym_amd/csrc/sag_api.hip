@@ -39,6 +39,7 @@ struct sag_ctx {
   float* S = nullptr;
   int32_t* I = nullptr;
   float* G = nullptr;  // [3][NBODY][N] spill of body accelerations beyond the LDS pool
+  int32_t* d_rows = nullptr; int32_t* d_count = nullptr;  // compacted busy list (split launches)
   // last installed layout (sag_reset)
   float* L_f = nullptr;   // [N][SAG_REC_FLOATS] AoS, device
   int32_t* L_i = nullptr; // [N][SAG_REC_INTS]
@@ -127,7 +128,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   a.has_box = c->cfg.has_box; a.G = c->G;
-  a.phase = c->phase;
+  a.phase = c->phase; a.rows = c->d_rows; a.count = c->d_count;
   if (!observe_only) c->phase ^= 1;
   const int blocks = (c->N + WAVE - 1) / WAVE;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -148,15 +149,19 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
   const bool btn = c->cfg.max_buttons > 0, tbox = c->cfg.has_box != 0;
-  const int bblocks = (c->N + BUSY_NBH - 1) / BUSY_NBH;
   // split form: QUIET kernel over every env whose busy bit is clear, then BUSY kernel over the
   // rest (compacted per 256-env neighbourhood).  observe() and SAG_SPLIT=0 use the single form.
   const bool split = c->split && !observe_only;
+  if (split) {
+    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(int32_t), c->stream));
+    hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
+                       c->d_rows, c->d_count);
+  }
 #define SAG_LAUNCH3(ROB, B_, X_)                                                                         \
   do {                                                                                                  \
     if (split) {                                                                                        \
       hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);       \
-      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3(bblocks), dim3(WAVE), 0, c->stream, a);       \
+      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);        \
     } else {                                                                                            \
       hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);             \
     }                                                                                                   \
@@ -231,6 +236,8 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->S, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->I, N * DI_COUNT * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->d_rows, N * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->d_count, 4 * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->L_f, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->L_i, N * SAG_REC_INTS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->st_f, N * SAG_REC_FLOATS * sizeof(float)));
@@ -257,7 +264,7 @@ int sag_destroy(sag_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  void* bufs[] = {c->S, c->I, c->G, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
+  void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
                   c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);

@@ -67,6 +67,8 @@ struct StepArgs {
   int32_t max_vases, max_hazards, max_pillars, max_buttons;  // context capacities (load bounds)
   int32_t has_box;
   int32_t phase;          // which copy of the busy bit this launch reads (0 / 1)
+  int32_t* rows;          // [N] env ids of the busy envs, compacted (k_compact)
+  int32_t* count;         // number of entries in rows
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
 };
@@ -507,14 +509,12 @@ __device__ inline void lidar_point(float* lds, int lane, double rx, double ry, d
 //  QUIET  the envs whose `busy` bit is clear: nothing can touch the robot or move during this
 //         step (classified conservatively at the end of the previous step), so all contact code
 //         is compiled out: small, high-occupancy, close to the memory roofline;
-//  BUSY   the envs whose bit is set, compacted per 256-env neighbourhood into full wavefronts,
-//         full physics.  QUIET + BUSY together do exactly what ALL does (tests compare them).
+//  BUSY   the envs whose bit is set, compacted (k_compact) into full wavefronts, full physics.  QUIET + BUSY together do exactly what ALL does (tests compare them).
 enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2 };
 // two copies of the busy bit, used alternately (StepArgs::phase): a launch reads bit 28 + phase and
 // writes bit 28 + (phase ^ 1), so the QUIET launch cannot re-flag an env for the BUSY launch of
 // the same step
 constexpr uint32_t TS_BUSY_BIT = 1u << 28;
-constexpr int BUSY_NBH = 256;  // envs per BUSY-mode wavefront (expected busy share ~ 1/4)
 
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX, int MODE>
 __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const int lane, const int i,
@@ -1278,7 +1278,11 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
 
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, 4) void k_step_quiet(StepArgs p) {
-  __shared__ float lds[LDS_FLOATS];
+  // positions (x, y) of the free bodies + the observation staging tile; no dynamic pool:
+  // 10 KB (Point) -> 16 wavefronts per CU
+  constexpr int QSLOTS = LS_YAW + (ROBOT == SAG_ROBOT_CAR ? 25 : 17);
+  static_assert(QSLOTS >= LS_YAW + NBODY, "the yaw rows written at load time must stay in bounds");
+  __shared__ float lds[QSLOTS * WAVE];
   const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
   const bool in = gi < p.N;
   const bool busy = in && ((uint32_t)p.I[(size_t)DI_TSTATE * p.N + gi] & (TS_BUSY_BIT << p.phase));
@@ -1289,29 +1293,55 @@ __global__ __launch_bounds__(WAVE, 4) void k_step_quiet(StepArgs p) {
                                                    min(WAVE, p.N - base), skip, nullptr);
 }
 
+// busy envs -> dense list.  Each 256-thread block covers 1024 envs, orders its own busy ones by
+// index (ballot + prefix) and claims a contiguous segment with one atomic; segments of different
+// blocks land in arbitrary order, which only affects which wavefront processes an env.
+__global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int phase, int32_t* rows, int32_t* count) {
+  __shared__ int wave_tot[4][4];
+  __shared__ int seg_base;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int e0 = blockIdx.x * 1024 + wv * 256;
+  int pre[4];
+  bool b[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int e = e0 + j * WAVE + lane;
+    b[j] = e < N && ((uint32_t)I[(size_t)DI_TSTATE * N + e] & (TS_BUSY_BIT << phase));
+    const uint64_t m = __ballot(b[j]);
+    pre[j] = __popcll(m & ((1ull << lane) - 1));
+    if (lane == 0) wave_tot[wv][j] = __popcll(m);
+  }
+  __syncthreads();
+  int before = 0, total = 0;
+  for (int w = 0; w < 4; w++)
+    for (int j = 0; j < 4; j++) {
+      const int t = wave_tot[w][j];
+      if (w < wv) before += t;
+      total += t;
+    }
+  if (threadIdx.x == 0) seg_base = total ? atomicAdd(count, total) : 0;
+  __syncthreads();
+  int off = seg_base + before;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (b[j]) rows[off + pre[j]] = e0 + j * WAVE + lane;
+    off += wave_tot[wv][j];
+  }
+}
+
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
   __shared__ float lds[LDS_FLOATS];
-  __shared__ int rows[BUSY_NBH];
-  const int lane = threadIdx.x, nb0 = blockIdx.x * BUSY_NBH;
-  int count = 0;
-#pragma unroll
-  for (int j = 0; j < BUSY_NBH / WAVE; j++) {
-    const int e = nb0 + j * WAVE + lane;
-    const bool b = e < p.N && ((uint32_t)p.I[(size_t)DI_TSTATE * p.N + e] & (TS_BUSY_BIT << p.phase));
-    const uint64_t m = __ballot(b);
-    if (b) rows[count + __popcll(m & ((1ull << lane) - 1))] = e;
-    count += __popcll(m);
-  }
-  if (count == 0) return;
+  __shared__ int rows[WAVE];
+  const int lane = threadIdx.x, c0 = blockIdx.x * WAVE;
+  const int count = *p.count;
+  if (c0 >= count) return;
+  const int nval = min(WAVE, count - c0);
+  const bool live = lane < nval;
+  const int i = p.rows[c0 + (live ? lane : 0)];
+  rows[lane] = i;
   __syncthreads();
-  for (int c0 = 0; c0 < count; c0 += WAVE) {
-    const int nval = min(WAVE, count - c0);
-    const bool live = lane < nval;
-    step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_BUSY>(p, lds, lane, rows[c0 + (live ? lane : 0)], live, 0, nval,
-                                                    0ull, rows + c0);
-    __syncthreads();
-  }
+  step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_BUSY>(p, lds, lane, i, live, 0, nval, 0ull, rows);
 }
 
 // ---------------------------------------------------------------------------
