@@ -489,10 +489,12 @@ __device__ inline void lidar_point(float* lds, int lane, double rx, double ry, d
     bin = h.bin; alias = h.alias; sensor = h.sensor;
   }
   const int bp = (bin + 1) & 15, bm = (bin + 15) & 15;
-  float* o = &STG(0);
-  o[bin] = fmaxf(o[bin], sensor);
-  o[bp] = fmaxf(o[bp], alias * sensor);
-  o[bm] = fmaxf(o[bm], (1.0f - alias) * sensor);
+  // closeness values are >= +0, so their bit patterns order like the floats: LDS integer
+  // atomic max (ds_max_i32, no return value) replaces read-max-write and its round trips
+  int* o = reinterpret_cast<int*>(&STG(0));
+  atomicMax(o + bin, __float_as_int(sensor));
+  atomicMax(o + bp, __float_as_int(alias * sensor));
+  atomicMax(o + bm, __float_as_int((1.0f - alias) * sensor));
 }
 
 #ifndef SAG_STEP_MIN_WAVES
