@@ -102,6 +102,7 @@ class DeviceRun:
     cost = self.ctx.dev_download(self.d_cost, (self.envs,), np.uint8)
     done = self.ctx.dev_download(self.d_done, (self.envs,), np.uint8)
     obs = self.ctx.dev_download(self.d_obs, (min(self.envs, 4096) * self.ctx.info['obs_dim'],), np.float32)
+    self.met_rate = float(self.ctx.dev_download(self.d_met, (self.envs,), np.uint8).mean())
     return float(cost.mean()), int(done.sum()), bool(np.isfinite(obs).all())
 
   def close(self):
@@ -262,7 +263,8 @@ def main(argv=None, run_factory=None, emit=print):
           'launches_timed': k_n,
           'alg_bytes_per_env_step': ALG_BYTES_PER_ENV_STEP,
       },
-      'checks': {'cost_rate_last_step': cost_rate, 'done_envs': n_done, 'obs_finite': finite},
+      'checks': {'cost_rate_last_step': cost_rate, 'done_envs': n_done, 'obs_finite': finite,
+                 'goal_met_rate_last_step': getattr(run, 'met_rate', None)},
   }
   run.close()
 

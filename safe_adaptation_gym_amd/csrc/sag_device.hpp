@@ -392,7 +392,7 @@ constexpr int STG_BASE = LS_YAW * WAVE;
 #define SAG_ABLATE 0
 #endif
 enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL_NO_RV = 16, ABL_NO_RS = 32,
-       ABL_NSUB1 = 64, ABL_NO_ACTIVE = 128 };
+       ABL_NSUB1 = 64, ABL_NO_ACTIVE = 128, ABL_NO_RESAMPLE = 8192 };
 #define ABL(f) ((SAG_ABLATE & (f)) != 0)
 #define SF(k) S[(size_t)(k) * N + i]
 #define LP(base, k) lds[((base) + (k)) * WAVE + lane]
@@ -1036,29 +1036,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   int met = 0;
   const double rx = R.x, ry = R.y;
   // GoToGoal._resample_goal_position (:59-80) + utils.draw_placement (utils.py:28-70)
-  auto resample_goal = [&]() {
-    double xmin = -1.5, ymin = -1.5, xmax = 1.5, ymax = 1.5;
-    const double k_robot = SF(SAG_F_KEEPOUT), k_haz = SF(SAG_F_KEEPOUT + 1), k_vase = SF(SAG_F_KEEPOUT + 2),
-                 k_pil = SF(SAG_F_KEEPOUT + 3), k_box = SF(SAG_F_KEEPOUT + 4);
-    bool found = false;
-#pragma unroll 1
-    for (int t = 0; t < 10000 && !found; t++) {
-      double ngx = rng.uniform(xmin + GOAL_KEEPOUT, xmax - GOAL_KEEPOUT);
-      double ngy = rng.uniform(ymin + GOAL_KEEPOUT, ymax - GOAL_KEEPOUT);
-      if (rng.exhausted) break;
-      bool ok = !(dist2d(ngx, ngy, rx, ry) < k_robot + GOAL_KEEPOUT);
-      for (int k = 0; k < nH && ok; k++)
-        ok = !(dist2d(ngx, ngy, SF(SAG_F_HAZARDS + 2 * k), SF(SAG_F_HAZARDS + 2 * k + 1)) < k_haz + GOAL_KEEPOUT);
-      for (int k = 0; k < nV && ok; k++)
-        ok = !(dist2d(ngx, ngy, LP(LS_X, k), LP(LS_Y, k)) < k_vase + GOAL_KEEPOUT);
-      for (int k = 0; k < nP && ok; k++)
-        ok = !(dist2d(ngx, ngy, SF(SAG_F_PILLARS + 2 * k), SF(SAG_F_PILLARS + 2 * k + 1)) < k_pil + GOAL_KEEPOUT);
-      if (has_box && ok) ok = !(dist2d(ngx, ngy, boxx, boxy) < k_box + GOAL_KEEPOUT);
-      if (ok) { goalx = (float)ngx; goaly = (float)ngy; found = true; }
-      else { xmin *= 1.01; ymin *= 1.01; xmax *= 1.01; ymax *= 1.01; }
-    }
-    if (!found) flags |= rng.exhausted ? 2 : 1;
-  };
+  bool need_goal = false;  // a goal was met: resample it (wave-cooperatively, below)
+  float box_last1 = 0, box_last2 = 0;
   if (!p.observe_only && !bad) {
     if (task == SAG_TASK_PRESS_BUTTONS || task == SAG_TASK_PRESS_BUTTONS_SCARCE) {
       int gb = tstate & 7, bstate = tstate >> 3 & 1, timer = tstate >> 4 & 7;
@@ -1097,13 +1076,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       double r = (double)last0 - dist;
       if (task == SAG_TASK_GO_TO_GOAL_SCARCE) r *= (dist <= GOAL_SIZE * 1.5) ? 1.0 : 0.0;
       float last = (float)dist;
-      if (dist <= GOAL_SIZE) {
-        met = 1;
-        resample_goal();
-        last = (float)dist2d(rx, ry, goalx, goaly);  // GoToGoal.reset: 2-D (:54-55)
-        if (task == SAG_TASK_CATCH_GOAL && live) { SF(SAG_F_CATCH) = goalx; SF(SAG_F_CATCH + 1) = goaly; }
-        r += 1.0;
-      }
+      if (dist <= GOAL_SIZE) { met = 1; need_goal = true; r += 1.0; }
       last0 = last;
       if (task == SAG_TASK_UNSUPERVISED) {  // tasks/unsupervised.py:48-67
         // subtree COM of the robot in body axes: point (mc/m, 0); car (0, .0074)
@@ -1131,18 +1104,110 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       const double bg = dist2d(bx, by, goalx, goaly);
       r += (double)last2 - bg;
       last2 = (float)bg;
-      if (bg <= GOAL_SIZE) {
-        met = 1;
-        resample_goal();
-        last0 = (float)dist2d(rx, ry, goalx, goaly);
-        last2 = (float)dist2d(goalx, goaly, bx, by);   // PushBox.reset (:94-100)
-        last1 = (float)dist2d(rx, ry, bx, by);
-        r += 1.0;
-      }
-      if (live) { SF(SAG_F_LAST + 1) = last1; SF(SAG_F_LAST + 2) = last2; }
+      if (bg <= GOAL_SIZE) { met = 1; need_goal = true; r += 1.0; }
+      box_last1 = last1; box_last2 = last2;
       rew0 = r;
     }
+  }
+  // ---- goal resampling (GoToGoal._resample_goal_position, tasks/go_to_goal.py:59-80 +
+  //      utils.draw_placement, utils.py:28-70), wave-cooperative.  A met goal needs ~30 rejection
+  //      tries on these crowded layouts, each testing 21 keep-out distances in fp64: done by the
+  //      one lane that owns the env this stretched a wavefront by ~300k cycles and set the tail of
+  //      the whole launch.  Candidate j of the reference's sequence is a pure function of j (the
+  //      rectangle has grown 1.01^j, its four words sit at stream position pos + 4 j), so the 64
+  //      lanes test candidates j = base + lane at once and the first accepted one wins.
+  {
+    uint64_t need_mask = __ballot(need_goal && !ABL(ABL_NO_RESAMPLE));
+    while (need_mask) {
+      const int src = __ffsll((unsigned long long)need_mask) - 1;
+      need_mask &= need_mask - 1;
+      const int s_i = __shfl(i, src);
+      const double s_rx = __shfl(R.x, src), s_ry = __shfl(R.y, src);
+      const int s_nH = __shfl(nH, src), s_nV = __shfl(nV, src), s_nP = __shfl(nP, src);
+      const int s_box = __shfl((int)has_box, src);
+      const double s_bx = __shfl(boxx, src), s_by = __shfl(boxy, src);
+      const int s_pos0 = __shfl(rng.pos, src), s_len = __shfl(rng.len, src);
+      const uint32_t s_env = __shfl(rng.env, src), s_step = __shfl(rng.step, src);
+      const uint32_t* s_tape = p.tape ? p.tape + (size_t)s_i * p.tape_len : nullptr;
+      const double k_robot = S[(size_t)SAG_F_KEEPOUT * N + s_i], k_haz = S[(size_t)(SAG_F_KEEPOUT + 1) * N + s_i],
+                   k_vase = S[(size_t)(SAG_F_KEEPOUT + 2) * N + s_i], k_pil = S[(size_t)(SAG_F_KEEPOUT + 3) * N + s_i],
+                   k_box = S[(size_t)(SAG_F_KEEPOUT + 4) * N + s_i];
+      int winner = -1, exhausted = 0;
+      float w_gx = 0, w_gy = 0;
+#pragma unroll 1
+      for (int base = 0; base < 10000 && winner < 0 && !exhausted; base += WAVE) {
+        const int j = base + lane;
+        double half = 1.5;  // one multiplication per earlier rejection, as the reference does
+#pragma unroll 1
+        for (int q = 0; q < j; q++) half *= 1.01;
+        // four words at stream position pos0 + 4 j
+        uint32_t wd[4];
+        bool out_of_tape = false;
+        const int w0 = s_pos0 + 4 * j;
+        if (s_tape) {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            out_of_tape |= w0 + t >= s_len;
+            wd[t] = w0 + t < s_len ? s_tape[w0 + t] : 0u;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            uint32_t c[4] = {s_env, s_step, (uint32_t)((w0 + t) >> 2), 0u};
+            philox4x32_10(c, p.key0, p.key1);
+            wd[t] = c[(w0 + t) & 3];
+          }
+        }
+        const double lo = -half + GOAL_KEEPOUT, hi = half - GOAL_KEEPOUT;
+        const double ngx = lo + (hi - lo) * (((wd[0] >> 5) * 67108864.0 + (wd[1] >> 6)) / 9007199254740992.0);
+        const double ngy = lo + (hi - lo) * (((wd[2] >> 5) * 67108864.0 + (wd[3] >> 6)) / 9007199254740992.0);
+        bool ok = !out_of_tape && j < 10000 && !(dist2d(ngx, ngy, s_rx, s_ry) < k_robot + GOAL_KEEPOUT);
+#pragma unroll
+        for (int k = 0; k < SAG_MAX_HAZARDS; k++) {
+          const double hx = __shfl(hzx[k], src), hy = __shfl(hzy[k], src);
+          if (k < s_nH && ok) ok = !(dist2d(ngx, ngy, hx, hy) < k_haz + GOAL_KEEPOUT);
+        }
+#pragma unroll 1
+        for (int k = 0; k < s_nV; k++) {
+          const double vx_ = lds[(LS_X + k) * WAVE + src], vy_ = lds[(LS_Y + k) * WAVE + src];
+          if (ok) ok = !(dist2d(ngx, ngy, vx_, vy_) < k_vase + GOAL_KEEPOUT);
+        }
+#pragma unroll
+        for (int k = 0; k < SAG_MAX_PILLARS; k++) {
+          const double px_ = __shfl(stx[k], src), py_ = __shfl(sty[k], src);
+          if (k < s_nP && ok) ok = !(dist2d(ngx, ngy, px_, py_) < k_pil + GOAL_KEEPOUT);
+        }
+        if (s_box && ok) ok = !(dist2d(ngx, ngy, s_bx, s_by) < k_box + GOAL_KEEPOUT);
+        const uint64_t okm = __ballot(ok), exm = __ballot(out_of_tape);
+        const int first_ok = okm ? __ffsll((unsigned long long)okm) - 1 : WAVE;
+        const int first_ex = exm ? __ffsll((unsigned long long)exm) - 1 : WAVE;
+        if (first_ok < first_ex) {
+          winner = base + first_ok;
+          w_gx = __shfl((float)ngx, first_ok); w_gy = __shfl((float)ngy, first_ok);
+        } else if (first_ex < WAVE) {
+          exhausted = 1; winner = base + first_ex;  // words consumed up to the failed draw
+        }
+      }
+      if (lane == src) {
+        if (winner >= 0 && !exhausted) { goalx = w_gx; goaly = w_gy; rng.pos = s_pos0 + 4 * (winner + 1); }
+        else if (exhausted) { rng.exhausted = 1; rng.pos = s_pos0 + 4 * (winner + 1); flags |= 2; }
+        else { rng.pos = s_pos0 + 4 * 10000; flags |= 1; }
+      }
+    }
+  }
+  if (!p.observe_only && !bad) {
+    if (need_goal) {
+      // GoToGoal.reset (:50-57): last goal distance becomes the 2-D distance to the new goal;
+      // CatchGoal.reset (catch_goal.py:36-40): new orbit origin; PushBox.reset (push_box.py:94-100)
+      last0 = (float)dist2d(rx, ry, goalx, goaly);
+      if (task == SAG_TASK_CATCH_GOAL && live) { SF(SAG_F_CATCH) = goalx; SF(SAG_F_CATCH + 1) = goaly; }
+      if (has_box) {
+        box_last2 = (float)dist2d(goalx, goaly, boxx, boxy);
+        box_last1 = (float)dist2d(rx, ry, boxx, boxy);
+      }
+    }
     if (live) {
+      if (has_box) { SF(SAG_F_LAST + 1) = box_last1; SF(SAG_F_LAST + 2) = box_last2; }
       SF(SAG_F_LAST) = last0;
       SF(SAG_F_GOAL) = goalx; SF(SAG_F_GOAL + 1) = goaly;
     }
@@ -1278,8 +1343,11 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
                                                  min(WAVE, p.N - base), 0ull, nullptr);
 }
 
+#ifndef SAG_QUIET_MIN_WAVES
+#define SAG_QUIET_MIN_WAVES 4
+#endif
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
-__global__ __launch_bounds__(WAVE, 4) void k_step_quiet(StepArgs p) {
+__global__ __launch_bounds__(WAVE, SAG_QUIET_MIN_WAVES) void k_step_quiet(StepArgs p) {
   // positions (x, y) of the free bodies + the observation staging tile; no dynamic pool:
   // 10 KB (Point) -> 16 wavefronts per CU
   constexpr int QSLOTS = LS_YAW + (ROBOT == SAG_ROBOT_CAR ? 25 : 17);
