@@ -103,6 +103,7 @@ class DeviceRun:
     done = self.ctx.dev_download(self.d_done, (self.envs,), np.uint8)
     obs = self.ctx.dev_download(self.d_obs, (min(self.envs, 4096) * self.ctx.info['obs_dim'],), np.float32)
     self.met_rate = float(self.ctx.dev_download(self.d_met, (self.envs,), np.uint8).mean())
+    self.busy_frac = self.ctx.busy_count() / self.envs
     return float(cost.mean()), int(done.sum()), bool(np.isfinite(obs).all())
 
   def close(self):
@@ -258,13 +259,14 @@ def main(argv=None, run_factory=None, emit=print):
           'unit': 'GB/s',
           'frac': achieved / HBM_PEAK_GBS,
           'traffic': traffic_per_launch(args.envs),
-          'kernel': 'sag::k_step_point',
+          'kernel': 'sag::k_compact + k_step_quiet + k_step_busy (one step() = the three launches)',
           'kernel_ms': k_ms,
           'launches_timed': k_n,
           'alg_bytes_per_env_step': ALG_BYTES_PER_ENV_STEP,
       },
       'checks': {'cost_rate_last_step': cost_rate, 'done_envs': n_done, 'obs_finite': finite,
-                 'goal_met_rate_last_step': getattr(run, 'met_rate', None)},
+                 'goal_met_rate_last_step': getattr(run, 'met_rate', None),
+                 'busy_env_fraction_last_step': getattr(run, 'busy_frac', None)},
   }
   run.close()
 

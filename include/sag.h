@@ -225,6 +225,12 @@ int sag_dev_fill_actions(sag_ctx* ctx, float* d_actions, uint32_t step_index);
  * stream: mean milliseconds per launch over the launches since the last call
  * with reset != 0.  Feeds bench.py's roofline.achieved. */
 int sag_kernel_time_ms(sag_ctx* ctx, int32_t reset, double* mean_ms, int64_t* launches);
+/* Diagnostic: how many envs the last split step handed to the busy kernel (0 for the
+ * single-kernel form).  Synchronises the context stream. */
+int sag_busy_count(sag_ctx* ctx, int32_t* count);
+/* Diagnostic, only in libraries built with -DSAG_CYCLES (SAG_ERR_UNSUPPORTED otherwise):
+ * wavefront clock ticks per code section of the step kernel, [3 launch forms][16]. */
+int sag_debug_cycles(sag_ctx* ctx, int32_t reset, uint64_t* out, int32_t n);
 /* Per-launch HIP-event bracketing of the step kernel is off by default. */
 int sag_enable_timing(sag_ctx* ctx, int32_t on);
 

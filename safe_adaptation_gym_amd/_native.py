@@ -31,7 +31,7 @@ EXPORTS = [
     'sag_robot_info', 'sag_create', 'sag_destroy', 'sag_last_error', 'sag_set_layout',
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
     'sag_observe', 'sag_lidar_cost', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
-    'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing',
+    'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles',
     'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts'
 ]
 
@@ -91,6 +91,8 @@ def load():
   lib.sag_dev_fill_actions.argtypes = [vp, vp, C.c_uint32]
   lib.sag_kernel_time_ms.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
   lib.sag_enable_timing.argtypes = [vp, C.c_int32]
+  lib.sag_busy_count.argtypes = [vp, C.POINTER(C.c_int32)]
+  lib.sag_debug_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]
   lib.sag_world_config_default.argtypes = [C.POINTER(WorldConfig)]
   lib.sag_world_config_default.restype = None
   lib.sag_sample_layouts.argtypes = [C.c_int32, C.c_int32, up, ip, C.POINTER(WorldConfig), C.c_int32,
@@ -304,6 +306,16 @@ class Context:
 
   def enable_timing(self, on=True):
     self._check(self.lib.sag_enable_timing(self.h, int(on)), 'sag_enable_timing')
+
+  def debug_cycles(self, reset=False):
+    out = (C.c_uint64 * 48)()
+    self._check(self.lib.sag_debug_cycles(self.h, int(reset), out, 48), 'sag_debug_cycles')
+    return np.array(out[:], np.uint64).reshape(3, 16)
+
+  def busy_count(self):
+    n = C.c_int32()
+    self._check(self.lib.sag_busy_count(self.h, C.byref(n)), 'sag_busy_count')
+    return n.value
 
   def kernel_time_ms(self, reset=False):
     ms, n = C.c_double(), C.c_int64()

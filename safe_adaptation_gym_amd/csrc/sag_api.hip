@@ -161,7 +161,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   do {                                                                                                  \
     if (split) {                                                                                        \
       hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);       \
-      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);        \
+      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3((c->N + SAG_BUSY_ENVS - 1) / SAG_BUSY_ENVS), dim3(WAVE), 0, c->stream, a); \
     } else {                                                                                            \
       hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);             \
     }                                                                                                   \
@@ -527,6 +527,34 @@ int sag_kernel_time_ms(sag_ctx* c, int32_t reset, double* mean_ms, int64_t* laun
   if (mean_ms) *mean_ms = c->ev_n ? c->ev_ms / (double)c->ev_n : 0.0;
   if (launches) *launches = c->ev_n;
   if (reset) { c->ev_ms = 0; c->ev_n = 0; }
+  return SAG_OK;
+}
+
+int sag_debug_cycles(sag_ctx* c, int32_t reset, uint64_t* out, int32_t n) {
+  if (!c || !out || n < 0) return SAG_ERR_ARG;
+#ifdef SAG_CYCLES
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  uint64_t host[3 * (CY_N + 1)];
+  HIPCHK(c, hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cyc), sizeof(host)));
+  for (int k = 0; k < n; k++) out[k] = k < 3 * (CY_N + 1) ? host[k] : 0;
+  if (reset) {
+    memset(host, 0, sizeof(host));
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_cyc), host, sizeof(host)));
+  }
+  return SAG_OK;
+#else
+  (void)reset;
+  for (int k = 0; k < n; k++) out[k] = 0;
+  return SAG_ERR_UNSUPPORTED;
+#endif
+}
+
+int sag_busy_count(sag_ctx* c, int32_t* count) {
+  if (!c || !count) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(count, c->d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
   return SAG_OK;
 }
 

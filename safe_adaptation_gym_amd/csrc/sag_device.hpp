@@ -394,6 +394,20 @@ constexpr int STG_BASE = LS_YAW * WAVE;
 enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL_NO_RV = 16, ABL_NO_RS = 32,
        ABL_NSUB1 = 64, ABL_NO_ACTIVE = 128, ABL_NO_RESAMPLE = 8192 };
 #define ABL(f) ((SAG_ABLATE & (f)) != 0)
+// section profile (tools/cycles.py): -DSAG_CYCLES accumulates wavefront clock ticks per code
+// section of step_body into g_cyc[mode][section]; off in the shipped library
+enum { CY_LOAD = 0, CY_ROBOT, CY_RS, CY_RV, CY_VS, CY_VV_BROAD, CY_VV_NARROW, CY_INTEG, CY_WRITEBACK,
+       CY_REWARD, CY_RESAMPLE, CY_COST, CY_LIDAR, CY_OBS_STORE, CY_TAIL, CY_N };
+#ifdef SAG_CYCLES
+__device__ unsigned long long g_cyc[3][CY_N + 1];
+#define CYC_DECL unsigned long long cyc_acc[CY_N] = {}; unsigned long long cyc_t = __builtin_readcyclecounter();
+#define CYC(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); cyc_acc[k] += t_ - cyc_t; cyc_t = t_; } while (0)
+#define CYC_FLUSH(mode) do { if (lane == 0) { for (int k_ = 0; k_ < CY_N; k_++) atomicAdd(&g_cyc[mode][k_], cyc_acc[k_]); atomicAdd(&g_cyc[mode][CY_N], 1ull); } } while (0)
+#else
+#define CYC_DECL
+#define CYC(k) do {} while (0)
+#define CYC_FLUSH(mode) do {} while (0)
+#endif
 #define SF(k) S[(size_t)(k) * N + i]
 #define LP(base, k) lds[((base) + (k)) * WAVE + lane]
 #define POOL(d, c) lds[(LS_POOL + (d) * 6 + (c)) * WAVE + lane]
@@ -529,6 +543,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   constexpr int OBS_DIM = CAR ? 72 : 60, NSENS = OBS_DIM - 48;
   constexpr int STG_STRIDE = CAR ? 25 : 17;
   static_assert(STG_BASE + WAVE * STG_STRIDE <= LDS_FLOATS, "staging tile must fit");
+  CYC_DECL
   const float my_bound = shape_bound(SH_ME, 0.f, 0.f);
   const int N = p.N;
   float* __restrict__ S = p.S;
@@ -692,6 +707,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   uint32_t btn_mask = 0;
   float cy = 1, sy = 0;
 
+  CYC(CY_LOAD);
 #pragma unroll 1
   for (int sub = 0; sub <= nsub; sub++) {
     sincosf(yaw, &sy, &cy);
@@ -760,6 +776,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         fric(-sy, cy, rx, ry, ext[2], &eacc[2], Ib, MU * CNC);              // y slip <-> +ball_x
       }
     }
+    CYC(CY_ROBOT);
     cost_contacts = 0; btn_mask = 0;
     if constexpr (!QUIET) {
     // `active` = bodies that can have a non-zero acceleration or velocity this substep.
@@ -784,6 +801,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
       }
     }
+    CYC(CY_RS);
     // robot vs free bodies: cheap broadphase for all, then each lane walks ITS OWN hit list
     // (ascending index = the specification's order), so a wavefront runs the narrowphase
     // max-hits times, not once per body index that any lane happens to touch
@@ -831,6 +849,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         }
       }
     }
+    CYC(CY_RV);
     if (sub == nsub) break;  // final forward: robot acceleration + contact flags only
     if (active && !ABL(ABL_NO_ACTIVE)) {
       // free bodies vs static circles (pillars then buttons), per active body
@@ -860,6 +879,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
           dy.set_acc(k, V.ax, V.ay, V.aw);
         }
       }
+      CYC(CY_VS);
       // free body pairs (a < b) in lexicographic order, the task object being the last body;
       // at least one of the two active.  Per a: broadphase mask over b, then the lane's own
       // hit list.  (A per-lane walk over a 55-bit pair list was measured slower.)
@@ -876,6 +896,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
           const float dx = LP(LS_X, b) - axp, dyy = LP(LS_Y, b) - ayp, rs = vase_r + (b == BOX_ID ? box_r : vase_r);
           if (dx * dx + dyy * dyy <= rs * rs) hit |= 1u << b;
         }
+        CYC(CY_VV_BROAD);
         for (uint32_t m = hit; m; m &= m - 1) {
           const int b = __ffs(m) - 1;
           const bool isb = b == BOX_ID;
@@ -889,7 +910,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
             active |= 1u << a | 1u << b;
           }
         }
+        CYC(CY_VV_NARROW);
       }
+      CYC(CY_VV_BROAD);
       // floor friction + semi-implicit Euler + rest capture for the active bodies
       for (uint32_t m = active; m; m &= m - 1) {
         const int k = __ffs(m) - 1;
@@ -936,6 +959,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         LP(LS_X, k) += h * vx_; LP(LS_Y, k) += h * vy_; LP(LS_YAW, k) += h * w_;
         if (vx_ == 0 && vy_ == 0 && w_ == 0) awake &= ~(1u << k); else awake |= 1u << k;
       }
+      CYC(CY_INTEG);
       dirty |= active;
     }
     } else {
@@ -963,6 +987,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
   }
 
+  CYC(CY_ROBOT);
   // ---- write back dynamic state -------------------------------------------------
   const float boxx = LP(LS_X, BOX_ID), boxy = LP(LS_Y, BOX_ID);
   if (!p.observe_only && live) {
@@ -1013,6 +1038,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     tstate = busy ? (tstate | nbit) : (tstate & ~nbit);
   }
 
+  CYC(CY_WRITEBACK);
   // hazards are only needed from here on (cost, lidar): loading them late keeps 18 registers
   // free during the physics; the reward arithmetic below covers the latency
   float hzx[SAG_MAX_HAZARDS], hzy[SAG_MAX_HAZARDS];
@@ -1109,6 +1135,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       rew0 = r;
     }
   }
+  CYC(CY_REWARD);
   // ---- goal resampling (GoToGoal._resample_goal_position, tasks/go_to_goal.py:59-80 +
   //      utils.draw_placement, utils.py:28-70), wave-cooperative.  A met goal needs ~30 rejection
   //      tries on these crowded layouts, each testing 21 keep-out distances in fp64: done by the
@@ -1195,6 +1222,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       }
     }
   }
+  CYC(CY_RESAMPLE);
   if (!p.observe_only && !bad) {
     if (need_goal) {
       // GoToGoal.reset (:50-57): last goal distance becomes the 2-D distance to the new goal;
@@ -1233,6 +1261,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   }
   if (flags && live) I[(size_t)DI_FLAGS * N + i] |= flags;
 
+  CYC(CY_COST);
   // ---- observation (safe_adaptation_gym.py:120-139, 225-237): four column chunks
   //      [obstacles 16 | objects 16 | goal 16 | sensors 12], each staged in LDS [lane][17]
   //      and written back transposed -------------------------------------------------------
@@ -1299,6 +1328,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         }
       }
       __syncthreads();
+      CYC(CY_LIDAR);
       if (chunk < 3) {
 #pragma unroll 4
         for (int j = 0; j < 16; j++) {
@@ -1318,6 +1348,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         }
       }
       __syncthreads();
+      CYC(CY_OBS_STORE);
     }
   }
   if (live) {
@@ -1331,6 +1362,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     if (p.goal_met) p.goal_met[i] = (uint8_t)met;
     if (p.tape_used) p.tape_used[i] = rng.pos;
   }
+  CYC(CY_TAIL);
+  CYC_FLUSH(MODE);
 }
 
 // ---- the three launch forms ------------------------------------------------------------
@@ -1399,14 +1432,17 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int ph
   }
 }
 
+#ifndef SAG_BUSY_ENVS
+#define SAG_BUSY_ENVS 64  // envs per busy wavefront
+#endif
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
   __shared__ float lds[LDS_FLOATS];
   __shared__ int rows[WAVE];
-  const int lane = threadIdx.x, c0 = blockIdx.x * WAVE;
+  const int lane = threadIdx.x, c0 = blockIdx.x * SAG_BUSY_ENVS;
   const int count = *p.count;
   if (c0 >= count) return;
-  const int nval = min(WAVE, count - c0);
+  const int nval = min(SAG_BUSY_ENVS, count - c0);
   const bool live = lane < nval;
   const int i = p.rows[c0 + (live ? lane : 0)];
   rows[lane] = i;
