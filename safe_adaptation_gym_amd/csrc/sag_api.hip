@@ -16,6 +16,10 @@
 
 #include "sag_device.hpp"
 
+#ifndef SAG_SPLIT_MIN_ENVS
+#define SAG_SPLIT_MIN_ENVS 393216  // measured crossover (tools/split_sweep.py): ~400k envs, Point and Car
+#endif
+
 using namespace sag;
 
 namespace {
@@ -59,7 +63,7 @@ struct sag_ctx {
   double ev_ms = 0; int64_t ev_n = 0;
   bool timing = false;
   int phase = 0;       // busy-bit copy read by the next step launch
-  bool split = true;   // QUIET + BUSY launches (SAG_SPLIT=0 in the environment selects the single form)
+  bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
 
@@ -220,6 +224,9 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
     return fail(nullptr, SAG_ERR_NODEVICE, "device %d out of range (%d visible)", cfg->device, ndev);
   sag_ctx* c = new sag_ctx();
   c->cfg = *cfg; c->rb = ROBOTS[cfg->robot]; c->N = cfg->n_envs;
+  // below ~one resident round of wavefronts a step is latency-bound and two dependent launches
+  // cost more than the divergence they remove
+  c->split = c->N >= SAG_SPLIT_MIN_ENVS;
   if (const char* e = getenv("SAG_SPLIT")) c->split = atoi(e) != 0;
   const size_t N = (size_t)c->N;
 #define CREATE_CHK(call)                                                                         \
