@@ -101,8 +101,17 @@ enum sag_rec_float {
   SAG_F_BOUND = 141,      /* info['bound'] (world.py:75-78); carried, not used on the device */
   SAG_F_ROBOT_EXT = 144,  /* robot DoF beyond the planar base. car (car.xml:21-32): wheel rates left,
                            * right (rad/s about the axle); rear ball: angular velocity x,y,z
-                           * (relative to the base, base frame); ball quaternion w,x,y,z           */
-  SAG_REC_FLOATS = 160
+                           * (relative to the base, base frame); ball quaternion w,x,y,z.
+                           * doggo (doggo.xml): [0] base z, [1..4] base quaternion w,x,y,z, [5] vz,
+                           * [6..8] base angular velocity in the base frame (MuJoCo free-joint qvel),
+                           * [9..21] the 13 hinge angles in qpos order (hip_1_z, hip_1_y, ankle_1,
+                           * hip_4_z, hip_4_y, ankle_4, waist_x, hip_2_z, hip_2_y, ankle_2, hip_3_z,
+                           * hip_3_y, ankle_3), [22..34] their rates.  ROBOT x, y, vx, vy are the base
+                           * position / world velocity; ROBOT yaw and w are derived (heading, world
+                           * yaw rate) and written back every step.  A zero quaternion at install
+                           * time means "upright at ROBOT yaw, z = 0.22, joints at 0".            */
+  SAG_ROBOT_EXT_FLOATS = 40,
+  SAG_REC_FLOATS = 184
 };
 
 enum sag_rec_int {

@@ -102,6 +102,8 @@ typedef struct {
   real qacc[3];
   real cost_margin; /* smallest |distance to a flag threshold| seen */
   uint32_t btn_contact_mask;
+  real touch[8];    /* doggo touch sensors of the final forward pass */
+  real comvel[4];   /* doggo subtree COM xy and its velocity (Unsupervised) */
 } OOut;
 
 int sago_sizeof_env(void) { return (int)sizeof(OEnv); }
@@ -538,7 +540,8 @@ typedef struct {
   real box_m, box_I;
   int nV, nP, nB, box_kind, haul;
   int robot_id;
-  real ext[16], ext_acc[5]; /* car: wheel rates L,R; ball rate x,y,z; ball quat w,x,y,z */
+  real ext[SAG_ROBOT_EXT_FLOATS], ext_acc[5]; /* car: wheel rates L,R; ball rate x,y,z; ball quat w,x,y,z */
+  void* dg;                                   /* doggo: Doggo* articulated state (sag_oracle_doggo.inc) */
 } World;
 
 static void material_default(Body* b) { b->mu = (real)FRICTION_MU; b->tc = (real)SOL_TC; b->dr = 1; b->prio = 0; }
@@ -548,6 +551,8 @@ static void body_static_circle(Body* b, real x, real y, real r) {
   b->x = x; b->y = y; b->ngeom = 1; b->g[0].type = 0; b->g[0].a = r; b->dynamic = 0;
   material_default(b);
 }
+
+#include "sag_oracle_doggo.inc"
 
 /* The task object of the PushBox family, as a planar free body.
  *  BOX  (push_box.py:28-72): box half .2 + four corner columns half .1 at (+-.2, +-.2), density
@@ -675,7 +680,7 @@ static void car_body(Body* r);
 static void world_from_env_r(const OEnv* e, World* w, int robot) {
   memset(w, 0, sizeof(*w));
   w->robot_id = robot;
-  for (int k = 0; k < 16; k++) w->ext[k] = e->f[SAG_F_ROBOT_EXT + k];
+  for (int k = 0; k < SAG_ROBOT_EXT_FLOATS; k++) w->ext[k] = e->f[SAG_F_ROBOT_EXT + k];
   const real* f = e->f;
   Body* r = &w->robot;
   r->x = f[SAG_F_ROBOT]; r->y = f[SAG_F_ROBOT + 1]; r->yaw = f[SAG_F_ROBOT + 2];
@@ -718,9 +723,15 @@ static void world_from_env_r(const OEnv* e, World* w, int robot) {
 static void world_to_env(const World* w, OEnv* e) {
   real* f = e->f;
   const Body* r = &w->robot;
-  for (int k = 0; k < 16; k++) f[SAG_F_ROBOT_EXT + k] = w->ext[k];
-  f[SAG_F_ROBOT] = r->x; f[SAG_F_ROBOT + 1] = r->y; f[SAG_F_ROBOT + 2] = r->yaw;
-  f[SAG_F_ROBOT + 3] = r->vx; f[SAG_F_ROBOT + 4] = r->vy; f[SAG_F_ROBOT + 5] = r->w;
+  if (w->robot_id == SAG_ROBOT_DOGGO && w->dg) {
+    dg_store((const Doggo*)w->dg, f + SAG_F_ROBOT, f + SAG_F_ROBOT_EXT);
+  } else {
+    for (int k = 0; k < SAG_ROBOT_EXT_FLOATS; k++) f[SAG_F_ROBOT_EXT + k] = w->ext[k];
+  }
+  if (w->robot_id != SAG_ROBOT_DOGGO) {
+    f[SAG_F_ROBOT] = r->x; f[SAG_F_ROBOT + 1] = r->y; f[SAG_F_ROBOT + 2] = r->yaw;
+    f[SAG_F_ROBOT + 3] = r->vx; f[SAG_F_ROBOT + 4] = r->vy; f[SAG_F_ROBOT + 5] = r->w;
+  }
   for (int k = 0; k < w->nV; k++) {
     const Body* b = &w->vase[k];
     real* v = f + SAG_F_VASES + 6 * k;
@@ -916,10 +927,10 @@ static void car_integrate_ext(World* w, real h) {
  *   object counting as the last body), then floor friction of each vase and of the box.
  * Returns robot/obstacle penetration count (cost rule, mujoco_bridge.py:177-191
  * with prefixes consts.OBSTACLES; the box is not an obstacle) and the button contact mask. */
-static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol* sol,
+static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* sol,
                          uint32_t* btn_mask) {
   if (w->robot_id == SAG_ROBOT_CAR) car_smooth(w, ctrl, sol);
-  else point_smooth(&w->robot, ctrl, e->f[SAG_F_GEAR], e->f[SAG_F_DAMP], sol->h);
+  else if (w->robot_id == SAG_ROBOT_POINT) point_smooth(&w->robot, ctrl, e->f[SAG_F_GEAR], e->f[SAG_F_DAMP], sol->h);
   for (int k = 0; k < w->nV; k++) { w->vase[k].ax = w->vase[k].ay = w->vase[k].aw = 0; }
   w->box.ax = w->box.ay = w->box.aw = 0;
   if (w->box_kind == SAG_BOX_ROD) { /* orientation-dependent inverse inertia */
@@ -930,6 +941,11 @@ static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol*
   const int has_box = w->box_kind != SAG_BOX_NONE;
   int cost_contacts = 0;
   uint32_t mask = 0;
+  if (w->robot_id == SAG_ROBOT_DOGGO) {
+    /* every robot row (limits, floor, pillars, buttons, vases, box, tether) in one PGS */
+    cost_contacts = dg_forward(w, (Doggo*)w->dg, ctrl, sol, &mask);
+    goto free_bodies;
+  }
   for (int p = 0; p < w->nP; p++)
     cost_contacts += collide_pair(&w->robot, &w->pillar[p], w->r_robot, w->r_pillar, sol, 1);
   for (int b = 0; b < w->nB; b++)
@@ -955,6 +971,7 @@ static int world_forward(World* w, const OEnv* e, const real ctrl[2], const Sol*
     }
     if (w->haul) haul_tendon(w, sol);
   }
+free_bodies:
   for (int k = 0; k < w->nV; k++) {
     for (int p = 0; p < w->nP; p++)
       collide_pair(&w->vase[k], &w->pillar[p], w->r_vase, w->r_pillar, sol, 1);
@@ -998,13 +1015,16 @@ static void integrate_free(Body* b, real h) {
 }
 
 /* nstep x mj_step (safe_adaptation_gym.py:72) */
-static void substeps_r(OEnv* e, const real ctrl[2], int nstep, double h, int robot) {
+static void substeps_r(OEnv* e, const real* ctrl, int nstep, double h, int robot) {
   World w;
+  Doggo dg;
   world_from_env_r(e, &w, robot);
+  if (robot == SAG_ROBOT_DOGGO) { w.dg = &dg; dg_load(&dg, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT); }
   Sol sol = make_sol(h);
   for (int s = 0; s < nstep; s++) {
     world_forward(&w, e, ctrl, &sol, NULL);
-    integrate(&w.robot, sol.h);
+    if (robot == SAG_ROBOT_DOGGO) dg_integrate(&dg, h);
+    else integrate(&w.robot, sol.h);
     if (robot == SAG_ROBOT_CAR) car_integrate_ext(&w, sol.h);
     for (int k = 0; k < w.nV; k++) integrate_free(&w.vase[k], sol.h);
     if (w.box_kind != SAG_BOX_NONE) integrate_free(&w.box, sol.h);
@@ -1012,6 +1032,34 @@ static void substeps_r(OEnv* e, const real ctrl[2], int nstep, double h, int rob
   world_to_env(&w, e);
 }
 void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) { substeps_r(e, ctrl, nstep, h, SAG_ROBOT_POINT); }
+/* doggo: `nstep` substeps with controls as doubles (tests) */
+void sago_doggo_substeps(OEnv* e, const double* ctrl12, int nstep, double h) {
+  real c[12];
+  for (int k = 0; k < 12; k++) c[k] = (real)ctrl12[k];
+  substeps_r(e, c, nstep, h, SAG_ROBOT_DOGGO);
+}
+/* doggo diagnostics for the analytic tests: total energy; mass matrix [19x19], bias [19], sphere
+ * centres [17x3], total mass, contact-free qacc [19] at zero control */
+double sago_doggo_energy(const OEnv* e) {
+  Doggo D;
+  dg_load(&D, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT);
+  return dg_energy(&D);
+}
+void sago_doggo_debug(const OEnv* e, double* M, double* bias, double* sph, double* mass, double* qacc0) {
+  Doggo D;
+  dg_load(&D, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT);
+  dg_kinematics(&D);
+  dg_mass_matrix(&D);
+  for (int i = 0; i < DG_NV; i++) for (int j = 0; j < DG_NV; j++) M[i * DG_NV + j] = D.L[i][j];
+  dg_bias(&D, bias);
+  for (int s = 0; s < DG_NS; s++) for (int k = 0; k < 3; k++) sph[3 * s + k] = D.sph[s][k];
+  *mass = 0;
+  for (int b = 0; b < DG_NB; b++) *mass += D.Ib[b].m;
+  double tau[DG_NV];
+  for (int i = 0; i < DG_NV; i++) tau[i] = -bias[i];
+  for (int j = 0; j < DG_NJ; j++) tau[6 + j] += -DG_STIFF * (D.q[j] - DG_SPRINGREF_DEG[j] * PI / 180);
+  if (dg_cholesky(D.L)) dg_solve(D.L, tau, qacc0);
+}
 
 /* ------------------------------------------------------------------------ */
 /* goal resampling: tasks/go_to_goal.py:59-80 + utils.py:22-70                */
@@ -1119,7 +1167,7 @@ static void task_reward(OEnv* e, int robot, Rng* g, uint32_t btn_mask, OOut* out
     case SAG_TASK_GO_TO_GOAL_SCARCE:
     case SAG_TASK_UNSUPERVISED: {
       /* tasks/go_to_goal.py:31-45: 3-D distance robot xpos - goal xpos */
-      double dist = dist3d(rx, ry, PT_Z, f[SAG_F_GOAL], f[SAG_F_GOAL + 1], GOAL_Z);
+      double dist = dist3d(rx, ry, robot == SAG_ROBOT_DOGGO ? (double)f[SAG_F_ROBOT_EXT] : PT_Z, f[SAG_F_GOAL], f[SAG_F_GOAL + 1], GOAL_Z);
       double r = (double)f[SAG_F_LAST] - dist;
       if (task == SAG_TASK_GO_TO_GOAL_SCARCE) /* go_to_goal_scarce.py:26-32: indicator(0<=d<=.45) */
         r *= (0 <= dist && dist <= GOAL_SIZE * 1.5) ? 1.0 : 0.0;
@@ -1142,6 +1190,7 @@ static void task_reward(OEnv* e, int robot, Rng* g, uint32_t btn_mask, OOut* out
         double x = rx + lx, y = ry + ly;
         double w = f[SAG_F_ROBOT + 5];
         double u = f[SAG_F_ROBOT + 3] - w * ly, v = f[SAG_F_ROBOT + 4] + w * lx;
+        if (robot == SAG_ROBOT_DOGGO) { x = out->comvel[0]; y = out->comvel[1]; u = out->comvel[2]; v = out->comvel[3]; }
         double radius = sqrt(x * x + y * y);
         out->reward[0] = (real)((((-u * y + v * x) / radius) / (1 + fabs(radius - 1.5))) * 1e-1);
         out->reward[1] = (real)r;
@@ -1242,6 +1291,7 @@ static int has_goal_body(int task) {
 /* ------------------------------------------------------------------------ */
 /* observation: safe_adaptation_gym.py:120-139,225-237 (Point: 48 + 12)       */
 /* ------------------------------------------------------------------------ */
+static void observe_doggo(const OEnv* e, const real qacc[3], const real* touch, real* obs);
 static void observe(const OEnv* e, int robot, const real qacc[3], real* obs) {
   const real* f = e->f;
   double lid[48];
@@ -1309,6 +1359,57 @@ static int state_bad(const OEnv* e) {
   }
   return 0;
 }
+static int state_bad_r(const OEnv* e, int robot) {
+  if (state_bad(e)) return 1;
+  if (robot == SAG_ROBOT_DOGGO)
+    for (int k = 0; k < 35; k++) {
+      real v = e->f[SAG_F_ROBOT_EXT + k];
+      if (!(v == v) || R_FABS(v) > (real)1e10) return 1;
+    }
+  return 0;
+}
+
+/* Doggo observation: lidar with the tilted base (safe_adaptation_gym.py:197-216: e = (d @ R)[:2]
+ * with d = [p_xy, 0] - robot_xpos), then accelerometer, velocimeter, gyro, magnetometer, 8 touch,
+ * 12 joint rates, 12 x (sin, cos) of the joint angles (:225-237, doggo.xml:83-126) = 104 */
+static void dg_lidar(const double pos[3], const double R[9], double px, double py, double* lid) {
+  const double dx = px - pos[0], dy = py - pos[1], dz = -pos[2];
+  lidar_accumulate(R[0] * dx + R[3] * dy + R[6] * dz, R[1] * dx + R[4] * dy + R[7] * dz, lid);
+}
+static void observe_doggo(const OEnv* e, const real qacc[3], const real* touch, real* obs) {
+  const real* f = e->f;
+  Doggo D;
+  dg_load(&D, f + SAG_F_ROBOT, f + SAG_F_ROBOT_EXT);
+  double R[9], lid[48];
+  dg_quat2mat(D.quat, R);
+  for (int k = 0; k < 48; k++) lid[k] = 0;
+  int nH = e->i[SAG_I_NH], nV = e->i[SAG_I_NV], nP = e->i[SAG_I_NP], nB = e->i[SAG_I_NB];
+  for (int k = 0; k < nH; k++) dg_lidar(D.pos, R, f[SAG_F_HAZARDS + 2 * k], f[SAG_F_HAZARDS + 2 * k + 1], lid);
+  for (int k = 0; k < nV; k++) dg_lidar(D.pos, R, f[SAG_F_VASES + 6 * k], f[SAG_F_VASES + 6 * k + 1], lid);
+  for (int k = 0; k < nP; k++) dg_lidar(D.pos, R, f[SAG_F_PILLARS + 2 * k], f[SAG_F_PILLARS + 2 * k + 1], lid);
+  if (e->i[SAG_I_BOX_KIND] != SAG_BOX_NONE) dg_lidar(D.pos, R, f[SAG_F_BOX], f[SAG_F_BOX + 1], lid + 16);
+  for (int b = 0; b < nB; b++) {
+    int g = button_group(e, b);
+    if (g == 3) dg_lidar(D.pos, R, f[SAG_F_BUTTONS + 2 * b], f[SAG_F_BUTTONS + 2 * b + 1], lid + 16);
+    if (g == 2) dg_lidar(D.pos, R, f[SAG_F_BUTTONS + 2 * b], f[SAG_F_BUTTONS + 2 * b + 1], lid + 32);
+  }
+  if (has_goal_body(e->i[SAG_I_TASK])) dg_lidar(D.pos, R, f[SAG_F_GOAL], f[SAG_F_GOAL + 1], lid + 32);
+  for (int k = 0; k < 48; k++) obs[k] = (real)lid[k];
+  const double a[3] = {qacc[0], qacc[1], (double)qacc[2] + GRAVITY}, m[3] = {0, -0.5, 0};
+  for (int k = 0; k < 3; k++) {
+    obs[48 + k] = (real)(R[k] * a[0] + R[3 + k] * a[1] + R[6 + k] * a[2]);
+    obs[51 + k] = (real)(R[k] * D.vlin[0] + R[3 + k] * D.vlin[1] + R[6 + k] * D.vlin[2]);
+    obs[54 + k] = (real)D.wloc[k];
+    obs[57 + k] = (real)(R[k] * m[0] + R[3 + k] * m[1] + R[6 + k] * m[2]);
+  }
+  for (int k = 0; k < 8; k++) obs[60 + k] = touch ? touch[k] : 0;
+  for (int k = 0; k < 12; k++) {
+    const int j = DG_ACT_JOINT[k];
+    obs[68 + k] = (real)D.qd[j];
+    obs[80 + 2 * k] = (real)sin(D.q[j]);
+    obs[81 + 2 * k] = (real)cos(D.q[j]);
+  }
+}
 
 /* ------------------------------------------------------------------------ */
 /* SafeAdaptationGym.step (safe_adaptation_gym.py:56-83)                      */
@@ -1340,28 +1441,39 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   if (e->i[SAG_I_TASK] == SAG_TASK_CATCH_GOAL) catch_goal_mocap(e, &g, time);
   substeps_r(e, ctrl, nstep, h, robot);
   e->i[SAG_I_STEP] += 1;
-  if (state_bad(e)) { /* PhysicsError branch (:73-75) */
+  if (state_bad_r(e, robot)) { /* PhysicsError branch (:73-75) */
     real z[3] = {0, 0, 0};
-    observe(e, robot, z, out->obs);
+    if (robot == SAG_ROBOT_DOGGO) memset(out->obs, 0, sizeof(out->obs));
+    else observe(e, robot, z, out->obs);
     out->reward[0] = -10; out->done = 1; out->cost = 0;
     out->tape_used = g.pos;
     return;
   }
   /* mj_forward at the final state (:76): contacts + qacc */
   World w;
+  Doggo dg;
   world_from_env_r(e, &w, robot);
+  if (robot == SAG_ROBOT_DOGGO) { w.dg = &dg; dg_load(&dg, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT); }
   Sol sol = make_sol(h);
   uint32_t mask = 0;
   int cc = world_forward(&w, e, ctrl, &sol, &mask);
   if (ext_cost_contacts >= 0) { cc = ext_cost_contacts; mask = ext_btn_mask; }
   out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
+  if (robot == SAG_ROBOT_DOGGO) {
+    double cv[4];
+    dg_com_vel(&dg, cv);
+    for (int k = 0; k < 3; k++) out->qacc[k] = (real)dg.qacc[k];
+    for (int k = 0; k < 8; k++) out->touch[k] = (real)dg.touch[k];
+    for (int k = 0; k < 4; k++) out->comvel[k] = (real)cv[k];
+  }
   out->btn_contact_mask = mask;
   task_reward(e, robot, &g, mask, out);         /* :77 */
   double margin = 1e30;
   int cost = cc + hazard_cost(e, &margin);      /* :78, world.py:144-155 */
   out->cost = cost > 0;
   out->cost_margin = (real)margin;
-  observe(e, robot, out->qacc, out->obs);       /* :80 */
+  if (robot == SAG_ROBOT_DOGGO) observe_doggo(e, out->qacc, out->touch, out->obs);
+  else observe(e, robot, out->qacc, out->obs);  /* :80 */
   out->tape_used = g.pos;
 }
 
@@ -1369,11 +1481,19 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
 void sago_observe(OEnv* e, int robot, OOut* out) {
   memset(out, 0, sizeof(*out));
   World w;
+  Doggo dg;
   world_from_env_r(e, &w, robot);
+  if (robot == SAG_ROBOT_DOGGO) { w.dg = &dg; dg_load(&dg, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT); }
   Sol sol = make_sol(DT[robot]);
   real ctrl[SAG_MAX_NU] = {0};
   world_forward(&w, e, ctrl, &sol, &out->btn_contact_mask);
   out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
+  if (robot == SAG_ROBOT_DOGGO) {
+    for (int k = 0; k < 3; k++) out->qacc[k] = (real)dg.qacc[k];
+    for (int k = 0; k < 8; k++) out->touch[k] = (real)dg.touch[k];
+    observe_doggo(e, out->qacc, out->touch, out->obs);
+    return;
+  }
   observe(e, robot, out->qacc, out->obs);
 }
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('SAG_LIB') or os.path.join(_HERE, 'libsag.so')
 
 ABI_VERSION = 2
 MAX_HAZARDS, MAX_VASES, MAX_PILLARS, MAX_BUTTONS, MAX_NU = 9, 10, 2, 6, 12
-REC_FLOATS, REC_INTS = 160, 16
+REC_FLOATS, REC_INTS = 184, 16
 
 # record field offsets (enum sag_rec_float / sag_rec_int)
 F_ROBOT, F_ROBOT0, F_GEAR, F_DAMP, F_ACTION_NOISE, F_CTRL_SCALE = 0, 6, 9, 10, 11, 12

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, 'oracle')
 
 # record schema (include/sag.h)
-REC_FLOATS = 160
+REC_FLOATS = 184
 REC_INTS = 16
 F_ROBOT, F_ROBOT0, F_GEAR, F_DAMP, F_ACTION_NOISE, F_CTRL_SCALE = 0, 6, 9, 10, 11, 12
 F_HAZARD_SIZE, F_VASE_SIZE, F_PILLAR_SIZE, F_KEEPOUT = 24, 25, 26, 27
@@ -50,7 +50,7 @@ class Oracle:
       _fields_ = [('obs', creal * 104), ('reward', creal * 2), ('cost', C.c_int),
                   ('done', C.c_int), ('goal_met', C.c_int), ('tape_used', C.c_int),
                   ('qacc', creal * 3), ('cost_margin', creal),
-                  ('btn_contact_mask', C.c_uint32)]
+                  ('btn_contact_mask', C.c_uint32), ('touch', creal * 8), ('comvel', creal * 4)]
 
     self.OEnv, self.OOut = OEnv, OOut
     assert lib.sago_sizeof_env() == C.sizeof(OEnv)
@@ -86,6 +86,26 @@ class Oracle:
     lib.sago_actions.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, fp]
     lib.sago_philox.argtypes = [up, up, up]
     lib.sago_robot_info.argtypes = [C.c_int, ip, dp]
+    lib.sago_doggo_substeps.argtypes = [C.POINTER(OEnv), dp, C.c_int, C.c_double]
+    lib.sago_doggo_energy.argtypes = [C.POINTER(OEnv)]
+    lib.sago_doggo_energy.restype = C.c_double
+    lib.sago_doggo_debug.argtypes = [C.POINTER(OEnv), dp, dp, dp, dp, dp]
+
+  # -- doggo diagnostics -----------------------------------------------------
+  def doggo_substeps(self, e, ctrl12, nstep, h=0.012):
+    c = np.ascontiguousarray(ctrl12, np.float64)
+    self.lib.sago_doggo_substeps(C.byref(e), c.ctypes.data_as(C.POINTER(C.c_double)), nstep, h)
+
+  def doggo_energy(self, e):
+    return self.lib.sago_doggo_energy(C.byref(e))
+
+  def doggo_debug(self, e):
+    M, bias, sph = np.zeros((19, 19)), np.zeros(19), np.zeros((17, 3))
+    mass, qacc = np.zeros(1), np.zeros(19)
+    dp = C.POINTER(C.c_double)
+    self.lib.sago_doggo_debug(C.byref(e), M.ctypes.data_as(dp), bias.ctypes.data_as(dp),
+                              sph.ctypes.data_as(dp), mass.ctypes.data_as(dp), qacc.ctypes.data_as(dp))
+    return M, bias, sph, float(mass[0]), qacc
 
   # -- single env ----------------------------------------------------------
   def env(self, rec_f, rec_i):

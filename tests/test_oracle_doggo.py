@@ -1,0 +1,219 @@
+"""Known-answer tests of the Doggo specification (oracle/sag_oracle_doggo.inc).  MuJoCo is
+absent, so the model is pinned by physics it must satisfy: mass from the geoms, symmetric
+positive-definite mass matrix, free fall, energy conservation without contacts, momentum,
+standing equilibrium on the floor, joint limits, mirror symmetry."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from golden_util import base_record
+
+DOGGO = 2
+DT = 0.012
+EXT = ol.F_ROBOT_EXT
+
+
+@pytest.fixture(scope='module')
+def oracle():
+  return ol.Oracle()
+
+
+def doggo_record(x=0.0, y=0.0, yaw=0.0, z=0.22, task='go_to_goal', names=('robot', 'goal')):
+  rf, ri = base_record(task, list(names), {'robot': 0.4})
+  rf[ol.F_ROBOT:ol.F_ROBOT + 3] = [x, y, yaw]
+  rf[EXT:EXT + 40] = 0     # (base_record presets the car's ball quaternion)
+  rf[EXT] = z
+  rf[EXT + 1:EXT + 5] = [np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)]
+  rf[ol.F_GOAL:ol.F_GOAL + 2] = [5.0, 5.0]
+  return rf, ri
+
+
+def capsule_mass(a, b, r=0.032, dens=5.0):
+  L = np.linalg.norm(np.subtract(b, a))
+  return dens * (np.pi * r * r * L + 4 / 3 * np.pi * r**3)
+
+
+def test_total_mass_matches_the_geoms(oracle):
+  """doggo.xml:15,48 two cylinders r .075 x .2 density .5; 12 capsules r .032 density 5."""
+  rf, ri = doggo_record()
+  M, bias, sph, mass, qacc = oracle.doggo_debug(oracle.env(rf, ri))
+  cyl = 0.5 * np.pi * 0.075**2 * 0.2
+  legs = (capsule_mass((.1, 0, 0), (.2, .1, 0)) + capsule_mass((0, 0, 0), (.098, .0566, -.05)) +
+          capsule_mass((0, 0, 0), (-.1176, -.0679, -.1)))
+  assert mass == pytest.approx(2 * cyl + 4 * legs, rel=1e-12)
+  np.testing.assert_allclose(np.diag(M)[:3], mass, rtol=1e-12)
+
+
+def test_mass_matrix_is_symmetric_positive_definite(oracle):
+  rng = np.random.RandomState(0)
+  for _ in range(5):
+    rf, ri = doggo_record(yaw=rng.uniform(0, 6))
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    rf[EXT + 1:EXT + 5] = q
+    rf[EXT + 9:EXT + 22] = rng.uniform(-0.5, 0.5, 13)
+    M = oracle.doggo_debug(oracle.env(rf, ri))[0]
+    np.testing.assert_allclose(M, M.T, atol=1e-15)
+    assert np.linalg.eigvalsh(M).min() > 0
+
+
+def test_kinetic_energy_matches_the_body_sum(oracle):
+  """qd^T M qd / 2 == sum over spheres is not available; instead: M is invariant under a world
+  rotation about z applied to the base (the robot is the same mechanism)."""
+  rf, ri = doggo_record(yaw=0.0)
+  rf[EXT + 9:EXT + 22] = np.linspace(-0.3, 0.3, 13)
+  M0 = oracle.doggo_debug(oracle.env(rf, ri))[0]
+  rf2, _ = doggo_record(yaw=1.1)
+  rf2[EXT + 9:EXT + 22] = rf[EXT + 9:EXT + 22]
+  M1 = oracle.doggo_debug(oracle.env(rf2, ri))[0]
+  c, s = np.cos(1.1), np.sin(1.1)
+  T = np.eye(19); T[:3, :3] = [[c, -s, 0], [s, c, 0], [0, 0, 1]]   # world linear velocity rotates
+  np.testing.assert_allclose(T.T @ M1 @ T, M0, atol=1e-12)
+
+
+def test_free_fall(oracle):
+  """High above the floor, no contact: the base accelerates at -g while the springs move the legs;
+  the centre of mass follows the parabola exactly (semi-implicit Euler: z_n = z0 - g h^2 n(n+1)/2)."""
+  rf, ri = doggo_record(z=5.0)
+  rf[EXT + 9:EXT + 22] = np.deg2rad([0, -10, -20, 0, -10, -20, 0, 0, 0, -20, 0, 0, -20])  # springs relaxed
+  e = oracle.env(rf, ri)
+  n = 20
+  oracle.doggo_substeps(e, np.zeros(12), n, DT)
+  out, _ = oracle.record(e)
+  assert out[EXT] == pytest.approx(5.0 - 9.81 * DT * DT * n * (n + 1) / 2, abs=1e-9)
+  assert out[EXT + 5] == pytest.approx(-9.81 * DT * n, abs=1e-9)
+  np.testing.assert_allclose(out[EXT + 22:EXT + 35], 0, atol=1e-9)   # joints stay put
+  np.testing.assert_allclose(out[ol.F_ROBOT:ol.F_ROBOT + 2], 0, atol=1e-12)
+
+
+def test_energy_is_conserved_without_contacts(oracle):
+  """Tumbling with swinging legs in free flight: kinetic + gravitational + spring energy changes
+  only by the first-order error of semi-implicit Euler (for the free-fall part exactly
+  -m g^2 h T / 2), i.e. proportionally to h.  A wrong Coriolis / gravity / spring term would leave
+  an h-independent drift."""
+  def drift(h, n):
+    rf, ri = doggo_record(z=2.0)
+    rf[EXT + 6:EXT + 9] = [0.8, -0.5, 0.3]                       # base angular velocity
+    rf[EXT + 22:EXT + 35] = np.linspace(-1, 1, 13) * 0.5         # joint rates
+    rf[EXT + 9:EXT + 22] = np.deg2rad([5, -20, -30, 5, -20, -30, 0, 5, 40, -30, 5, 40, -30])
+    e = oracle.env(rf, ri)
+    e0 = oracle.doggo_energy(e)
+    oracle.doggo_substeps(e, np.zeros(12), n, h)
+    return oracle.doggo_energy(e) - e0
+  d1, d2, d3 = drift(0.002, 50), drift(0.0005, 200), drift(0.000125, 800)
+  assert d1 / d2 == pytest.approx(4.0, rel=0.02)
+  assert d2 / d3 == pytest.approx(4.0, rel=0.02)
+  mass = oracle.doggo_debug(oracle.env(*doggo_record()))[3]
+  # the free-fall term dominates; the rest (rotation, legs) is of the same order or smaller
+  assert abs(d3 + 0.5 * mass * 9.81**2 * 0.000125 * 0.1) < 2e-5
+
+
+def test_linear_momentum_in_free_flight(oracle):
+  """Motors, springs and joint limits are internal forces: the horizontal momentum M[0:2,:] qd is
+  constant up to the integrator's O(h) error, the vertical one changes by -m g T."""
+  def change(h, n):
+    rf, ri = doggo_record(z=50.0)
+    rf[ol.F_ROBOT + 3:ol.F_ROBOT + 5] = [0.3, -0.2]
+    rf[EXT + 6:EXT + 9] = [0.5, 0.4, -0.3]
+    rf[EXT + 9:EXT + 22] = np.deg2rad([5, -20, -30, 5, -20, -30, 0, 5, 40, -30, 5, 40, -30])
+    e = oracle.env(rf, ri)
+
+    def momentum(e):
+      M = oracle.doggo_debug(e)[0]
+      r = oracle.record(e)[0]
+      qd = np.r_[r[ol.F_ROBOT + 3:ol.F_ROBOT + 5], r[EXT + 5], r[EXT + 6:EXT + 9], r[EXT + 22:EXT + 35]]
+      return (M @ qd)[:3]
+    p0 = momentum(e)
+    ctrl = np.array([1, -1, 1, -1, 0.5, 0.5, -0.5, -0.5, 1, 1, -1, -1.0])
+    oracle.doggo_substeps(e, ctrl, n, h)
+    return momentum(e) - p0, np.abs(p0[:2]).max()
+  d1, scale = change(0.002, 60)
+  d2, _ = change(0.00025, 480)
+  mass = oracle.doggo_debug(oracle.env(*doggo_record()))[3]
+  assert np.abs(d1[:2]).max() < 0.03 * scale
+  assert np.abs(d2[:2]).max() < np.abs(d1[:2]).max() / 5     # first order in h
+  assert d2[2] == pytest.approx(-mass * 9.81 * 0.12, rel=1e-3)
+
+
+def test_settles_standing_on_the_floor(oracle):
+  """Dropped from the reset pose (z = .22, joints 0) with zero control the robot comes to rest on
+  its feet: velocities vanish, the feet carry the weight (touch sensors sum to m g), the base stays
+  above the floor and level."""
+  rf, ri = doggo_record()
+  e = oracle.env(rf, ri)
+  for _ in range(60):
+    out = oracle.step(e, DOGGO, np.zeros(12), noise=np.zeros(12))
+  r = oracle.record(e)[0]
+  mass = oracle.doggo_debug(e)[3]
+  qd = np.r_[r[ol.F_ROBOT + 3:ol.F_ROBOT + 5], r[EXT + 5:EXT + 9], r[EXT + 22:EXT + 35]]
+  assert np.abs(qd).max() < 3e-2, qd   # no joint damping in doggo.xml: the legs creep to rest
+  assert 0.05 < r[EXT] < 0.25
+  q = r[EXT + 1:EXT + 5]
+  assert abs(q[1]) < 0.05 and abs(q[2]) < 0.05              # level
+  touch = np.array(out.obs[60:68])
+  assert touch.sum() == pytest.approx(mass * 9.81, rel=0.01)
+  assert out.cost == 0 and out.done == 0
+
+
+def test_mirror_symmetry(oracle):
+  """The mechanism is symmetric about the x-z plane (legs 1<->4, 2<->3): mirrored controls give the
+  mirrored motion."""
+  # small torques, short horizon: no joint limit is reached (limit rows are solved in a fixed order)
+  a = 0.03 * np.array([0.5, -0.2, 0.3, 0.1, 0.4, 0.6, 0.3, 0.2, -0.5, -0.1, -0.7, -0.6])   # hip_z 1-4, hip_y 1-4, ankle 1-4
+  # mirror: leg 1<->4, 2<->3; hip_z axes are (0,0,1) on the left, (0,0,-1) on the right, so the
+  # mirrored hip_z angle keeps its sign; hip_y axis (0,1,0) and the ankle axes mirror into each other
+  # with the same sign convention
+  perm = [3, 2, 1, 0]
+  b = np.r_[a[0:4][perm], a[4:8][perm], a[8:12][perm]]
+  outs = []
+  for ctrl in (a, b):
+    rf, ri = doggo_record(z=50.0)   # free flight: contact rows are solved in a fixed (unmirrored) order
+    e = oracle.env(rf, ri)
+    rf[EXT + 9:EXT + 22] = np.deg2rad([5, -20, -30, 5, -20, -30, 0, 5, 40, -30, 5, 40, -30])
+    e = oracle.env(rf, ri)
+    for _ in range(2):
+      oracle.step(e, DOGGO, ctrl, noise=np.zeros(12))
+    outs.append(oracle.record(e)[0])
+  ra, rb = outs
+  assert ra[ol.F_ROBOT] == pytest.approx(rb[ol.F_ROBOT], abs=1e-9)
+  assert ra[ol.F_ROBOT + 1] == pytest.approx(-rb[ol.F_ROBOT + 1], abs=1e-9)
+  assert ra[EXT] == pytest.approx(rb[EXT], abs=1e-9)
+  assert abs(ra[ol.F_ROBOT + 1]) > 1e-6 or abs(ra[EXT + 9] - ra[EXT + 12]) > 1e-3   # not trivially symmetric
+  ja, jb = ra[EXT + 9:EXT + 22], rb[EXT + 9:EXT + 22]
+  # qpos order: leg1 (0-2), leg4 (3-5), waist (6), leg2 (7-9), leg3 (10-12)
+  np.testing.assert_allclose(ja[0:3], jb[3:6], atol=1e-9)
+  np.testing.assert_allclose(ja[7:10], jb[10:13], atol=1e-9)
+  assert ja[6] == pytest.approx(-jb[6], abs=1e-9)
+
+
+def test_joint_limits_hold(oracle):
+  """Full torque against the hip_y upper limit (15 deg): the joint ends a little beyond it (soft
+  constraint) and does not run away."""
+  rf, ri = doggo_record(z=50.0)   # free flight: only the limit stops the joint
+  e = oracle.env(rf, ri)
+  ctrl = np.zeros(12); ctrl[4] = 1.0  # hip_1_y
+  for _ in range(30):
+    oracle.step(e, DOGGO, ctrl, noise=np.zeros(12))
+  r = oracle.record(e)[0]
+  q = np.rad2deg(r[EXT + 9 + 1])
+  assert 14.0 < q < 25.0, q
+
+
+def test_observation_layout(oracle):
+  """104 = lidar 48 + accelerometer/velocimeter/gyro/magnetometer 12 + touch 8 + joint rates 12 +
+  12 x (sin, cos); at rest in the air the accelerometer reads 0 (free fall) and the magnetometer
+  R^T (0, -.5, 0)."""
+  yaw = 0.7
+  rf, ri = doggo_record(yaw=yaw, z=5.0)
+  rf[EXT + 9:EXT + 22] = np.deg2rad([0, -10, -20, 0, -10, -20, 0, 0, 0, -20, 0, 0, -20])
+  out = oracle.observe(oracle.env(rf, ri), DOGGO)
+  obs = np.array(out.obs)
+  np.testing.assert_allclose(obs[48:51], 0, atol=1e-9)
+  np.testing.assert_allclose(obs[57:60], [-0.5 * np.sin(yaw), -0.5 * np.cos(yaw), 0], atol=1e-12)
+  # jointpos order hip_1..4_z, hip_1..4_y, ankle_1..4 (doggo.xml:92-107)
+  ang = np.deg2rad([0, 0, 0, 0, -10, 0, 0, -10, -20, -20, -20, -20])
+  np.testing.assert_allclose(obs[80:104:2], np.sin(ang), atol=1e-12)
+  np.testing.assert_allclose(obs[81:104:2], np.cos(ang), atol=1e-12)
+  # lidar: the goal at (5, 5) is out of range (> 5 m): zero; a goal 1 m ahead lights its bin
+  rf[ol.F_GOAL:ol.F_GOAL + 2] = [np.cos(yaw), np.sin(yaw)]
+  obs = np.array(oracle.observe(oracle.env(rf, ri), DOGGO).obs)
+  assert obs[32] == pytest.approx(0.8, abs=1e-9)
