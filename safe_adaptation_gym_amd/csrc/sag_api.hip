@@ -7,6 +7,7 @@
 // so callers may capture it into a hipGraph.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -105,6 +106,85 @@ int ensure_scratch(sag_ctx* c, size_t bytes) {
   return 0;
 }
 
+// ---- Doggo model tables (doggo.xml), built in fp64 and copied to constant memory ----
+// Geometry numbers are the XML's: body offsets (:18-79), joint axes / ranges / springref (:21-71),
+// geoms as (from, to, radius, density) with capsules unless noted (:5-6,15,48), touch sites (:27-28 ...).
+void dg_build_model(DgModel& M) {
+  static const int parent[DG_NB] = {-1, 0, 1, 0, 3, 0, 5, 6, 5, 8};
+  static const double bpos[DG_NB][3] = {{0, 0, 0}, {.2, .1, 0}, {.098, .0566, -.05}, {.2, -.1, 0}, {.098, -.0566, -.05},
+                                        {0, 0, 0}, {-.2, .1, 0}, {.098, .0566, -.05}, {-.2, -.1, 0}, {.098, -.0566, -.05}};
+  static const int dof_body[DG_NV] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 3, 3, 4, 5, 6, 6, 7, 8, 8, 9};
+  static const double axis[DG_NJ][3] = {{0, 0, 1}, {0, 1, 0}, {-.5, .866, 0}, {0, 0, -1}, {0, 1, 0}, {.5, .866, 0}, {1, 0, 0},
+                                        {0, 0, 1}, {0, 1, 0}, {-.5, .866, 0}, {0, 0, -1}, {0, 1, 0}, {.5, .866, 0}};
+  static const double range_deg[DG_NJ][2] = {{-10, 30}, {-75, 15}, {-75, 0}, {-10, 30}, {-75, 15}, {-75, 0}, {-30, 30},
+                                             {-10, 30}, {0, 135}, {-75, 0}, {-10, 30}, {0, 135}, {-75, 0}};
+  static const double springref_deg[DG_NJ] = {0, -10, -20, 0, -10, -20, 0, 0, 0, -20, 0, 0, -20};
+  static const int act_joint[12] = {0, 7, 10, 3, 1, 8, 11, 4, 2, 9, 12, 5};
+  struct G { int body; double a[3], b[3], r, dens; bool capsule; };
+  static const G geoms[14] = {
+      {0, {0, 0, 0}, {.2, 0, 0}, .075, .5, false}, {0, {.1, 0, 0}, {.2, .1, 0}, .032, 5, true},
+      {0, {.1, 0, 0}, {.2, -.1, 0}, .032, 5, true}, {1, {0, 0, 0}, {.098, .0566, -.05}, .032, 5, true},
+      {2, {0, 0, 0}, {-.1176, -.0679, -.1}, .032, 5, true}, {3, {0, 0, 0}, {.098, -.0566, -.05}, .032, 5, true},
+      {4, {0, 0, 0}, {-.1176, .0679, -.1}, .032, 5, true}, {5, {-.2, 0, 0}, {0, 0, 0}, .075, .5, false},
+      {5, {-.1, 0, 0}, {-.2, .1, 0}, .032, 5, true}, {5, {-.1, 0, 0}, {-.2, -.1, 0}, .032, 5, true},
+      {6, {0, 0, 0}, {.098, .0566, -.05}, .032, 5, true}, {7, {0, 0, 0}, {-.1176, -.0679, -.1}, .032, 5, true},
+      {8, {0, 0, 0}, {.098, -.0566, -.05}, .032, 5, true}, {9, {0, 0, 0}, {-.1176, .0679, -.1}, .032, 5, true}};
+  struct Sp { int body; double p[3], r; int touch; };
+  static const Sp spheres[DG_NS] = {
+      {0, {0, 0, 0}, .075, -1}, {0, {.1, 0, 0}, .075, -1}, {0, {.2, 0, 0}, .075, -1},
+      {1, {0, 0, 0}, .032, -1}, {2, {0, 0, 0}, .032, 0}, {2, {-.1176, -.0679, -.1}, .032, 4},
+      {3, {0, 0, 0}, .032, -1}, {4, {0, 0, 0}, .032, 3}, {4, {-.1176, .0679, -.1}, .032, 7},
+      {5, {-.1, 0, 0}, .075, -1}, {5, {-.2, 0, 0}, .075, -1},
+      {6, {0, 0, 0}, .032, -1}, {7, {0, 0, 0}, .032, 1}, {7, {-.1176, -.0679, -.1}, .032, 5},
+      {8, {0, 0, 0}, .032, -1}, {9, {0, 0, 0}, .032, 2}, {9, {-.1176, .0679, -.1}, .032, 6}};
+  const double pi = 3.14159265358979323846;
+  memset(&M, 0, sizeof(M));
+  for (int b = 0; b < DG_NB; b++) {
+    M.parent[b] = parent[b];
+    for (int k = 0; k < 3; k++) M.bpos[b][k] = bpos[b][k];
+    unsigned anc = 0;
+    for (int a = b; a >= 0; a = parent[a]) anc |= 1u << a;
+    M.anc[b] = anc;
+  }
+  for (int i = 0; i < DG_NV; i++) M.dof_body[i] = dof_body[i];
+  for (int j = 0; j < DG_NJ; j++) {
+    const double n = std::sqrt(axis[j][0] * axis[j][0] + axis[j][1] * axis[j][1] + axis[j][2] * axis[j][2]);
+    for (int k = 0; k < 3; k++) M.axis[j][k] = axis[j][k] / n;
+    M.lo[j] = range_deg[j][0] * pi / 180; M.hi[j] = range_deg[j][1] * pi / 180;
+    M.springref[j] = springref_deg[j] * pi / 180;
+  }
+  for (int k = 0; k < 12; k++) M.act_joint[k] = act_joint[k];
+  double gm[14], gc[14][3], gI[14][9];
+  for (int g = 0; g < 14; g++) {
+    const G& q = geoms[g];
+    const double d[3] = {q.b[0] - q.a[0], q.b[1] - q.a[1], q.b[2] - q.a[2]};
+    const double L = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), r = q.r;
+    const double u[3] = {d[0] / L, d[1] / L, d[2] / L};
+    const double mc = q.dens * pi * r * r * L, ms = q.capsule ? q.dens * 4.0 / 3.0 * pi * r * r * r : 0.0;
+    const double Ia = mc * r * r / 2 + ms * 2 * r * r / 5;
+    const double It = mc * (r * r / 4 + L * L / 12) + ms * (2 * r * r / 5 + L * L / 4 + 3 * L * r / 8);
+    gm[g] = mc + ms;
+    for (int k = 0; k < 3; k++) gc[g][k] = 0.5 * (q.a[k] + q.b[k]);
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) gI[g][3 * a + b] = It * ((a == b ? 1.0 : 0.0) - u[a] * u[b]) + Ia * u[a] * u[b];
+    M.m[q.body] += gm[g];
+    for (int k = 0; k < 3; k++) M.com[q.body][k] += gm[g] * gc[g][k];
+  }
+  for (int b = 0; b < DG_NB; b++)
+    for (int k = 0; k < 3; k++) M.com[b][k] /= M.m[b];
+  for (int g = 0; g < 14; g++) {
+    const int b = geoms[g].body;
+    const double d[3] = {gc[g][0] - M.com[b][0], gc[g][1] - M.com[b][1], gc[g][2] - M.com[b][2]};
+    const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    for (int a = 0; a < 3; a++)
+      for (int c = 0; c < 3; c++) M.I[b][3 * a + c] += gI[g][3 * a + c] + gm[g] * ((a == c ? d2 : 0.0) - d[a] * d[c]);
+  }
+  for (int s = 0; s < DG_NS; s++) {
+    M.sph_body[s] = spheres[s].body; M.sph_touch[s] = spheres[s].touch; M.sph_r[s] = spheres[s].r;
+    for (int k = 0; k < 3; k++) M.sph_p[s][k] = spheres[s].p[k];
+  }
+}
+
 // drain finished timing events into the running mean
 void drain_events(sag_ctx* c) {
   for (size_t k = 0; k < c->ev_used; k++) {
@@ -119,8 +199,6 @@ void drain_events(sag_ctx* c) {
 int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint32_t* d_tape,
                 int tape_len, int nstep, float* d_obs, float* d_rew, uint8_t* d_cost,
                 uint8_t* d_done, uint8_t* d_met, int32_t* d_used, int observe_only) {
-  if (c->cfg.robot == SAG_ROBOT_DOGGO)
-    return fail(c, SAG_ERR_UNSUPPORTED, "the Doggo robot has no device integrator in this build");
   StepArgs a;
   a.S = c->S; a.I = c->I; a.N = c->N;
   a.actions = d_act; a.noise = d_noise; a.tape = d_tape; a.tape_len = tape_len;
@@ -155,7 +233,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   const bool btn = c->cfg.max_buttons > 0, tbox = c->cfg.has_box != 0;
   // split form: QUIET kernel over every env whose busy bit is clear, then BUSY kernel over the
   // rest (compacted per 256-env neighbourhood).  observe() and SAG_SPLIT=0 use the single form.
-  const bool split = c->split && !observe_only;
+  const bool split = c->split && !observe_only && c->cfg.robot != SAG_ROBOT_DOGGO;
   if (split) {
     HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
@@ -178,7 +256,10 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     else SAG_LAUNCH3(ROB, true, true);             \
   } while (0)
   if (c->cfg.robot == SAG_ROBOT_POINT) SAG_LAUNCH(SAG_ROBOT_POINT);
-  else SAG_LAUNCH(SAG_ROBOT_CAR);
+  else if (c->cfg.robot == SAG_ROBOT_CAR) SAG_LAUNCH(SAG_ROBOT_CAR);
+  else {  // Doggo: one (buttons + task object) instance, single-launch form
+    hipLaunchKernelGGL((k_step<SAG_ROBOT_DOGGO, true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
+  }
 #undef SAG_LAUNCH
 #undef SAG_LAUNCH3
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
@@ -258,6 +339,11 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->d_done, N));
   CREATE_CHK(hipMalloc(&c->d_met, N));
   CREATE_CHK(hipMalloc(&c->d_used, N * sizeof(int32_t)));
+  if (cfg->robot == SAG_ROBOT_DOGGO) {
+    DgModel model;
+    dg_build_model(model);
+    CREATE_CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dg), &model, sizeof(model)));
+  }
   CREATE_CHK(hipMemsetAsync(c->S, 0, N * SAG_REC_FLOATS * sizeof(float), c->stream));
   CREATE_CHK(hipMemsetAsync(c->I, 0, N * DI_COUNT * sizeof(int32_t), c->stream));
   CREATE_CHK(hipStreamSynchronize(c->stream));

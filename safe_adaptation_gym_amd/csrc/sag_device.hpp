@@ -408,6 +408,9 @@ __device__ unsigned long long g_cyc[3][CY_N + 1];
 #define CYC(k) do {} while (0)
 #define CYC_FLUSH(mode) do {} while (0)
 #endif
+}  // namespace sag
+#include "sag_doggo.hpp"
+namespace sag {
 #define SF(k) S[(size_t)(k) * N + i]
 #define LP(base, k) lds[((base) + (k)) * WAVE + lane]
 #define POOL(d, c) lds[(LS_POOL + (d) * 6 + (c)) * WAVE + lane]
@@ -526,6 +529,240 @@ __device__ inline void lidar_point(float* lds, int lane, double rx, double ry, d
 //         step (classified conservatively at the end of the previous step), so all contact code
 //         is compiled out: small, high-occupancy, close to the memory roofline;
 //  BUSY   the envs whose bit is set, compacted (k_compact) into full wavefronts, full physics.  QUIET + BUSY together do exactly what ALL does (tests compare them).
+// Doggo lidar: the base is tilted, so e = (d @ R)[:2] with d = [p_xy, 0] - robot_xpos
+// (safe_adaptation_gym.py:197-216) has a -z R[2,:2] term; evaluated in fp64 as the reference does
+template <int STG_STRIDE>
+__device__ inline void lidar_point_tilted(float* lds, int lane, const double* pos, const double* Rm, float px, float py) {
+  const double dx = (double)px - pos[0], dy = (double)py - pos[1], dz = -pos[2];
+  const double EX = Rm[0] * dx + Rm[3] * dy + Rm[6] * dz;
+  const double EY = Rm[1] * dx + Rm[4] * dy + Rm[7] * dz;
+  const double two_pi = PI_D * 2, bin_size = two_pi / SAG_LIDAR_BINS;
+  double a = atan2(EY, EX);
+  if (a < 0) a += two_pi;
+  int bin = (int)(a / bin_size);
+  if (bin >= SAG_LIDAR_BINS) bin -= SAG_LIDAR_BINS;
+  const float alias = (float)((a - bin_size * bin) / bin_size);
+  const double Dd = hypot(EX, EY);
+  const float sensor = (float)((5.0 - Dd > 0 ? 5.0 - Dd : 0.0) / 5.0);
+  const int bp = (bin + 1) & 15, bm = (bin + 15) & 15;
+  int* o = reinterpret_cast<int*>(&STG(0));
+  atomicMax(o + bin, __float_as_int(sensor));
+  atomicMax(o + bp, __float_as_int(alias * sensor));
+  atomicMax(o + bm, __float_as_int((1.0f - alias) * sensor));
+}
+
+// ---------------------------------------------------------------------------
+// Doggo: the substep loop (specification: oracle/sag_oracle_doggo.inc + world_forward order).
+// Robot rows (joint limits, floor, pillars, buttons, vases, task object, HaulBox tether) go through
+// one projected Gauss-Seidel in fp64; the planar free bodies keep the fp32 arithmetic and the pair
+// order of the Point/Car kernels, without the sleeping-body shortcut (every body is processed; a
+// resting body is a fixed point of the update, so the result is the same).
+// ---------------------------------------------------------------------------
+struct DgResult {
+  double qacc_lin[3], touch[8], comvel[4];
+  int cost_contacts;
+  uint32_t btn_mask;
+};
+
+__device__ inline void dg_body_view(const DgWorld& Wd, int k, BV& V, float& c, float& s) {
+  const float* B = Wd.fb[k];
+  V.x = B[0]; V.y = B[1]; V.vx = B[3]; V.vy = B[4]; V.w = B[5]; V.ax = B[6]; V.ay = B[7]; V.aw = B[8];
+  sincosf(B[2], &s, &c);
+  const float* m = Wd.minv[k];
+  V.m0 = m[0]; V.m1 = m[1]; V.m2 = m[2]; V.m3 = m[3]; V.m4 = m[4]; V.m5 = m[5]; V.dyn = 1;
+}
+
+// floor friction + semi-implicit Euler + rest capture of one planar free body (the block of
+// step_body, on the [x y yaw vx vy w ax ay aw] layout)
+__device__ __attribute__((noinline)) void dg_free_body_finish(float* B, bool is_task_obj, const BodyK& vk,
+                                                              const BodyK& bk, float bc, float h) {
+  float vx_ = B[3], vy_ = B[4], w_ = B[5], ax_ = B[6], ay_ = B[7], aw_ = B[8];
+  if (!is_task_obj || bk.sh == SH_BOX) {
+    const float mm = !is_task_obj ? vk.m : bk.m, II = !is_task_obj ? vk.I : bk.I, rr = !is_task_obj ? vk.reff : bk.reff;
+    const float fmax_ = MU * GRAV * mm;
+    float fx = -SOL_D0 * mm * (bc * vx_ + ax_), fy = -SOL_D0 * mm * (bc * vy_ + ay_);
+    const float f2 = fx * fx + fy * fy;
+    if (f2 > fmax_ * fmax_) { const float sc = fmax_ / sqrtf(f2); fx *= sc; fy *= sc; }
+    ax_ += fx / mm; ay_ += fy / mm;
+    const float t = clampf(-SOL_D0 * II * (bc * w_ + aw_), -fmax_ * rr, fmax_ * rr);
+    aw_ += t / II;
+  } else {
+    float c, s; sincosf(B[2], &s, &c);
+    float bvx = c * vx_ + s * vy_, bvy = -s * vx_ + c * vy_, bax = c * ax_ + s * ay_, bay = -s * ax_ + c * ay_;
+    const float mg = bk.m * GRAV;
+    float tlim;
+    if (bk.sh == SH_ROD) {
+      const float mx = 1.5f * bk.m, lx = 0.05f * mg / 0.08f, ly = 1.2f * mg;
+      const float fx = clampf(-SOL_D0 * mx * (bc * bvx + bax), -lx, lx);
+      const float fy = clampf(-SOL_D0 * bk.m * (bc * bvy + bay), -ly, ly);
+      bax += fx / mx; bay += fy / bk.m;
+      tlim = 1.2f * mg * 0.15f;
+    } else {
+      const float me = 1.4f * bk.m, lim = 0.05f * mg / 0.14f;
+      float fx = -SOL_D0 * me * (bc * bvx + bax), fy = -SOL_D0 * me * (bc * bvy + bay);
+      const float f2 = fx * fx + fy * fy;
+      if (f2 > lim * lim) { const float sc = lim / sqrtf(f2); fx *= sc; fy *= sc; }
+      bax += fx / me; bay += fy / me;
+      tlim = 0.003f * mg;
+    }
+    ax_ = c * bax - s * bay; ay_ = s * bax + c * bay;
+    aw_ += clampf(-SOL_D0 * bk.I * (bc * w_ + aw_), -tlim, tlim) / bk.I;
+  }
+  vx_ += h * ax_; vy_ += h * ay_; w_ += h * aw_;
+  if (fabsf(vx_) < REST_V && fabsf(vy_) < REST_V && fabsf(w_) < REST_W && fabsf(h * ax_) < REST_V &&
+      fabsf(h * ay_) < REST_V && fabsf(h * aw_) < REST_W) { vx_ = 0; vy_ = 0; w_ = 0; }
+  B[3] = vx_; B[4] = vy_; B[5] = w_;
+  B[0] += h * vx_; B[1] += h * vy_; B[2] += h * w_;
+}
+
+__device__ __attribute__((noinline)) void doggo_physics(
+    DgState& D, DgWorld& Wd, DgResult& out, const float* ctrl12, int nsub, float hf, const float* stx,
+    const float* sty, int nP, int nB, float psz, float vsz, const BodyK& vk, const BodyK& bk, const Sol& sol0,
+    const Sol& solb, int nV, bool has_box, bool haul) {
+  DgWork K;
+  DgRows R;
+  const DgModel& M = g_dg;
+  const double h = (double)hf;
+  const float vase_r = vk.reff, box_r = shape_bound(bk.sh, vsz, 0);
+  const double top_vase = 2.0 * (double)vsz;
+  const double top_box = bk.sh == SH_ROD ? 0.16 : (bk.sh == SH_BALL ? 0.28 : 0.4);
+  out.cost_contacts = 0; out.btn_mask = 0;
+#pragma unroll 1
+  for (int sub = 0; sub <= nsub; sub++) {
+    for (int k = 0; k < NBODY; k++) { Wd.fb[k][6] = 0; Wd.fb[k][7] = 0; Wd.fb[k][8] = 0; }
+    if (has_box && bk.sh == SH_ROD) {
+      float c, s; sincosf(Wd.fb[BOX_ID][2], &s, &c);
+      const float ix = 1.0f / (1.5f * bk.m), iy = 1.0f / bk.m;
+      Wd.minv[BOX_ID][0] = c * c * ix + s * s * iy; Wd.minv[BOX_ID][1] = c * s * (ix - iy);
+      Wd.minv[BOX_ID][3] = s * s * ix + c * c * iy;
+    }
+    // ---- robot: smooth dynamics -----------------------------------------------------
+    double bias[DG_NV], tau[DG_NV], qd[DG_NV];
+    dg_kinematics(D, K);
+    dg_mass_matrix(K);
+    dg_bias(D, K, bias);
+    dg_qd(D, qd);
+    for (int k = 0; k < DG_NV; k++) tau[k] = 0;
+    for (int j = 0; j < DG_NJ; j++) tau[6 + j] = -DG_STIFF * (D.q[j] - M.springref[j]);
+    for (int k = 0; k < 12; k++) tau[6 + M.act_joint[k]] += DG_GEAR * (double)ctrl12[k];
+    for (int k = 0; k < DG_NV; k++) tau[k] -= bias[k];
+    if (!dg_cholesky(K.L)) {  // not positive definite: the state is already broken (PhysicsError)
+      D.pos[0] = __longlong_as_double(0x7ff8000000000000ll);
+      break;
+    }
+    dg_solve(K.L, tau, K.qacc);
+    for (int k = 0; k < 8; k++) K.touch[k] = 0;
+    R.n = 0;
+    // ---- rows: joint limits, floor, pillars, buttons, vases, task object, tether ----
+#pragma unroll 1
+    for (int j = 0; j < DG_NJ; j++) {
+      double depth = 0, sign = 0;
+      if (D.q[j] < M.lo[j]) { depth = M.lo[j] - D.q[j]; sign = 1; }
+      else if (D.q[j] > M.hi[j]) { depth = D.q[j] - M.hi[j]; sign = -1; }
+      if (sign == 0) continue;
+      double J[DG_NV];
+      for (int k = 0; k < DG_NV; k++) J[k] = 0;
+      J[6 + j] = 1;
+      DgRow* r = dg_add_row(R, K, Wd, J, sign, -1, 0, 0, 0, 0);
+      if (!r) break;
+      r->imp = dg_impedance(depth);
+      r->aref = -(double)sol0.bcoef * dg_row_vel(*r, Wd, qd) + (double)sol0.kcoef * depth;
+    }
+#pragma unroll 1
+    for (int s = 0; s < DG_NS; s++) {
+      const double depth = M.sph_r[s] - K.sph[s][2];
+      if (depth <= 0) continue;
+      const double n[3] = {0, 0, 1}, c[3] = {K.sph[s][0], K.sph[s][1], 0.5 * (K.sph[s][2] - M.sph_r[s])};
+      dg_add_contact(R, D, K, Wd, qd, s, n, c, depth, -1, (double)sol0.bcoef, (double)sol0.kcoef, (double)MU);
+    }
+    int cc = 0;
+    uint32_t mask = 0;
+#pragma unroll 1
+    for (int q = 0; q < nP; q++)
+      cc += dg_collide_body(R, D, K, Wd, qd, -1, SH_STATIC, stx[q], sty[q], 0.f, psz, vsz, psz, 1.0,
+                            (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu);
+#pragma unroll 1
+    for (int b = 0; b < nB; b++)
+      if (dg_collide_body(R, D, K, Wd, qd, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f,
+                          BUTTON_R, vsz, BUTTON_R, 0.2, (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu))
+        mask |= 1u << b;
+#pragma unroll 1
+    for (int k = 0; k < nV; k++)
+      cc += dg_collide_body(R, D, K, Wd, qd, k, SH_VASE, Wd.fb[k][0], Wd.fb[k][1], Wd.fb[k][2], vase_r, vsz, 0.f,
+                            top_vase, (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu);
+    if (has_box) {
+      dg_collide_body(R, D, K, Wd, qd, BOX_ID, bk.sh, Wd.fb[BOX_ID][0], Wd.fb[BOX_ID][1], Wd.fb[BOX_ID][2], box_r,
+                      vsz, 0.f, top_box, (double)solb.bcoef, (double)solb.kcoef, (double)solb.mu);
+      if (haul) {  // haul_box.py:21-29: tendon base site <-> box site (z .2), range [0, .75]
+        const double dx = (double)Wd.fb[BOX_ID][0] - D.pos[0], dy = (double)Wd.fb[BOX_ID][1] - D.pos[1], dz = 0.2 - D.pos[2];
+        const double d2 = dx * dx + dy * dy, Lt = sqrt(d2 + dz * dz), viol = Lt - 0.75;
+        if (viol > 0 && d2 >= 1e-18) {
+          const double j[3] = {dx / Lt, dy / Lt, dz / Lt};
+          double J[DG_NV];
+          dg_jac(D, K, 0, D.pos, j, J);
+          DgRow* r = dg_add_row(R, K, Wd, J, 1.0, BOX_ID, -j[0], -j[1], (double)Wd.fb[BOX_ID][0], (double)Wd.fb[BOX_ID][1]);
+          if (r) {
+            r->imp = dg_impedance(viol);
+            r->aref = -(double)sol0.bcoef * dg_row_vel(*r, Wd, qd) + (double)sol0.kcoef * viol;
+          }
+        }
+      }
+    }
+    dg_pgs(R, K, Wd);
+    for (int k = 0; k < R.n; k++)
+      if (R.row[k].touch >= 0 && R.row[k].parent < 0) K.touch[R.row[k].touch] += R.row[k].f;
+    out.cost_contacts = cc; out.btn_mask = mask;
+    if (sub == nsub) break;
+    // ---- planar world: free bodies vs statics, free-body pairs, friction, integration ----
+#pragma unroll 1
+    for (int k = 0; k < NBODY; k++) {
+      const bool isb = k == BOX_ID;
+      if (isb ? !has_box : k >= nV) continue;
+      const float br = isb ? box_r : vase_r;
+#pragma unroll 1
+      for (int q = 0; q < SAG_MAX_PILLARS + nB; q++) {
+        if (q == nP && q < SAG_MAX_PILLARS) q = SAG_MAX_PILLARS;
+        if (q >= SAG_MAX_PILLARS + nB) break;
+        const bool is_p = q < SAG_MAX_PILLARS;
+        const float sr = is_p ? psz : BUTTON_R;
+        const float dx = stx[q] - Wd.fb[k][0], dyy = sty[q] - Wd.fb[k][1], rs = br + sr;
+        if (dx * dx + dyy * dyy > rs * rs) continue;
+        BV V; float cv, sv; dg_body_view(Wd, k, V, cv, sv);
+        BV St; St.x = stx[q]; St.y = sty[q]; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
+        St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
+        collide_shapes(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
+        Wd.fb[k][6] = V.ax; Wd.fb[k][7] = V.ay; Wd.fb[k][8] = V.aw;
+      }
+    }
+#pragma unroll 1
+    for (int a = 0; a < nV; a++)
+#pragma unroll 1
+      for (int b = a + 1; b < NBODY; b++) {
+        const bool isb = b == BOX_ID;
+        if (isb ? !has_box : b >= nV) continue;
+        const float dx = Wd.fb[b][0] - Wd.fb[a][0], dyy = Wd.fb[b][1] - Wd.fb[a][1], rs = vase_r + (isb ? box_r : vase_r);
+        if (dx * dx + dyy * dyy > rs * rs) continue;
+        BV A, B; float ca, sa, cb, sb;
+        dg_body_view(Wd, a, A, ca, sa);
+        dg_body_view(Wd, b, B, cb, sb);
+        if (collide_shapes(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0)) {
+          Wd.fb[a][6] = A.ax; Wd.fb[a][7] = A.ay; Wd.fb[a][8] = A.aw;
+          Wd.fb[b][6] = B.ax; Wd.fb[b][7] = B.ay; Wd.fb[b][8] = B.aw;
+        }
+      }
+    dg_integrate(D, K.qacc, h);
+#pragma unroll 1
+    for (int k = 0; k < NBODY; k++) {
+      const bool isb = k == BOX_ID;
+      if (isb ? !has_box : k >= nV) continue;
+      dg_free_body_finish(Wd.fb[k], isb, vk, bk, sol0.bcoef, hf);
+    }
+  }
+  for (int k = 0; k < 3; k++) out.qacc_lin[k] = K.qacc[k];
+  for (int k = 0; k < 8; k++) out.touch[k] = K.touch[k];
+  dg_com_vel(D, K, out.comvel);
+}
+
 enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2 };
 // two copies of the busy bit, used alternately (StepArgs::phase): a launch reads bit 28 + phase and
 // writes bit 28 + (phase ^ 1), so the QUIET launch cannot re-flag an env for the BUSY launch of
@@ -537,11 +774,14 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
                                           const bool live, const int base_env, const int nvalid,
                                           const uint64_t skip_mask, const int* rows) {
   constexpr int NSTAT = SAG_MAX_PILLARS + (HAS_BTN ? SAG_MAX_BUTTONS : 0);
-  constexpr bool CAR = ROBOT == SAG_ROBOT_CAR;
+  constexpr bool CAR = ROBOT == SAG_ROBOT_CAR, DOGGO = ROBOT == SAG_ROBOT_DOGGO;
+  static_assert(!DOGGO || MODE == MODE_ALL, "Doggo runs the single-launch form");
   constexpr bool QUIET = MODE == MODE_QUIET;
   constexpr int SH_ME = CAR ? SH_CAR : SH_ROBOT;
-  constexpr int OBS_DIM = CAR ? 72 : 60, NSENS = OBS_DIM - 48;
-  constexpr int STG_STRIDE = CAR ? 25 : 17;
+  constexpr int OBS_DIM = DOGGO ? 104 : (CAR ? 72 : 60);
+  // sensor columns per staged chunk: Doggo's 56 go out as two chunks of 28
+  constexpr int NSENS = DOGGO ? 28 : OBS_DIM - 48, NCHUNK = DOGGO ? 5 : 4;
+  constexpr int STG_STRIDE = DOGGO ? 29 : (CAR ? 25 : 17);
   static_assert(STG_BASE + WAVE * STG_STRIDE <= LDS_FLOATS, "staging tile must fit");
   CYC_DECL
   const float my_bound = shape_bound(SH_ME, 0.f, 0.f);
@@ -573,9 +813,11 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   float last0 = SF(SAG_F_LAST);
   float a0 = 0, a1 = 0, n0 = 0, n1 = 0;
   if (!p.observe_only) {
-    const float2 a = reinterpret_cast<const float2*>(p.actions)[i];
-    a0 = a.x; a1 = a.y;
-    if (p.noise) { const float2 z = reinterpret_cast<const float2*>(p.noise)[i]; n0 = z.x; n1 = z.y; }
+    if constexpr (!DOGGO) {
+      const float2 a = reinterpret_cast<const float2*>(p.actions)[i];
+      a0 = a.x; a1 = a.y;
+      if (p.noise) { const float2 z = reinterpret_cast<const float2*>(p.noise)[i]; n0 = z.x; n1 = z.y; }
+    }
   }
   {
     float vpos[NBODY * 3];
@@ -617,8 +859,30 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 
   // ---- action noise + clip (safe_adaptation_gym.py:58-67) ---------------------
   float ctrl0 = 0, ctrl1 = 0;
+  float ctrl12[DOGGO ? 12 : 1] = {};
+  if constexpr (DOGGO) {
+    if (!p.observe_only) {
+      const float an = SF(SAG_F_ACTION_NOISE);
+#pragma unroll 1
+      for (int j = 0; j < 12; j += 2) {
+        float z0, z1;
+        if (p.noise) { z0 = p.noise[(size_t)i * 12 + j]; z1 = p.noise[(size_t)i * 12 + j + 1]; }
+        else {
+          uint32_t c[4] = {rng.env, rng.step, (uint32_t)(j >> 1), 1u};
+          philox4x32_10(c, p.key0, p.key1);
+          const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+          const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+          const float r = sqrtf(-2.0f * logf(u1)), a = 6.28318530717958647692f * u2;
+          z0 = r * cosf(a); z1 = r * sinf(a);
+        }
+        const float l0 = SF(SAG_F_CTRL_SCALE + j), l1 = SF(SAG_F_CTRL_SCALE + j + 1);
+        ctrl12[j] = clampf(p.actions[(size_t)i * 12 + j] + an * z0, -l0, l0);
+        ctrl12[j + 1] = clampf(p.actions[(size_t)i * 12 + j + 1] + an * z1, -l1, l1);
+      }
+    }
+  }
   if (!p.observe_only) {
-    if (!p.noise) {
+    if (!p.noise && !DOGGO) {
       uint32_t c[4] = {rng.env, rng.step, 0u, 1u};
       philox4x32_10(c, p.key0, p.key1);
       float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -708,6 +972,51 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   float cy = 1, sy = 0;
 
   CYC(CY_LOAD);
+  // Doggo: its own substep loop (doggo_physics); state in private memory
+  DgState dgs;
+  DgResult dgr;
+  double dg_rot[DOGGO ? 9 : 1] = {};  // base rotation matrix (lidar, sensors)
+  if constexpr (DOGGO) {
+    DgWorld Wd;
+    dg_load(dgs, S, (size_t)N, (size_t)i);
+    for (int k = 0; k < NBODY; k++) {
+      const bool isb = k == BOX_ID;
+      const bool on = isb ? has_box : k < nV;
+      const int f = isb ? SAG_F_BOX : SAG_F_VASES + 6 * k;
+      Wd.fb[k][0] = LP(LS_X, k); Wd.fb[k][1] = LP(LS_Y, k); Wd.fb[k][2] = LP(LS_YAW, k);
+      Wd.fb[k][3] = on ? SF(f + 3) : 0.f; Wd.fb[k][4] = on ? SF(f + 4) : 0.f; Wd.fb[k][5] = on ? SF(f + 5) : 0.f;
+      for (int c = 0; c < 6; c++) Wd.minv[k][c] = 0;
+      if (!isb) { Wd.minv[k][0] = Wd.minv[k][3] = 1.0f / vk.m; Wd.minv[k][5] = 1.0f / vk.I; }
+      else {
+        Wd.minv[k][5] = 1.0f / bk.I;
+        Wd.minv[k][0] = Wd.minv[k][3] = bk.sh == SH_BALL ? 1.0f / (1.4f * bk.m) : 1.0f / bk.m;  // rod: per substep
+      }
+    }
+    doggo_physics(dgs, Wd, dgr, ctrl12, nsub, h, stx, sty, nP, nB, psz, vsz, vk, bk, sol0, solb, nV, has_box,
+                  HAS_TBOX && task == SAG_TASK_HAUL_BOX);
+    cost_contacts = dgr.cost_contacts; btn_mask = dgr.btn_mask;
+    float wz;
+    if (!p.observe_only && live) dg_store(dgs, S, (size_t)N, (size_t)i, yaw, wz);
+    else { double Rm[9], ww[3]; dg_quat2mat(dgs.quat, Rm); dg_matvec(Rm, dgs.wloc, ww); yaw = (float)atan2(Rm[3], Rm[0]); wz = (float)ww[2]; }
+    {
+      double Rm[9];
+      dg_quat2mat(dgs.quat, Rm);
+      for (int k = 0; k < 9; k++) dg_rot[k] = Rm[k];
+    }
+    R.x = (float)dgs.pos[0]; R.y = (float)dgs.pos[1]; R.vx = (float)dgs.vlin[0]; R.vy = (float)dgs.vlin[1]; R.w = wz;
+    R.ax = (float)dgr.qacc_lin[0]; R.ay = (float)dgr.qacc_lin[1];
+    awake = 0;
+    for (int k = 0; k < NBODY; k++) {
+      const bool isb = k == BOX_ID;
+      if (isb ? !has_box : k >= nV) continue;
+      LP(LS_X, k) = Wd.fb[k][0]; LP(LS_Y, k) = Wd.fb[k][1]; LP(LS_YAW, k) = Wd.fb[k][2];
+      if (Wd.fb[k][3] != 0 || Wd.fb[k][4] != 0 || Wd.fb[k][5] != 0) awake |= 1u << k;
+      if (!p.observe_only && live) {
+        const int f = isb ? SAG_F_BOX : SAG_F_VASES + 6 * k;
+        for (int c = 0; c < 6; c++) SF(f + c) = Wd.fb[k][c];
+      }
+    }
+  } else {
 #pragma unroll 1
   for (int sub = 0; sub <= nsub; sub++) {
     sincosf(yaw, &sy, &cy);
@@ -987,12 +1296,15 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
   }
 
+  }  // !DOGGO
   CYC(CY_ROBOT);
   // ---- write back dynamic state -------------------------------------------------
   const float boxx = LP(LS_X, BOX_ID), boxy = LP(LS_Y, BOX_ID);
   if (!p.observe_only && live) {
-    SF(SAG_F_ROBOT) = R.x; SF(SAG_F_ROBOT + 1) = R.y; SF(SAG_F_ROBOT + 2) = yaw;
-    SF(SAG_F_ROBOT + 3) = R.vx; SF(SAG_F_ROBOT + 4) = R.vy; SF(SAG_F_ROBOT + 5) = R.w;
+    if constexpr (!DOGGO) {
+      SF(SAG_F_ROBOT) = R.x; SF(SAG_F_ROBOT + 1) = R.y; SF(SAG_F_ROBOT + 2) = yaw;
+      SF(SAG_F_ROBOT + 3) = R.vx; SF(SAG_F_ROBOT + 4) = R.vy; SF(SAG_F_ROBOT + 5) = R.w;
+    }
     if constexpr (CAR) {
 #pragma unroll
       for (int k = 0; k < 9; k++) SF(SAG_F_ROBOT_EXT + k) = ext[k];
@@ -1055,6 +1367,12 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     float v[6] = {R.x, R.y, yaw, R.vx, R.vy, R.w};
 #pragma unroll
     for (int k = 0; k < 6; k++) bad |= !(fabsf(v[k]) <= 1e10f);
+    if constexpr (DOGGO) {
+      bad |= !(fabs(dgs.pos[2]) <= 1e10) || !(fabs(dgs.vlin[2]) <= 1e10);
+      for (int k = 0; k < 4; k++) bad |= !(fabs(dgs.quat[k]) <= 1e10);
+      for (int k = 0; k < 3; k++) bad |= !(fabs(dgs.wloc[k]) <= 1e10);
+      for (int k = 0; k < DG_NJ; k++) bad |= !(fabs(dgs.q[k]) <= 1e10) || !(fabs(dgs.qd[k]) <= 1e10);
+    }
   }
 
   // ---- reward (tasks/<task>.py compute_reward), fp64 from the fp32 state -----------
@@ -1097,7 +1415,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     } else if (!has_box) {
       // GoToGoal family (tasks/go_to_goal.py:31-45): 3-D distance incl. dz
       double gx = goalx, gy = goaly;
-      double dx = rx - gx, dyy = ry - gy, dz = PT_Z - GOAL_Z;
+      double dx = rx - gx, dyy = ry - gy, dz = (DOGGO ? (double)(float)dgs.pos[2] : (double)PT_Z) - GOAL_Z;
       double dist = sqrt(dx * dx + dyy * dyy + dz * dz);
       double r = (double)last0 - dist;
       if (task == SAG_TASK_GO_TO_GOAL_SCARCE) r *= (dist <= GOAL_SIZE * 1.5) ? 1.0 : 0.0;
@@ -1111,6 +1429,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         const double lx = c * bx_ - s * by_, ly = s * bx_ + c * by_;
         double x = rx + lx, y = ry + ly, w = R.w;
         double u = (double)R.vx - w * ly, v = (double)R.vy + w * lx;
+        if constexpr (DOGGO) { x = dgr.comvel[0]; y = dgr.comvel[1]; u = dgr.comvel[2]; v = dgr.comvel[3]; }
         double radius = sqrt(x * x + y * y);
         rew0 = (((-u * y + v * x) / radius) / (1 + fabs(radius - 1.5))) * 1e-1;
         rew1 = r;
@@ -1275,9 +1594,33 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     // slots of envs this launch does not own are skipped
     auto row_ok = [&](int e) { return e < nvalid && !(skip_mask >> e & 1ull); };
     auto row_of = [&](int e) { return (size_t)(MODE == MODE_BUSY ? rows[e] : base_env + e); };
+    auto lid = [&](float px, float py) {
+      if constexpr (DOGGO) lidar_point_tilted<STG_STRIDE>(lds, lane, dgs.pos, dg_rot, px, py);
+      else lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, px, py);
+    };
+    // Doggo sensors (doggo.xml:83-126 via safe_adaptation_gym.py:225-237): accelerometer, velocimeter,
+    // gyro, magnetometer, 8 touch, 12 joint rates, 12 x (sin, cos)
+    float dsens[DOGGO ? 56 : 1] = {};
+    if constexpr (DOGGO) {
+      const double a3[3] = {bad ? 0.0 : dgr.qacc_lin[0], bad ? 0.0 : dgr.qacc_lin[1], (bad ? 0.0 : dgr.qacc_lin[2]) + (double)GRAV};
+      const double m3[3] = {0, -0.5, 0};
+      for (int k = 0; k < 3; k++) {
+        dsens[k] = (float)(dg_rot[k] * a3[0] + dg_rot[3 + k] * a3[1] + dg_rot[6 + k] * a3[2]);
+        dsens[3 + k] = (float)(dg_rot[k] * dgs.vlin[0] + dg_rot[3 + k] * dgs.vlin[1] + dg_rot[6 + k] * dgs.vlin[2]);
+        dsens[6 + k] = (float)dgs.wloc[k];
+        dsens[9 + k] = (float)(dg_rot[k] * m3[0] + dg_rot[3 + k] * m3[1] + dg_rot[6 + k] * m3[2]);
+      }
+      for (int k = 0; k < 8; k++) dsens[12 + k] = (float)dgr.touch[k];
+      for (int k = 0; k < 12; k++) {
+        const int j = g_dg.act_joint[k];
+        dsens[20 + k] = (float)dgs.qd[j];
+        dsens[32 + 2 * k] = (float)sin(dgs.q[j]);
+        dsens[33 + 2 * k] = (float)cos(dgs.q[j]);
+      }
+    }
     __syncthreads();  // physics is done with the yaw / pool slots everywhere in the wavefront
 #pragma unroll 1
-    for (int chunk = 0; chunk < 4; chunk++) {
+    for (int chunk = 0; chunk < NCHUNK; chunk++) {
       if (chunk < 3) {
 #pragma unroll
         for (int k = 0; k < 16; k++) STG(k) = 0.0f;
@@ -1285,27 +1628,28 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (chunk == 0 && !ABL(ABL_NO_LIDAR)) {
 #pragma unroll 1
         for (int k = 0; k < SAG_MAX_HAZARDS; k++)
-          if (k < nH) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, hzx[k], hzy[k]);
+          if (k < nH) lid(hzx[k], hzy[k]);
 #pragma unroll 1
         for (int k = 0; k < nV; k++)
-          lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, LP(LS_X, k), LP(LS_Y, k));
+          lid(LP(LS_X, k), LP(LS_Y, k));
 #pragma unroll 1
         for (int k = 0; k < SAG_MAX_PILLARS; k++)
-          if (k < nP) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, stx[k], sty[k]);
+          if (k < nP) lid(stx[k], sty[k]);
       } else if (chunk == 1 || chunk == 2) {
         const int want = chunk == 1 ? 3 : 2;  // GROUP_OBJECTS then GROUP_GOAL (consts.py:13-16)
-        if (chunk == 1 && has_box) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, boxx, boxy);
+        if (chunk == 1 && has_box) lid(boxx, boxy);
 #pragma unroll 1
         for (int b = 0; b < (HAS_BTN ? SAG_MAX_BUTTONS : 0); b++) {
           if (b < nB) {
             int g;
             if (task == SAG_TASK_COLLECT) g = (act >> b & 1) ? 2 : 0;
             else g = bstate == 0 ? 0 : (b == gb ? 2 : 3);
-            if (g == want) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf,
-                                       stx[(SAG_MAX_PILLARS + b) % NSTAT], sty[(SAG_MAX_PILLARS + b) % NSTAT]);
+            if (g == want) lid(stx[(SAG_MAX_PILLARS + b) % NSTAT], sty[(SAG_MAX_PILLARS + b) % NSTAT]);
           }
         }
-        if (chunk == 2 && nB == 0) lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, goalx, goaly);
+        if (chunk == 2 && nB == 0) lid(goalx, goaly);
+      } else if (DOGGO) {
+        for (int k = 0; k < 28; k++) STG(k) = dsens[(DOGGO ? (chunk - 3) * 28 : 0) + k];
       } else if (chunk == 3) {
         const float qax = bad ? 0.0f : R.ax, qay = bad ? 0.0f : R.ay;
         STG(0) = cf * qax + sf * qay;
@@ -1340,11 +1684,12 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 #pragma unroll 4
         for (int j = 0; j < NSENS; j++) {
           const int e = j * WAVE + lane;
-          // e / 12 (e < 768) or e / 24 (e < 1536), exact
-          const int env = (int)(((uint32_t)e * 43691u) >> (NSENS == 12 ? 19 : 20));
+          // e / 12 (e < 768), e / 24 (e < 1536) or e / 28 (e < 1792), exact
+          const int env = NSENS == 28 ? (int)(((uint32_t)e * 2341u) >> 16)
+                                      : (int)(((uint32_t)e * 43691u) >> (NSENS == 12 ? 19 : 20));
           const int col = e - env * NSENS;
           const float v = lds[STG_BASE + env * STG_STRIDE + col];
-          if (row_ok(env) && !ABL(ABL_NO_OBS_STORE)) o[row_of(env) * OBS_DIM + 48 + col] = v;
+          if (row_ok(env) && !ABL(ABL_NO_OBS_STORE)) o[row_of(env) * OBS_DIM + 48 + (chunk - 3) * NSENS + col] = v;
         }
       }
       __syncthreads();

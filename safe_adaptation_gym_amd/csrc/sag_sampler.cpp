@@ -231,7 +231,7 @@ int sample_one(int robot, int task_id, uint32_t seed, const sag_world_config& cf
   ri[SAG_I_ACTIVE_MASK] = (int32_t)active_mask;
   rf[SAG_F_ROBOT] = (float)it[0].x; rf[SAG_F_ROBOT + 1] = (float)it[0].y; rf[SAG_F_ROBOT + 2] = (float)robot_rot;
   for (int k = 0; k < 3; k++) rf[SAG_F_ROBOT0 + k] = rf[SAG_F_ROBOT + k];
-  rf[SAG_F_ROBOT_EXT + 5] = 1.0f;
+  if (robot == SAG_ROBOT_CAR) rf[SAG_F_ROBOT_EXT + 5] = 1.0f;  // rear ball quaternion w; doggo: all zero = reset pose
   rf[SAG_F_GEAR] = (float)T.gear; rf[SAG_F_DAMP] = (float)T.damp;
   rf[SAG_F_ACTION_NOISE] = (float)cfg.action_noise;
   for (int k = 0; k < SAG_MAX_NU; k++) rf[SAG_F_CTRL_SCALE + k] = (float)ctrl_scale[k];

@@ -120,7 +120,9 @@ class World:
     rf[nat.F_ROBOT:nat.F_ROBOT + 2] = lay['robot']
     rf[nat.F_ROBOT + 2] = self.robot_rot
     rf[nat.F_ROBOT0:nat.F_ROBOT0 + 3] = rf[nat.F_ROBOT:nat.F_ROBOT + 3]
-    rf[nat.F_ROBOT_EXT + 5] = 1.0  # car: rear ball quaternion (w, x, y, z) = identity
+    if self.robot.name == 'car':
+      rf[nat.F_ROBOT_EXT + 5] = 1.0  # rear ball quaternion (w, x, y, z) = identity
+    # doggo: an all-zero extension block = the reset pose (upright at robot_rot, z .22, joints 0)
     rf[nat.F_BOUND] = self.bound
     rf[nat.F_GEAR], rf[nat.F_DAMP] = t.GEAR, t.DAMPING
     rf[nat.F_ACTION_NOISE] = cfg.action_noise

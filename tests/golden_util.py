@@ -93,7 +93,7 @@ def set_poses(rf, names, pos, yaw=None, v0=None, wz=None):
     rf[F_BOX:F_BOX + 2] = pos['box'][:2]
 
 
-def base_record(task, names, keepouts, env_id=0):
+def base_record(task, names, keepouts, env_id=0, robot='point'):
   rf = np.zeros(REC_FLOATS, np.float64)
   ri = np.zeros(REC_INTS, np.int32)
   ri[I_TASK] = TASK_ID[task]
@@ -115,7 +115,8 @@ def base_record(task, names, keepouts, env_id=0):
   rf[F_KEEPOUT + 3] = keepouts.get('pillars0', 0.3)
   rf[F_KEEPOUT + 4] = keepouts.get('box', 0.5)
   rf[F_CATCH + 2], rf[F_CATCH + 3] = 1.0, 0.2  # catch_goal.py:15-16
-  rf[144 + 5] = 1.0  # car rear-ball quaternion w
+  if robot != 'doggo':
+    rf[144 + 5] = 1.0  # car rear-ball quaternion w (ignored by point)
   return rf, ri
 
 

@@ -403,8 +403,96 @@ def test_car_env_api(nat):
   R = obs[:, 63:72].reshape(-1, 3, 3)
   np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.broadcast_to(np.eye(3), (70, 3, 3)), atol=1e-5)
   assert (np.abs(obs[:, 60:63]).max(1) > 0.1).mean() > 0.9, 'the rear ball spins once the car moves'
-  with pytest.raises(nat.SagError, match='Doggo'):
-    sag.make('doggo', 'go_to_goal', n_envs=4).step(np.zeros((4, 12), np.float32))
+  env.close()
+
+
+# ----------------------------------------------------------------------------------
+# Doggo (3-D articulated; fp64 robot solve on the device, fp32 planar world)
+# ----------------------------------------------------------------------------------
+DOGGO_TASKS = ['go_to_goal', 'push_box', 'press_buttons', 'haul_box', 'unsupervised', 'collect', MIXED]
+
+
+@pytest.mark.parametrize('task', DOGGO_TASKS)
+def test_doggo_lockstep_vs_oracle(nat, oracle, task):
+  """Same protocol as test_step_lockstep_vs_oracle for the Doggo robot (BASELINE config 4 shape
+  for 'multitask').  Stated tolerance after one step (12 substeps) from identical fp32 state:
+  robot qpos within 2e-5, qvel within 2e-3 abs + 2e-3 rel of the fp64 oracle (the device solves the
+  robot in fp64 but stores fp32 and keeps the planar world in fp32; 12 substeps of stiff
+  soft-contact dynamics amplify that rounding), free bodies within the planar STATE_TOL;
+  threshold events (a sphere's penetration changing sign with the rounding) are counted and
+  bounded.  goal_met / done / task ints / RNG words exact on rows inside the tolerance."""
+  n, T = 64, 30
+  from safe_adaptation_gym_amd import benchmark
+  if task == MIXED:
+    names = [nm for nm, _ in benchmark.make('multitask', batch_size=n, seed=666).train_tasks]
+  else:
+    names = task
+  rf, ri = bu.sample_records_native('doggo', names, n, seed=666)
+  ctx = nat.Context('doggo', n, seed=4321)
+  ctx.set_layout(rf, ri)
+  mt = np.random.RandomState(5)
+  obs0 = ctx.observe()
+  rf, ri = ctx.get_state()
+  np.testing.assert_allclose(obs0, oracle.observe_batch(oracle.make_batch(rf, ri), 2, 104), rtol=0, atol=OBS_TOL)
+  E = 144
+  pos_f = [0, 1, 2, E] + list(range(E + 1, E + 5)) + list(range(E + 9, E + 22))
+  viol = n_rows = 0
+  touched = 0
+  for t in range(T):
+    rf, ri = ctx.get_state()
+    arr = oracle.make_batch(rf, ri)
+    act = mt.uniform(-1, 1, size=(n, 12)).astype(np.float32)
+    if t < 3:
+      act[:] = 0   # let the robots land first
+    noise = mt.normal(size=(n, 12)).astype(np.float32)
+    tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
+    d_obs, d_rew, d_cost, d_done, d_met, d_used = ctx.step(act, noise, tape)
+    o_obs, o_rew, o_cost, o_done, o_met, o_used, o_margin = oracle.step_batch_full(arr, 2, act, noise, tape, obs_dim=104)
+    d_rf, d_ri = ctx.get_state()
+    o_rf, o_ri = oracle.batch_records(arr)
+    tol = np.full(d_rf.shape[1], 2e-3)
+    tol[pos_f] = 2e-5
+    for k in range(10):
+      tol[81 + 6 * k:81 + 6 * k + 6] = STATE_TOL
+      tol[81 + 6 * k + 5] = 2e-4
+    tol[41:47] = STATE_TOL; tol[46] = 5e-3
+    bad = (np.abs(d_rf - o_rf) > tol + tol * np.abs(o_rf)).any(1)
+    viol += int(bad.sum()); n_rows += n
+    ok = ~bad
+    np.testing.assert_array_equal(d_done, o_done)
+    assert not d_done.any()
+    np.testing.assert_array_equal(d_met[ok], o_met[ok])
+    np.testing.assert_array_equal(d_used[ok], o_used[ok])
+    np.testing.assert_array_equal(d_ri[ok], o_ri[ok])
+    mism = ok & (d_cost != o_cost) & (o_margin > 1e-5)
+    assert mism.sum() <= 1, f'cost flags differ away from a threshold at step {t}'
+    # observation as a function of the device's own post-step state (lidar, kinematic sensors)
+    f_obs = oracle.observe_batch(oracle.make_batch(d_rf, d_ri), 2, 104)
+    np.testing.assert_allclose(d_obs[:, :48], f_obs[:, :48], rtol=0, atol=OBS_TOL, err_msg=f'lidar step {t}')
+    np.testing.assert_allclose(d_obs[:, 51:60], f_obs[:, 51:60], rtol=0, atol=2e-5, err_msg=f'vel/gyro/mag step {t}')
+    np.testing.assert_allclose(d_obs[:, 68:], f_obs[:, 68:], rtol=0, atol=2e-5, err_msg=f'joint sensors step {t}')
+    # end to end (accelerometer and touch come from the stiff contact solve: relative tolerance)
+    np.testing.assert_allclose(d_obs[ok, :48], o_obs[ok, :48], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(d_obs[ok, 60:68], o_obs[ok, 60:68], rtol=2e-2, atol=2e-3, err_msg=f'touch step {t}')
+    np.testing.assert_allclose(d_rew[ok], o_rew[ok], rtol=0, atol=2e-4, err_msg=f'reward step {t}')
+    touched += int((d_obs[:, 60:68] > 0).any(1).sum())
+  assert touched > 0.8 * n * (T - 3), 'the robots should stand on the floor'
+  assert viol <= 0.02 * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'
+  ctx.close()
+
+
+def test_doggo_env_api(nat):
+  """make('doggo', ...): obs 104, 12 actions; zero action lets the robot settle on its feet."""
+  import safe_adaptation_gym_amd as sag
+  env = sag.make('doggo', 'go_to_goal', seed=3, n_envs=96)
+  obs = env.reset()
+  assert obs.shape == (96, 104) and env.action_space.shape == (12,)
+  for _ in range(40):
+    obs, reward, done, info = env.step(np.zeros((96, 12), np.float32))
+  assert np.isfinite(obs).all() and not done.any()
+  touch = obs[:, 60:68]
+  assert (touch.sum(1) > 0.3).mean() > 0.95      # m g = 0.39 N carried by the feet
+  assert (np.abs(obs[:, 68:80]).max(1) < 0.5).mean() > 0.9   # joint rates have died down
   env.close()
 
 
