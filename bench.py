@@ -41,8 +41,13 @@ def build_records(task, envs_per_gpu, rank, seed=666, robot='point'):
   from safe_adaptation_gym_amd import _native as nat
   from safe_adaptation_gym_amd import benchmark
   g0 = rank * envs_per_gpu
-  rf, ri, status = nat.sample_layouts(robot, seed + g0 + np.arange(envs_per_gpu, dtype=np.int64),
-                                      benchmark.TASKS[task].TASK_ID, env_id0=g0)
+  if task == 'multitask':
+    # BASELINE config 4: task of env g from the benchmark's TaskSampler order (task_sampler.py:15-19)
+    names = [nm for nm, _ in benchmark.make('multitask', batch_size=envs_per_gpu, seed=seed + rank).train_tasks]
+    tids = np.array([benchmark.TASKS[nm].TASK_ID for nm in names], np.int32)
+  else:
+    tids = benchmark.TASKS[task].TASK_ID
+  rf, ri, status = nat.sample_layouts(robot, seed + g0 + np.arange(envs_per_gpu, dtype=np.int64), tids, env_id0=g0)
   assert not status.any(), 'layout sampling failed'
   return rf, ri
 
@@ -61,7 +66,7 @@ class DeviceRun:
     self.ctx.set_layout(rf, ri)
     self.envs = envs
     od = self.ctx.info['obs_dim']
-    self.d_act = [self.ctx.dev_alloc(envs * 2 * 4) for _ in range(N_ACTION_BUFS)]
+    self.d_act = [self.ctx.dev_alloc(envs * self.ctx.info['nu'] * 4) for _ in range(N_ACTION_BUFS)]
     for k, b in enumerate(self.d_act):
       self.ctx.dev_fill_actions(b, k)
     self.d_obs = self.ctx.dev_alloc(envs * od * 4)
@@ -298,6 +303,15 @@ def main(argv=None, run_factory=None, emit=print):
                          'roofline_frac': 804 * n_c3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         r3.close()
       res['c3_car_push_box'] = c3
+      # BASELINE config 4 shape on one GPU: Doggo, multitask sampler, 4096 envs (x 8 GPUs = 32768)
+      r4 = DeviceRun('multitask', 4096, device, 0, robot='doggo')
+      r4.burn_in(20)
+      r4.timing(True)
+      t = timed(r4, 30, 5, lambda: None)
+      ms, _ = r4.kernel_time_ms()
+      res['c4_doggo_multitask_4096'] = {'value': 4096 * 30 / t, 'unit': 'env-steps/s', 'kernel_ms': ms,
+                                        'note': 'per GPU; fp64 articulated solve, 12 substeps, latency-bound (64 wavefronts)'}
+      r4.close()
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(args.task)
   if rank == 0:

@@ -64,6 +64,7 @@ struct sag_ctx {
   double ev_ms = 0; int64_t ev_n = 0;
   bool timing = false;
   int phase = 0;       // busy-bit copy read by the next step launch
+  int n_cu = 256;      // compute units of the device
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
@@ -211,6 +212,13 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   a.has_box = c->cfg.has_box; a.G = c->G;
   a.phase = c->phase; a.rows = c->d_rows; a.count = c->d_count;
+  {
+    // one Doggo wavefront per CU (its LDS working set): aim for one resident round over the chip
+    int epw = 64;
+    while (epw > 8 && (c->N + epw - 1) / epw < c->n_cu) epw >>= 1;
+    if (const char* e = getenv("SAG_DOGGO_EPW")) epw = atoi(e);
+    a.envs_per_wave = epw < 1 ? 1 : (epw > 64 ? 64 : epw);
+  }
   if (!observe_only) c->phase ^= 1;
   const int blocks = (c->N + WAVE - 1) / WAVE;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -258,7 +266,8 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   if (c->cfg.robot == SAG_ROBOT_POINT) SAG_LAUNCH(SAG_ROBOT_POINT);
   else if (c->cfg.robot == SAG_ROBOT_CAR) SAG_LAUNCH(SAG_ROBOT_CAR);
   else {  // Doggo: one (buttons + task object) instance, single-launch form
-    hipLaunchKernelGGL((k_step<SAG_ROBOT_DOGGO, true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
+    hipLaunchKernelGGL((k_step<SAG_ROBOT_DOGGO, true, true>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave),
+                       dim3(WAVE), 0, c->stream, a);
   }
 #undef SAG_LAUNCH
 #undef SAG_LAUNCH3
@@ -321,6 +330,10 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   } while (0)
   CREATE_CHK(hipSetDevice(cfg->device));
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+  }
   CREATE_CHK(hipMalloc(&c->S, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->I, N * DI_COUNT * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));

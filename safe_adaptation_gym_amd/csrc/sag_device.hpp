@@ -47,6 +47,7 @@ __host__ __device__ inline void unpack_tstate(uint32_t t, int32_t* ri) {
 }
 
 struct StepArgs {
+  int envs_per_wave;  // Doggo only (k_step<DOGGO>): 8..64
   float* S;          // [SAG_REC_FLOATS][N]
   int32_t* I;        // [DI_COUNT][N]
   int32_t N;
@@ -616,13 +617,20 @@ __device__ __attribute__((noinline)) void dg_free_body_finish(float* B, bool is_
 }
 
 __device__ __attribute__((noinline)) void doggo_physics(
-    DgState& D, DgWorld& Wd, DgResult& out, const float* ctrl12, int nsub, float hf, const float* stx,
+    DgState& D, DgWorld& Wd, DgResult& out, lds_f64* dgL, const float* ctrl12, int nsub, float hf, const float* stx,
     const float* sty, int nP, int nB, float psz, float vsz, const BodyK& vk, const BodyK& bk, const Sol& sol0,
     const Sol& solb, int nV, bool has_box, bool haul) {
   DgWork K;
   DgRows R;
+  K.L = dgL; K.xs = dgL + DG_NTRI * WAVE; K.dinv = K.xs + 3 * DG_NV * WAVE;
   const DgModel& M = g_dg;
   const double h = (double)hf;
+#ifdef SAG_CYCLES
+  unsigned long long dcy[12] = {}, dct = __builtin_readcyclecounter();
+#define DCY(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); dcy[k] += t_ - dct; dct = t_; } while (0)
+#else
+#define DCY(k) do {} while (0)
+#endif
   const float vase_r = vk.reff, box_r = shape_bound(bk.sh, vsz, 0);
   const double top_vase = 2.0 * (double)vsz;
   const double top_box = bk.sh == SH_ROD ? 0.16 : (bk.sh == SH_BALL ? 0.28 : 0.4);
@@ -638,59 +646,87 @@ __device__ __attribute__((noinline)) void doggo_physics(
     }
     // ---- robot: smooth dynamics -----------------------------------------------------
     double bias[DG_NV], tau[DG_NV], qd[DG_NV];
+    DCY(7);
     dg_kinematics(D, K);
+    DCY(0);
     dg_mass_matrix(K);
+    DCY(1);
     dg_bias(D, K, bias);
+    DCY(2);
     dg_qd(D, qd);
     for (int k = 0; k < DG_NV; k++) tau[k] = 0;
     for (int j = 0; j < DG_NJ; j++) tau[6 + j] = -DG_STIFF * (D.q[j] - M.springref[j]);
     for (int k = 0; k < 12; k++) tau[6 + M.act_joint[k]] += DG_GEAR * (double)ctrl12[k];
     for (int k = 0; k < DG_NV; k++) tau[k] -= bias[k];
-    if (!dg_cholesky(K.L)) {  // not positive definite: the state is already broken (PhysicsError)
+    if (!dg_cholesky(K.L, K.dinv)) {  // not positive definite: the state is already broken (PhysicsError)
       D.pos[0] = __longlong_as_double(0x7ff8000000000000ll);
       break;
     }
-    dg_solve(K.L, tau, K.qacc);
+    for (int k = 0; k < DG_NV; k++) K.xs[k * 64] = tau[k];
+    dg_solve_lds<1>(K.L, K.dinv, K.xs);
+    for (int k = 0; k < DG_NV; k++) K.qacc[k] = K.xs[k * 64];
+    DCY(3);
     for (int k = 0; k < 8; k++) K.touch[k] = 0;
     R.n = 0;
     // ---- rows: joint limits, floor, pillars, buttons, vases, task object, tether ----
+    // each lane walks ITS OWN list of violated limits / touching spheres (ascending index = the
+    // specification's row order): the wavefront iterates max-count times, not once per index that
+    // any of its 64 envs needs
+    uint32_t lim_mask = 0;
+    for (int j = 0; j < DG_NJ; j++)
+      if (D.q[j] < M.lo[j] || D.q[j] > M.hi[j]) lim_mask |= 1u << j;
 #pragma unroll 1
-    for (int j = 0; j < DG_NJ; j++) {
+    for (uint32_t lm = lim_mask; lm; lm &= lm - 1) {
+      const int j = __ffs(lm) - 1;
       double depth = 0, sign = 0;
       if (D.q[j] < M.lo[j]) { depth = M.lo[j] - D.q[j]; sign = 1; }
       else if (D.q[j] > M.hi[j]) { depth = D.q[j] - M.hi[j]; sign = -1; }
-      if (sign == 0) continue;
       double J[DG_NV];
       for (int k = 0; k < DG_NV; k++) J[k] = 0;
       J[6 + j] = 1;
-      DgRow* r = dg_add_row(R, K, Wd, J, sign, -1, 0, 0, 0, 0);
+      DgRow* r = dg_add_row1(R, K, Wd, J, sign, -1, 0, 0, 0, 0);
       if (!r) break;
       r->imp = dg_impedance(depth);
       r->aref = -(double)sol0.bcoef * dg_row_vel(*r, Wd, qd) + (double)sol0.kcoef * depth;
     }
+    DCY(8);
+    uint32_t floor_mask = 0;
+    for (int s = 0; s < DG_NS; s++)
+      if (M.sph_r[s] - K.sph[s][2] > 0) floor_mask |= 1u << s;
 #pragma unroll 1
-    for (int s = 0; s < DG_NS; s++) {
+    for (uint32_t fm = floor_mask; fm; fm &= fm - 1) {
+      const int s = __ffs(fm) - 1;
       const double depth = M.sph_r[s] - K.sph[s][2];
-      if (depth <= 0) continue;
       const double n[3] = {0, 0, 1}, c[3] = {K.sph[s][0], K.sph[s][1], 0.5 * (K.sph[s][2] - M.sph_r[s])};
       dg_add_contact(R, D, K, Wd, qd, s, n, c, depth, -1, (double)sol0.bcoef, (double)sol0.kcoef, (double)MU);
     }
+    DCY(9);
     int cc = 0;
     uint32_t mask = 0;
+    // every sphere centre lies within .52 m of the base origin (hip offset .224 + hip link .124 +
+    // shin .168): bodies farther than that plus the radii cannot touch and are skipped outright
+    auto near = [&](float bx, float by, float rb) {
+      const double dx = (double)bx - D.pos[0], dy = (double)by - D.pos[1], rs = 0.6 + (double)rb;
+      return dx * dx + dy * dy <= rs * rs;
+    };
 #pragma unroll 1
     for (int q = 0; q < nP; q++)
+      if (near(stx[q], sty[q], psz))
       cc += dg_collide_body(R, D, K, Wd, qd, -1, SH_STATIC, stx[q], sty[q], 0.f, psz, vsz, psz, 1.0,
                             (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu);
 #pragma unroll 1
     for (int b = 0; b < nB; b++)
-      if (dg_collide_body(R, D, K, Wd, qd, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f,
+      if (near(stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], BUTTON_R) &&
+          dg_collide_body(R, D, K, Wd, qd, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f,
                           BUTTON_R, vsz, BUTTON_R, 0.2, (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu))
         mask |= 1u << b;
 #pragma unroll 1
     for (int k = 0; k < nV; k++)
+      if (near(Wd.fb[k][0], Wd.fb[k][1], vase_r))
       cc += dg_collide_body(R, D, K, Wd, qd, k, SH_VASE, Wd.fb[k][0], Wd.fb[k][1], Wd.fb[k][2], vase_r, vsz, 0.f,
                             top_vase, (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu);
     if (has_box) {
+      if (near(Wd.fb[BOX_ID][0], Wd.fb[BOX_ID][1], box_r))
       dg_collide_body(R, D, K, Wd, qd, BOX_ID, bk.sh, Wd.fb[BOX_ID][0], Wd.fb[BOX_ID][1], Wd.fb[BOX_ID][2], box_r,
                       vsz, 0.f, top_box, (double)solb.bcoef, (double)solb.kcoef, (double)solb.mu);
       if (haul) {  // haul_box.py:21-29: tendon base site <-> box site (z .2), range [0, .75]
@@ -700,7 +736,7 @@ __device__ __attribute__((noinline)) void doggo_physics(
           const double j[3] = {dx / Lt, dy / Lt, dz / Lt};
           double J[DG_NV];
           dg_jac(D, K, 0, D.pos, j, J);
-          DgRow* r = dg_add_row(R, K, Wd, J, 1.0, BOX_ID, -j[0], -j[1], (double)Wd.fb[BOX_ID][0], (double)Wd.fb[BOX_ID][1]);
+          DgRow* r = dg_add_row1(R, K, Wd, J, 1.0, BOX_ID, -j[0], -j[1], (double)Wd.fb[BOX_ID][0], (double)Wd.fb[BOX_ID][1]);
           if (r) {
             r->imp = dg_impedance(viol);
             r->aref = -(double)sol0.bcoef * dg_row_vel(*r, Wd, qd) + (double)sol0.kcoef * viol;
@@ -708,7 +744,9 @@ __device__ __attribute__((noinline)) void doggo_physics(
         }
       }
     }
+    DCY(4);
     dg_pgs(R, K, Wd);
+    DCY(5);
     for (int k = 0; k < R.n; k++)
       if (R.row[k].touch >= 0 && R.row[k].parent < 0) K.touch[R.row[k].touch] += R.row[k].f;
     out.cost_contacts = cc; out.btn_mask = mask;
@@ -758,6 +796,14 @@ __device__ __attribute__((noinline)) void doggo_physics(
       dg_free_body_finish(Wd.fb[k], isb, vk, bk, sol0.bcoef, hf);
     }
   }
+  DCY(6);
+#ifdef SAG_CYCLES
+  if ((threadIdx.x & 63) == 0) {
+    for (int k = 0; k < 12; k++) atomicAdd(&g_cyc[1][k], dcy[k]);
+    atomicAdd(&g_cyc[1][CY_N], 1ull);
+  }
+#endif
+#undef DCY
   for (int k = 0; k < 3; k++) out.qacc_lin[k] = K.qacc[k];
   for (int k = 0; k < 8; k++) out.touch[k] = K.touch[k];
   dg_com_vel(D, K, out.comvel);
@@ -772,7 +818,7 @@ constexpr uint32_t TS_BUSY_BIT = 1u << 28;
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX, int MODE>
 __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const int lane, const int i,
                                           const bool live, const int base_env, const int nvalid,
-                                          const uint64_t skip_mask, const int* rows) {
+                                          const uint64_t skip_mask, const int* rows, double* dgL = nullptr) {
   constexpr int NSTAT = SAG_MAX_PILLARS + (HAS_BTN ? SAG_MAX_BUTTONS : 0);
   constexpr bool CAR = ROBOT == SAG_ROBOT_CAR, DOGGO = ROBOT == SAG_ROBOT_DOGGO;
   static_assert(!DOGGO || MODE == MODE_ALL, "Doggo runs the single-launch form");
@@ -992,8 +1038,13 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         Wd.minv[k][0] = Wd.minv[k][3] = bk.sh == SH_BALL ? 1.0f / (1.4f * bk.m) : 1.0f / bk.m;  // rod: per substep
       }
     }
-    doggo_physics(dgs, Wd, dgr, ctrl12, nsub, h, stx, sty, nP, nB, psz, vsz, vk, bk, sol0, solb, nV, has_box,
-                  HAS_TBOX && task == SAG_TASK_HAUL_BOX);
+    for (int k = 0; k < 3; k++) dgr.qacc_lin[k] = 0;
+    for (int k = 0; k < 8; k++) dgr.touch[k] = 0;
+    for (int k = 0; k < 4; k++) dgr.comvel[k] = 1;
+    dgr.cost_contacts = 0; dgr.btn_mask = 0;
+    if (live)  // padding lanes of a partly filled wavefront stay out of the divergence union
+      doggo_physics(dgs, Wd, dgr, (lds_f64*)dgL + lane, ctrl12, nsub, h, stx, sty, nP, nB, psz, vsz, vk, bk, sol0, solb, nV,
+                    has_box, HAS_TBOX && task == SAG_TASK_HAUL_BOX);
     cost_contacts = dgr.cost_contacts; btn_mask = dgr.btn_mask;
     float wz;
     if (!p.observe_only && live) dg_store(dgs, S, (size_t)N, (size_t)i, yaw, wz);
@@ -1715,10 +1766,15 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
   __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
-  const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
-  const bool live = gi < p.N;
+  // Doggo: the Cholesky factor of the mass matrix, [190][64 lanes] fp64 = 95 KB (one wavefront per CU)
+  __shared__ double dgL[ROBOT == SAG_ROBOT_DOGGO ? (DG_NTRI + 4 * DG_NV) * WAVE : 1];  // + 3 solve vectors, 1 / diagonal
+  // Doggo batches are small and its wavefronts long: fewer envs per wavefront (p.envs_per_wave)
+  // spread a batch over more CUs and shrink the divergence union; the idle lanes just mirror env N-1
+  const int epw = ROBOT == SAG_ROBOT_DOGGO ? p.envs_per_wave : WAVE;
+  const int lane = threadIdx.x, base = blockIdx.x * epw, gi = base + lane;
+  const bool live = gi < p.N && lane < epw;
   step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_ALL>(p, lds, lane, live ? gi : p.N - 1, live, base,
-                                                 min(WAVE, p.N - base), 0ull, nullptr);
+                                                 min(epw, p.N - base), 0ull, nullptr, dgL);
 }
 
 #ifndef SAG_QUIET_MIN_WAVES

@@ -34,6 +34,10 @@ struct DgModel {
 };
 __constant__ DgModel g_dg;
 
+// LDS pointers keep their address space through the (non-inlined) function boundaries: a generic
+// `double*` turns every access into a flat load that takes the slow path to the LDS aperture
+typedef __attribute__((address_space(3))) double lds_f64;
+
 struct DgState {
   double pos[3], quat[4], q[DG_NJ];
   double vlin[3], wloc[3], qd[DG_NJ];
@@ -45,7 +49,9 @@ struct DgWork {
   double R[DG_NB][9], p[DG_NB][3];
   DgVec S[DG_NV];
   DgInertia Ib[DG_NB];
-  double L[DG_NV * (DG_NV + 1) / 2];  // packed lower triangle: mass matrix, then its Cholesky factor
+  lds_f64* L;                         // LDS, [packed lower index][lane]: mass matrix, then its Cholesky factor
+  lds_f64* xs;                        // LDS, [3][19][lane]: right-hand sides / solutions of a solve
+  lds_f64* dinv;                      // LDS, [19][lane]: 1 / diagonal of the factor
   double Mlin[2][DG_NV];              // rows 0, 1 of the mass matrix (momentum, Unsupervised)
   double qacc[DG_NV];
   double sph[DG_NS][3];
@@ -61,7 +67,10 @@ struct DgRow {
   short parent, other, touch;    // normal row of a friction row / free-body index / touch slot; -1 = none
 };
 
-__device__ inline int dg_tri(int i, int j) { return i * (i + 1) / 2 + j; }  // i >= j
+constexpr int DG_NTRI = DG_NV * (DG_NV + 1) / 2;
+// packed lower triangle, one column of 64 lanes per entry (bank = lane: conflict-free); the
+// pointer handed around is already offset by the lane
+__device__ __host__ constexpr int dg_tri(int i, int j) { return (i * (i + 1) / 2 + j) * 64; }  // i >= j
 __device__ inline void dg_cross(const double* a, const double* b, double* o) {
   const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   o[0] = x; o[1] = y; o[2] = z;
@@ -218,7 +227,7 @@ __device__ __attribute__((noinline)) void dg_mass_matrix(DgWork& K) {
     for (int i = 0; i <= j; i++) {
       const bool on = M.anc[bj] >> M.dof_body[i] & 1u;
       const double v = on ? dg_sdot(K.S[i], F) : 0.0;
-      K.L[dg_tri(j, i)] = v;
+      K.L[dg_tri(j, i)] = v;  // (runtime indices: a computed LDS address)
       if (i < 2) K.Mlin[i][j] = v;
     }
   }
@@ -277,36 +286,108 @@ __device__ __attribute__((noinline)) void dg_bias(const DgState& D, const DgWork
   }
 }
 
-__device__ __attribute__((noinline)) bool dg_cholesky(double* L) {
+// Cholesky of the 19x19 mass matrix in place.  Factor, inverse diagonal and the solve vectors live
+// in LDS, where a run-time index is just an address: rolled loops, little code.  (Private-memory
+// arrays made the row solves 76 % of the step; a fully unrolled register version was 60 KB of code
+// that thrashed the instruction cache.)  LDS loads are issued in batches of 4 before they are used,
+// otherwise every multiply-add waits a full LDS round trip.
+__device__ __attribute__((noinline)) bool dg_cholesky(lds_f64* L, lds_f64* dinv) {
+  bool ok = true;
 #pragma unroll 1
   for (int j = 0; j < DG_NV; j++) {
     double d = L[dg_tri(j, j)];
-    for (int k = 0; k < j; k++) d -= L[dg_tri(j, k)] * L[dg_tri(j, k)];
-    if (!(d > 0)) return false;
+    {
+      int k = 0;
+      for (; k + 4 <= j; k += 4) {
+        double l[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) l[u] = L[dg_tri(j, k + u)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) d -= l[u] * l[u];
+      }
+      for (; k < j; k++) { const double l = L[dg_tri(j, k)]; d -= l * l; }
+    }
+    ok = ok && d > 0;
     d = sqrt(d);
     L[dg_tri(j, j)] = d;
+    const double inv = 1.0 / d;
+    dinv[j * 64] = inv;
+#pragma unroll 1
     for (int i = j + 1; i < DG_NV; i++) {
       double s = L[dg_tri(i, j)];
-      for (int k = 0; k < j; k++) s -= L[dg_tri(i, k)] * L[dg_tri(j, k)];
-      L[dg_tri(i, j)] = s / d;
+      int k = 0;
+      for (; k + 4 <= j; k += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = L[dg_tri(i, k + u)]; b[u] = L[dg_tri(j, k + u)]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) s -= a[u] * b[u];
+      }
+      for (; k < j; k++) s -= L[dg_tri(i, k)] * L[dg_tri(j, k)];
+      L[dg_tri(i, j)] = s * inv;
     }
   }
-  return true;
+  return ok;
 }
-template <typename TB>
-__device__ __attribute__((noinline)) void dg_solve(const double* L, const TB* b, double* x) {
-  double y[DG_NV];
+// NR right-hand sides at once: x[(r * 19 + i) * 64] <- (L L^T)^-1 x.  The three rows of a contact
+// (normal, two tangents) share every load of the factor.
+template <int NR>
+__device__ __attribute__((noinline)) void dg_solve_lds(const lds_f64* L, const lds_f64* dinv, lds_f64* x) {
 #pragma unroll 1
   for (int i = 0; i < DG_NV; i++) {
-    double s = (double)b[i];
-    for (int k = 0; k < i; k++) s -= L[dg_tri(i, k)] * y[k];
-    y[i] = s / L[dg_tri(i, i)];
+    double s[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) s[r] = x[(r * DG_NV + i) * 64];
+    int k = 0;
+    for (; k + 4 <= i; k += 4) {
+      double l[4], xv[NR][4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        l[u] = L[dg_tri(i, k + u)];
+#pragma unroll
+        for (int r = 0; r < NR; r++) xv[r][u] = x[(r * DG_NV + k + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) s[r] -= l[u] * xv[r][u];
+    }
+    for (; k < i; k++) {
+      const double l = L[dg_tri(i, k)];
+#pragma unroll
+      for (int r = 0; r < NR; r++) s[r] -= l * x[(r * DG_NV + k) * 64];
+    }
+    const double inv = dinv[i * 64];
+#pragma unroll
+    for (int r = 0; r < NR; r++) x[(r * DG_NV + i) * 64] = s[r] * inv;
   }
 #pragma unroll 1
   for (int i = DG_NV - 1; i >= 0; i--) {
-    double s = y[i];
-    for (int k = i + 1; k < DG_NV; k++) s -= L[dg_tri(k, i)] * x[k];
-    x[i] = s / L[dg_tri(i, i)];
+    double s[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) s[r] = x[(r * DG_NV + i) * 64];
+    int k = i + 1;
+    for (; k + 4 <= DG_NV; k += 4) {
+      double l[4], xv[NR][4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        l[u] = L[dg_tri(k + u, i)];
+#pragma unroll
+        for (int r = 0; r < NR; r++) xv[r][u] = x[(r * DG_NV + k + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) s[r] -= l[u] * xv[r][u];
+    }
+    for (; k < DG_NV; k++) {
+      const double l = L[dg_tri(k, i)];
+#pragma unroll
+      for (int r = 0; r < NR; r++) s[r] -= l * x[(r * DG_NV + k) * 64];
+    }
+    const double inv = dinv[i * 64];
+#pragma unroll
+    for (int r = 0; r < NR; r++) x[(r * DG_NV + i) * 64] = s[r] * inv;
   }
 }
 
@@ -342,17 +423,19 @@ struct DgWorld {
 
 struct DgRows { DgRow row[DG_MAXROWS]; int n; };
 
-// sign * J is the row; the other body (if any) moves along (dx, dy) at lever (px, py) - its centre
-__device__ __attribute__((noinline)) DgRow* dg_add_row(DgRows& R, const DgWork& K, const DgWorld& Wd, const double* J,
-                                                       double sign, int other, double dx, double dy, double px, double py) {
+// Row from right-hand-side slot `slot` of K.xs: J (as stored, fp32) was written there and solved in
+// place, so the slot now holds W = M^-1 J^T.  The other body (if any) moves along (dx, dy) at lever
+// (px, py) - its centre.
+__device__ __attribute__((noinline)) DgRow* dg_add_row(DgRows& R, const DgWork& K, const DgWorld& Wd, const float* Jf,
+                                                       int slot, int other, double dx, double dy, double px, double py) {
   if (R.n >= DG_MAXROWS) return nullptr;
   DgRow& r = R.row[R.n++];
-  for (int i = 0; i < DG_NV; i++) r.J[i] = (float)(sign * J[i]);
-  // the fp64 Jacobian is rounded to fp32 for storage; W is computed from the stored row so that
-  // A = J W stays consistent
-  dg_solve(K.L, r.J, r.W);
   double A = 0;
-  for (int i = 0; i < DG_NV; i++) A += (double)r.J[i] * r.W[i];
+  for (int i = 0; i < DG_NV; i++) {
+    r.J[i] = Jf[i];
+    r.W[i] = K.xs[(slot * DG_NV + i) * 64];
+    A += (double)r.J[i] * r.W[i];
+  }
   r.other = (short)other; r.parent = -1; r.touch = -1; r.f = 0; r.mu = 0;
   r.ou[0] = r.ou[1] = r.ou[2] = 0; r.od[0] = r.od[1] = 0; r.orx = r.ory = 0;
   if (other >= 0) {
@@ -367,6 +450,15 @@ __device__ __attribute__((noinline)) DgRow* dg_add_row(DgRows& R, const DgWork& 
   }
   r.A = A;
   return &r;
+}
+// one row: the fp64 Jacobian is rounded to fp32 for storage and W is computed from the stored
+// row, so that A = J W stays consistent
+__device__ inline DgRow* dg_add_row1(DgRows& R, const DgWork& K, const DgWorld& Wd, const double* J, double sign,
+                                     int other, double dx, double dy, double px, double py) {
+  float Jf[DG_NV];
+  for (int i = 0; i < DG_NV; i++) { Jf[i] = (float)(sign * J[i]); K.xs[i * 64] = (double)Jf[i]; }
+  dg_solve_lds<1>(K.L, K.dinv, K.xs);
+  return dg_add_row(R, K, Wd, Jf, 0, other, dx, dy, px, py);
 }
 __device__ inline double dg_row_vel(const DgRow& r, const DgWorld& Wd, const double* qd) {
   double v = 0;
@@ -391,32 +483,41 @@ __device__ inline double dg_row_acc(const DgRow& r, const DgWorld& Wd, const dou
 __device__ __attribute__((noinline)) void dg_add_contact(DgRows& R, const DgState& D, const DgWork& K, const DgWorld& Wd,
                                                          const double* qd, int s, const double* n, const double* c,
                                                          double depth, int other, double bcoef, double kcoef, double mu) {
+  if (R.n + 3 > DG_MAXROWS) return;
   const int b = g_dg.sph_body[s];
-  double J[DG_NV];
   const int first = R.n;
-  dg_jac(D, K, b, c, n, J);
-  DgRow* r = dg_add_row(R, K, Wd, J, 1.0, other, -n[0], -n[1], c[0], c[1]);
-  if (!r) return;
-  r->imp = dg_impedance(depth);
-  r->aref = -bcoef * dg_row_vel(*r, Wd, qd) + kcoef * depth;
-  r->touch = (short)g_dg.sph_touch[s];
-  double t1[3], t2[3];
-  if (fabs(n[2]) > 0.5) { t1[0] = 1; t1[1] = 0; t1[2] = 0; }
-  else { t1[0] = -n[1]; t1[1] = n[0]; t1[2] = 0; }
-  dg_cross(n, t1, t2);
+  double dir[3][3];
+  for (int k = 0; k < 3; k++) dir[0][k] = n[k];
+  if (fabs(n[2]) > 0.5) { dir[1][0] = 1; dir[1][1] = 0; dir[1][2] = 0; }
+  else { dir[1][0] = -n[1]; dir[1][1] = n[0]; dir[1][2] = 0; }
+  dg_cross(dir[0], dir[1], dir[2]);
+  float Jf[3][DG_NV];
 #pragma unroll 1
-  for (int k = 0; k < 2; k++) {
-    const double* T = k == 0 ? t1 : t2;
-    dg_jac(D, K, b, c, T, J);
-    DgRow* t = dg_add_row(R, K, Wd, J, 1.0, other, -T[0], -T[1], c[0], c[1]);
-    if (!t) return;
-    t->imp = R.row[first].imp;
-    t->aref = -bcoef * dg_row_vel(*t, Wd, qd);
-    t->parent = (short)first; t->mu = mu;
+  for (int k = 0; k < 3; k++) {
+    double J[DG_NV];
+    dg_jac(D, K, b, c, dir[k], J);
+    for (int i = 0; i < DG_NV; i++) { Jf[k][i] = (float)J[i]; K.xs[(k * DG_NV + i) * 64] = (double)Jf[k][i]; }
+  }
+  dg_solve_lds<3>(K.L, K.dinv, K.xs);   // normal and both tangents share the factor loads
+#pragma unroll 1
+  for (int k = 0; k < 3; k++) {
+    DgRow* r = dg_add_row(R, K, Wd, Jf[k], k, other, -dir[k][0], -dir[k][1], c[0], c[1]);
+    if (k == 0) {
+      r->imp = dg_impedance(depth);
+      r->aref = -bcoef * dg_row_vel(*r, Wd, qd) + kcoef * depth;
+      r->touch = (short)g_dg.sph_touch[s];
+    } else {
+      r->imp = R.row[first].imp;
+      r->aref = -bcoef * dg_row_vel(*r, Wd, qd);
+      r->parent = (short)first; r->mu = mu;
+    }
   }
 }
 
 __device__ __attribute__((noinline)) void dg_pgs(DgRows& R, DgWork& K, DgWorld& Wd) {
+  double qa[DG_NV];  // registers: every inner loop below is fully unrolled
+#pragma unroll
+  for (int i = 0; i < DG_NV; i++) qa[i] = K.qacc[i];
 #pragma unroll 1
   for (int it = 0; it < DG_PGS_ITERS; it++)
 #pragma unroll 1
@@ -424,7 +525,14 @@ __device__ __attribute__((noinline)) void dg_pgs(DgRows& R, DgWork& K, DgWorld& 
       DgRow& r = R.row[k];
       if (!(r.A > 0)) continue;
       const double reg = r.A * (1 - r.imp) / r.imp;
-      double fnew = r.f + (r.aref - dg_row_acc(r, Wd, K.qacc) - reg * r.f) / (r.A + reg);
+      double acc = 0;
+#pragma unroll
+      for (int i = 0; i < DG_NV; i++) acc += (double)r.J[i] * qa[i];
+      if (r.other >= 0) {
+        const float* B = Wd.fb[r.other];
+        acc += (double)((B[6] - B[8] * r.ory) * r.od[0] + (B[7] + B[8] * r.orx) * r.od[1]);
+      }
+      double fnew = r.f + (r.aref - acc - reg * r.f) / (r.A + reg);
       double lo = 0, hi = 1e30;
       if (r.parent >= 0) { const double fn = R.row[r.parent].f; lo = -r.mu * fn; hi = r.mu * fn; }
       if (fnew < lo) fnew = lo;
@@ -432,12 +540,15 @@ __device__ __attribute__((noinline)) void dg_pgs(DgRows& R, DgWork& K, DgWorld& 
       const double df = fnew - r.f;
       if (df == 0) continue;
       r.f = fnew;
-      for (int i = 0; i < DG_NV; i++) K.qacc[i] += r.W[i] * df;
+#pragma unroll
+      for (int i = 0; i < DG_NV; i++) qa[i] += r.W[i] * df;
       if (r.other >= 0) {
         float* B = Wd.fb[r.other];
         B[6] += (float)((double)r.ou[0] * df); B[7] += (float)((double)r.ou[1] * df); B[8] += (float)((double)r.ou[2] * df);
       }
     }
+#pragma unroll
+  for (int i = 0; i < DG_NV; i++) K.qacc[i] = qa[i];
 }
 
 // circle (sphere footprint) vs the geoms of one planar body: contacts with normal from the circle
