@@ -310,7 +310,7 @@ def main(argv=None, run_factory=None, emit=print):
       t = timed(r4, 30, 5, lambda: None)
       ms, _ = r4.kernel_time_ms()
       res['c4_doggo_multitask_4096'] = {'value': 4096 * 30 / t, 'unit': 'env-steps/s', 'kernel_ms': ms,
-                                        'note': 'per GPU; fp64 articulated solve, 12 substeps, latency-bound (64 wavefronts)'}
+                                        'note': 'per GPU; fp64 articulated solve, 12 substeps, latency-bound (one wavefront per CU)'}
       r4.close()
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(args.task)
