@@ -41,6 +41,11 @@ struct sag_ctx {
   RobotInfo rb;
   int N;
   hipStream_t stream = nullptr;
+  // split form: the busy kernel (few, long, VALU-bound wavefronts) runs on a second stream beside
+  // the quiet kernel (many short memory-bound ones); fork/join events order them against the main stream
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;  // SAG_OVERLAP=0: both kernels on the main stream, one after the other
   float* S = nullptr;
   int32_t* I = nullptr;
   float* G = nullptr;  // [3][NBODY][N] spill of body accelerations beyond the LDS pool
@@ -242,16 +247,22 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   // split form: QUIET kernel over every env whose busy bit is clear, then BUSY kernel over the
   // rest (compacted per 256-env neighbourhood).  observe() and SAG_SPLIT=0 use the single form.
   const bool split = c->split && !observe_only && c->cfg.robot != SAG_ROBOT_DOGGO;
+  hipStream_t quiet_stream = c->stream;
   if (split) {
     HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(int32_t), c->stream));
     hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
                        c->d_rows, c->d_count);
+    if (c->overlap) {
+      HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      quiet_stream = c->stream2;
+    }
   }
 #define SAG_LAUNCH3(ROB, B_, X_)                                                                         \
   do {                                                                                                  \
     if (split) {                                                                                        \
-      hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);       \
       hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3((c->N + SAG_BUSY_ENVS - 1) / SAG_BUSY_ENVS), dim3(WAVE), 0, c->stream, a); \
+      hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, quiet_stream, a);    \
     } else {                                                                                            \
       hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);             \
     }                                                                                                   \
@@ -271,6 +282,10 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   }
 #undef SAG_LAUNCH
 #undef SAG_LAUNCH3
+  if (split && c->overlap) {
+    HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  }
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipGetLastError());
   return 0;
@@ -331,6 +346,14 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipSetDevice(cfg->device));
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   {
+    int lo = 0, hi = 0;  // (numerically lower = higher priority)
+    CREATE_CHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    CREATE_CHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+  }
+  CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  if (const char* e = getenv("SAG_OVERLAP")) c->overlap = atoi(e) != 0;
+  {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
   }
@@ -374,6 +397,9 @@ int sag_destroy(sag_ctx* c) {
                   c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);
+  if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return SAG_OK;
