@@ -18,7 +18,8 @@
 #include "sag_device.hpp"
 
 #ifndef SAG_SPLIT_MIN_ENVS
-#define SAG_SPLIT_MIN_ENVS 393216  // measured crossover (tools/split_sweep.py): ~400k envs, Point and Car
+#define SAG_SPLIT_MIN_ENVS 262144  // measured crossover (tools/split_sweep.py, overlapped launches): Point ~260k, Car ~390k
+#define SAG_SPLIT_MIN_ENVS_CAR 393216
 #endif
 
 using namespace sag;
@@ -331,7 +332,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   c->cfg = *cfg; c->rb = ROBOTS[cfg->robot]; c->N = cfg->n_envs;
   // below ~one resident round of wavefronts a step is latency-bound and two dependent launches
   // cost more than the divergence they remove
-  c->split = c->N >= SAG_SPLIT_MIN_ENVS;
+  c->split = c->N >= (cfg->robot == SAG_ROBOT_CAR ? SAG_SPLIT_MIN_ENVS_CAR : SAG_SPLIT_MIN_ENVS);
   if (const char* e = getenv("SAG_SPLIT")) c->split = atoi(e) != 0;
   const size_t N = (size_t)c->N;
 #define CREATE_CHK(call)                                                                         \
