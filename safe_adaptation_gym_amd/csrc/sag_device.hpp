@@ -1764,7 +1764,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 
 // ---- the three launch forms ------------------------------------------------------------
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
-__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
+__global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_DOGGO ? 1 : SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
   __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
   // Doggo: the Cholesky factor of the mass matrix, [190][64 lanes] fp64 = 95 KB (one wavefront per CU)
   __shared__ double dgL[ROBOT == SAG_ROBOT_DOGGO ? (DG_NTRI + 4 * DG_NV) * WAVE : 1];  // + 3 solve vectors, 1 / diagonal

@@ -105,3 +105,19 @@ def test_impossible_layout_raises_resampling_error():
       w.sample_layout()
   finally:
     wm.World._generate_new_layout = orig
+
+
+def test_doggo_record_is_the_reset_pose():
+  """World.record for Doggo leaves the robot extension block zero: the device (and the oracle)
+  read that as the reset pose of mujoco_bridge.py:59-63 - upright at robot_rot, z = z_height .22,
+  joints and velocities 0 - and fill it on the first step."""
+  from safe_adaptation_gym_amd import _native as nat
+  w = World(np.random.RandomState(3), benchmark.TASKS['go_to_goal'](), Robot('xmls/doggo.xml'))
+  w.sample_layout(); w.reset()
+  rf, ri = w.record()
+  assert rf.shape == (nat.REC_FLOATS,) and nat.REC_FLOATS == 184
+  assert not rf[nat.F_ROBOT_EXT:nat.F_ROBOT_EXT + 40].any()
+  assert rf[nat.F_CTRL_SCALE:nat.F_CTRL_SCALE + 12].min() > 0
+  wc = World(np.random.RandomState(3), benchmark.TASKS['go_to_goal'](), Robot('xmls/car.xml'))
+  wc.sample_layout(); wc.reset()
+  assert wc.record()[0][nat.F_ROBOT_EXT + 5] == 1.0   # car: rear-ball quaternion w
