@@ -1166,10 +1166,10 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     // (ascending index = the specification's order), so a wavefront runs the narrowphase
     // max-hits times, not once per body index that any lane happens to touch
     uint32_t hits = 0;
-#pragma unroll 1
-    for (int k = 0; k < nV; k++) {
+#pragma unroll
+    for (int k = 0; k < SAG_MAX_VASES; k++) {  // unrolled: static LDS offsets, loads issued together
       const float dx = LP(LS_X, k) - R.x, dyy = LP(LS_Y, k) - R.y, rs = my_bound + vase_r;
-      if (dx * dx + dyy * dyy <= rs * rs) hits |= 1u << k;
+      if (k < nV && dx * dx + dyy * dyy <= rs * rs) hits |= 1u << k;
     }
     if (has_box) {
       const float dx = LP(LS_X, BOX_ID) - R.x, dyy = LP(LS_Y, BOX_ID) - R.y, rs = my_bound + box_r;
