@@ -1,7 +1,7 @@
 // sag_api.hip - host side of the C ABI declared in include/sag.h.
 //
 // One context = one GPU = one HIP stream.  Device memory: the SoA world
-// (S: [SAG_REC_FLOATS][N] f32, I: [DI_COUNT][N] i32), AoS staging for records,
+// (S: [DEV_GROUPS][N] float4, I: tstate [N] + int4 [N]; sag_device.hpp didx / iaddr), AoS staging for records,
 // pinned host + device staging for the host-pointer step.  No allocation, no
 // synchronisation and no host<->device copy happens inside sag_step_device(),
 // so callers may capture it into a hipGraph.
@@ -358,7 +358,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
   }
-  CREATE_CHK(hipMalloc(&c->S, N * SAG_REC_FLOATS * sizeof(float)));
+  CREATE_CHK(hipMalloc(&c->S, N * DEV_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->I, N * DI_COUNT * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->d_rows, N * sizeof(int32_t)));
@@ -381,7 +381,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
     dg_build_model(model);
     CREATE_CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dg), &model, sizeof(model)));
   }
-  CREATE_CHK(hipMemsetAsync(c->S, 0, N * SAG_REC_FLOATS * sizeof(float), c->stream));
+  CREATE_CHK(hipMemsetAsync(c->S, 0, N * DEV_FLOATS * sizeof(float), c->stream));
   CREATE_CHK(hipMemsetAsync(c->I, 0, N * DI_COUNT * sizeof(int32_t), c->stream));
   CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK

@@ -23,8 +23,55 @@ namespace sag {
 
 constexpr int WAVE = 64;
 
-// device int fields
+// device int fields.  TSTATE is a plain [N] column (k_compact and the quiet kernel's busy test read
+// only it); the other four words of an env sit together as one int4 behind it.
 enum { DI_META = 0, DI_TSTATE = 1, DI_STEP = 2, DI_ENVID = 3, DI_FLAGS = 4, DI_COUNT = 5 };
+__host__ __device__ constexpr size_t iaddr(int w, size_t N, size_t i) {
+  return w == DI_TSTATE ? i : N + i * 4 + (w == DI_META ? 0 : (w == DI_STEP ? 1 : (w == DI_ENVID ? 2 : 3)));
+}
+
+// ---- device layout of the float state ---------------------------------------------------------
+// Groups of four floats per env, group-major: float4 number g of env i is ((float4*)S)[g * N + i].
+// A wavefront reading group g of 64 consecutive envs moves one contiguous KB (as coalesced as the
+// plain field-major layout), and a GATHER - the busy kernel reading scattered envs - moves a quarter
+// of the cache lines per useful float.  The order inside the device record follows what the step
+// prologue reads together, not the order of the ABI record (k_install / k_extract translate):
+//   0 robot x y yaw vx | 4 vy w goal_x goal_y | 8 last0 gear damp action_noise | 12 ctrl_scale0,1
+//   vase_size pillar_size | 16 pillars | 20..37 hazards, 38 hazard_size, 39 bound |
+//   40.. positions (x y yaw) of the 11 free bodies | 76.. their velocities (vx vy w) |
+//   112 buttons | 124 catch | 128 last1,2 | 130 keepouts | 136 rebuild pose | 140 ctrl_scale2.. |
+//   152 robot extension
+constexpr int DEV_FLOATS = 192, DEV_GROUPS = DEV_FLOATS / 4;
+constexpr int DV_POS = 40, DV_VEL = 76, DG_HAZ = 5, DG_POS = 10, DG_PILLARS = 4, DG_BUTTONS = 28;
+__host__ __device__ constexpr int didx(int k) {
+  return k < 6 ? k
+       : k < 9 ? 136 + (k - 6)
+       : k < 12 ? k
+       : k < 14 ? k
+       : k < 24 ? 140 + (k - 14)
+       : k == 24 ? 38
+       : k < 27 ? 14 + (k - 25)
+       : k < 32 ? 130 + (k - 27)
+       : k < 34 ? 6 + (k - 32)
+       : k < 38 ? 124 + (k - 34)
+       : k == 38 ? 8
+       : k < 41 ? 128 + (k - 39)
+       : k < 44 ? DV_POS + 30 + (k - 41)
+       : k < 47 ? DV_VEL + 30 + (k - 44)
+       : k < 65 ? 20 + (k - 47)
+       : k < 69 ? 16 + (k - 65)
+       : k < 81 ? 112 + (k - 69)
+       : k < 141 ? ((k - 81) % 6 < 3 ? DV_POS + 3 * ((k - 81) / 6) + (k - 81) % 6
+                                     : DV_VEL + 3 * ((k - 81) / 6) + (k - 81) % 6 - 3)
+       : k == 141 ? 39
+       : k < 144 ? 150 + (k - 142)
+       : 152 + (k - 144);
+}
+static_assert(didx(SAG_F_BUTTONS) == 112 && didx(SAG_F_VASES + 6 * 3 + 4) == DV_VEL + 10 && didx(SAG_F_BOX + 1) == DV_POS + 31 &&
+              didx(SAG_F_HAZARDS) == 4 * DG_HAZ && didx(SAG_F_PILLARS) == 4 * DG_PILLARS, "device layout constants");
+__host__ __device__ constexpr size_t saddr(int k, size_t N, size_t i) {
+  return ((size_t)(didx(k) >> 2) * N + i) * 4 + (didx(k) & 3);
+}
 
 // ---- packing of the int record into two device words -----------------------
 __host__ __device__ inline uint32_t pack_meta(const int32_t* ri) {
@@ -48,8 +95,8 @@ __host__ __device__ inline void unpack_tstate(uint32_t t, int32_t* ri) {
 
 struct StepArgs {
   int envs_per_wave;  // Doggo only (k_step<DOGGO>): 8..64
-  float* S;          // [SAG_REC_FLOATS][N]
-  int32_t* I;        // [DI_COUNT][N]
+  float* S;          // [DEV_GROUPS][N] float4 (see didx)
+  int32_t* I;        // tstate [N], then (meta, step, envid, flags) [N] int4 (see iaddr)
   int32_t N;
   const float* actions;   // [N][nu]
   const float* noise;     // [N][nu] or nullptr
@@ -412,7 +459,10 @@ __device__ unsigned long long g_cyc[3][CY_N + 1];
 }  // namespace sag
 #include "sag_doggo.hpp"
 namespace sag {
-#define SF(k) S[(size_t)(k) * N + i]
+#define SF(k) S[saddr((k), (size_t)N, (size_t)i)]
+// by DEVICE index (free-body positions DV_POS + 3 k + c, velocities DV_VEL + 3 k + c with k = BOX_ID for
+// the task object): no record-to-device translation for run-time body indices
+#define SD(d) S[((size_t)((d) >> 2) * N + i) * 4 + ((d) & 3)]
 #define LP(base, k) lds[((base) + (k)) * WAVE + lane]
 #define POOL(d, c) lds[(LS_POOL + (d) * 6 + (c)) * WAVE + lane]
 #define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]  // STG_STRIDE: constexpr of the enclosing kernel
@@ -427,7 +477,7 @@ struct Dyn {
   uint32_t dmap;  // 2 bits per body: 0 = no pool entry, 1..DPOOL
   uint32_t ovf;   // bodies whose velocity/acceleration live in global memory
   int nd;
-  __device__ int vel_field(int k) const { return k == BOX_ID ? SAG_F_BOX + 3 : SAG_F_VASES + 6 * k + 3; }
+  __device__ int vel_field(int k) const { return DV_VEL + 3 * k; }  // device index
   __device__ int slot(int k) const { return (int)(dmap >> (2 * k) & 3u) - 1; }
   __device__ bool has(int k) const { return (dmap >> (2 * k) & 3u) || (ovf >> k & 1u); }
   // give body k a dynamic entry (zero velocity unless `from_state`, zero acceleration)
@@ -435,13 +485,13 @@ struct Dyn {
     if (has(k)) return;
     float vx = 0, vy = 0, w = 0;
     if (nd < DPOOL) {
-      if (from_state) { const int f = vel_field(k); vx = SF(f); vy = SF(f + 1); w = SF(f + 2); }
+      if (from_state) { const int f = vel_field(k); vx = SD(f); vy = SD(f + 1); w = SD(f + 2); }
       const int d = nd++;
       dmap |= (uint32_t)(d + 1) << (2 * k);
       POOL(d, 0) = vx; POOL(d, 1) = vy; POOL(d, 2) = w; POOL(d, 3) = 0; POOL(d, 4) = 0; POOL(d, 5) = 0;
     } else {
       ovf |= 1u << k;  // velocity stays in its SoA home, acceleration in the spill array
-      if (!from_state) { const int f = vel_field(k); SF(f) = 0; SF(f + 1) = 0; SF(f + 2) = 0; }
+      if (!from_state) { const int f = vel_field(k); SD(f) = 0; SD(f + 1) = 0; SD(f + 2) = 0; }
       for (int c = 0; c < 3; c++) G[((size_t)c * NBODY + k) * N + i] = 0;
     }
   }
@@ -450,7 +500,7 @@ struct Dyn {
     if (d >= 0) { vx = POOL(d, 0); vy = POOL(d, 1); w = POOL(d, 2); ax = POOL(d, 3); ay = POOL(d, 4); aw = POOL(d, 5); }
     else if (ovf >> k & 1u) {
       const int f = vel_field(k);
-      vx = SF(f); vy = SF(f + 1); w = SF(f + 2);
+      vx = SD(f); vy = SD(f + 1); w = SD(f + 2);
       ax = G[((size_t)0 * NBODY + k) * N + i]; ay = G[((size_t)1 * NBODY + k) * N + i]; aw = G[((size_t)2 * NBODY + k) * N + i];
     } else { vx = vy = w = ax = ay = aw = 0; }
   }
@@ -462,7 +512,7 @@ struct Dyn {
   __device__ void set_vel(int k, float vx, float vy, float w) {
     const int d = slot(k);
     if (d >= 0) { POOL(d, 0) = vx; POOL(d, 1) = vy; POOL(d, 2) = w; }
-    else { const int f = vel_field(k); SF(f) = vx; SF(f + 1) = vy; SF(f + 2) = w; }
+    else { const int f = vel_field(k); SD(f) = vx; SD(f + 1) = vy; SD(f + 2) = w; }
   }
 };
 
@@ -838,25 +888,30 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 
   // ---- issue every load up front (bounds are context capacities, not per-env counts, so
   //      nothing waits on the meta word) ------------------------------------------------------
-  const uint32_t meta = (uint32_t)I[(size_t)DI_META * N + i];
-  uint32_t tstate = (uint32_t)I[(size_t)DI_TSTATE * N + i];
-  int step = I[(size_t)DI_STEP * N + i];
-  const uint32_t env_id = (uint32_t)I[(size_t)DI_ENVID * N + i];
+  // vector loads: one int4 and a handful of float4 per env (device layout: didx / iaddr)
+  const float4* __restrict__ S4 = reinterpret_cast<const float4*>(S);
+  auto G4 = [&](int g) { return S4[(size_t)g * N + i]; };
+  const int4 iw = reinterpret_cast<const int4*>(I + N)[i];
+  const uint32_t meta = (uint32_t)iw.x;
+  uint32_t tstate = (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)];
+  int step = iw.y;
+  const uint32_t env_id = (uint32_t)iw.z;
+  const float4 gA = G4(0), gB = G4(1), gC = G4(2), gD = G4(3);
   BV R;
-  R.x = SF(SAG_F_ROBOT); R.y = SF(SAG_F_ROBOT + 1);
-  float yaw = SF(SAG_F_ROBOT + 2);
-  R.vx = SF(SAG_F_ROBOT + 3); R.vy = SF(SAG_F_ROBOT + 4); R.w = SF(SAG_F_ROBOT + 5);
+  R.x = gA.x; R.y = gA.y;
+  float yaw = gA.z;
+  R.vx = gA.w; R.vy = gB.x; R.w = gB.y;
   R.ax = R.ay = R.aw = 0; R.dyn = 1;
-  const float gear = SF(SAG_F_GEAR), damp = SF(SAG_F_DAMP);
-  const float vsz = SF(SAG_F_VASE_SIZE), psz = SF(SAG_F_PILLAR_SIZE);
+  const float gear = gC.y, damp = gC.z;
+  const float vsz = gD.z, psz = gD.w;
   // car: wheel rates L, R; rear ball rate x, y, z (base axes); ball quaternion w, x, y, z
   float ext[9] = {0, 0, 0, 0, 0, 1, 0, 0, 0}, eacc[5] = {0, 0, 0, 0, 0};
   if constexpr (CAR) {
 #pragma unroll
     for (int k = 0; k < 9; k++) ext[k] = SF(SAG_F_ROBOT_EXT + k);
   }
-  float goalx = SF(SAG_F_GOAL), goaly = SF(SAG_F_GOAL + 1);
-  float last0 = SF(SAG_F_LAST);
+  float goalx = gB.z, goaly = gB.w;
+  float last0 = gC.x;
   float a0 = 0, a1 = 0, n0 = 0, n1 = 0;
   if (!p.observe_only) {
     if constexpr (!DOGGO) {
@@ -866,31 +921,43 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
   }
   {
-    float vpos[NBODY * 3];
+    // positions (x y yaw) of the 11 free bodies: 9 consecutive groups of the device record
+    float vpos[36];
+    const int need = HAS_TBOX && p.has_box ? 9 : (3 * capV + 3) / 4;
 #pragma unroll
-    for (int k = 0; k < SAG_MAX_VASES; k++) {
-      if (k < capV) {
-        vpos[3 * k] = SF(SAG_F_VASES + 6 * k); vpos[3 * k + 1] = SF(SAG_F_VASES + 6 * k + 1);
-        vpos[3 * k + 2] = SF(SAG_F_VASES + 6 * k + 2);
-      } else { vpos[3 * k] = vpos[3 * k + 1] = vpos[3 * k + 2] = 0; }
+    for (int g = 0; g < 9; g++) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g < need) v = G4(DG_POS + g);
+      vpos[4 * g] = v.x; vpos[4 * g + 1] = v.y; vpos[4 * g + 2] = v.z; vpos[4 * g + 3] = v.w;
     }
-    if (HAS_TBOX && p.has_box) { vpos[3 * BOX_ID] = SF(SAG_F_BOX); vpos[3 * BOX_ID + 1] = SF(SAG_F_BOX + 1); vpos[3 * BOX_ID + 2] = SF(SAG_F_BOX + 2); }
-    else { vpos[3 * BOX_ID] = vpos[3 * BOX_ID + 1] = vpos[3 * BOX_ID + 2] = 0; }
+#pragma unroll
+    for (int k = 0; k < SAG_MAX_VASES; k++)
+      if (k >= capV) { vpos[3 * k] = vpos[3 * k + 1] = vpos[3 * k + 2] = 0; }
+    if (!(HAS_TBOX && p.has_box)) { vpos[3 * BOX_ID] = vpos[3 * BOX_ID + 1] = vpos[3 * BOX_ID + 2] = 0; }
 #pragma unroll
     for (int k = 0; k < NBODY; k++) { LP(LS_X, k) = vpos[3 * k]; LP(LS_Y, k) = vpos[3 * k + 1]; LP(LS_YAW, k) = vpos[3 * k + 2]; }
   }
   // static colliders: pillars then buttons, in registers
   float stx[NSTAT], sty[NSTAT];
-#pragma unroll
-  for (int k = 0; k < SAG_MAX_PILLARS; k++) {
-    stx[k] = k < capP ? SF(SAG_F_PILLARS + 2 * k) : 0.f;
-    sty[k] = k < capP ? SF(SAG_F_PILLARS + 2 * k + 1) : 0.f;
+  {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (capP > 0) v = G4(DG_PILLARS);
+    stx[0] = v.x; sty[0] = v.y; stx[1] = capP > 1 ? v.z : 0.f; sty[1] = capP > 1 ? v.w : 0.f;
+    static_assert(SAG_MAX_PILLARS == 2, "pillars fill one group");
   }
   if constexpr (HAS_BTN) {
+    float bt[12];
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (2 * g < capB) v = G4(DG_BUTTONS + g);
+      bt[4 * g] = v.x; bt[4 * g + 1] = v.y; bt[4 * g + 2] = v.z; bt[4 * g + 3] = v.w;
+    }
+    static_assert(SAG_MAX_BUTTONS == 6, "buttons fill three groups");
 #pragma unroll
     for (int k = 0; k < SAG_MAX_BUTTONS; k++) {
-      stx[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k) : 0.f;
-      sty[SAG_MAX_PILLARS + k] = k < capB ? SF(SAG_F_BUTTONS + 2 * k + 1) : 0.f;
+      stx[SAG_MAX_PILLARS + k] = k < capB ? bt[2 * k] : 0.f;
+      sty[SAG_MAX_PILLARS + k] = k < capB ? bt[2 * k + 1] : 0.f;
     }
   }
   const int task = meta & 15, nH = meta >> 4 & 15, nV = meta >> 8 & 15, nP = meta >> 12 & 3,
@@ -936,8 +1003,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       float r = sqrtf(-2.0f * logf(u1)), a = 6.28318530717958647692f * u2;
       n0 = r * cosf(a); n1 = r * sinf(a);
     }
-    const float an = SF(SAG_F_ACTION_NOISE);
-    const float cs0 = SF(SAG_F_CTRL_SCALE), cs1 = SF(SAG_F_CTRL_SCALE + 1);
+    const float an = gC.w;
+    const float cs0 = gD.x, cs1 = gD.y;
     ctrl0 = clampf(a0 + an * n0, -cs0, cs0);
     ctrl1 = clampf(a1 + an * n1, -cs1, cs1);
     // ---- CatchGoal.set_mocaps (tasks/catch_goal.py:20-31), time before the step ---
@@ -1028,9 +1095,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     for (int k = 0; k < NBODY; k++) {
       const bool isb = k == BOX_ID;
       const bool on = isb ? has_box : k < nV;
-      const int f = isb ? SAG_F_BOX : SAG_F_VASES + 6 * k;
+      const int f = DV_VEL + 3 * k;
       Wd.fb[k][0] = LP(LS_X, k); Wd.fb[k][1] = LP(LS_Y, k); Wd.fb[k][2] = LP(LS_YAW, k);
-      Wd.fb[k][3] = on ? SF(f + 3) : 0.f; Wd.fb[k][4] = on ? SF(f + 4) : 0.f; Wd.fb[k][5] = on ? SF(f + 5) : 0.f;
+      Wd.fb[k][3] = on ? SD(f) : 0.f; Wd.fb[k][4] = on ? SD(f + 1) : 0.f; Wd.fb[k][5] = on ? SD(f + 2) : 0.f;
       for (int c = 0; c < 6; c++) Wd.minv[k][c] = 0;
       if (!isb) { Wd.minv[k][0] = Wd.minv[k][3] = 1.0f / vk.m; Wd.minv[k][5] = 1.0f / vk.I; }
       else {
@@ -1063,8 +1130,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       LP(LS_X, k) = Wd.fb[k][0]; LP(LS_Y, k) = Wd.fb[k][1]; LP(LS_YAW, k) = Wd.fb[k][2];
       if (Wd.fb[k][3] != 0 || Wd.fb[k][4] != 0 || Wd.fb[k][5] != 0) awake |= 1u << k;
       if (!p.observe_only && live) {
-        const int f = isb ? SAG_F_BOX : SAG_F_VASES + 6 * k;
-        for (int c = 0; c < 6; c++) SF(f + c) = Wd.fb[k][c];
+        for (int c = 0; c < 3; c++) { SD(DV_POS + 3 * k + c) = Wd.fb[k][c]; SD(DV_VEL + 3 * k + c) = Wd.fb[k][3 + c]; }
       }
     }
   } else {
@@ -1361,8 +1427,10 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   const float boxx = LP(LS_X, BOX_ID), boxy = LP(LS_Y, BOX_ID);
   if (!p.observe_only && live) {
     if constexpr (!DOGGO) {
-      SF(SAG_F_ROBOT) = R.x; SF(SAG_F_ROBOT + 1) = R.y; SF(SAG_F_ROBOT + 2) = yaw;
-      SF(SAG_F_ROBOT + 3) = R.vx; SF(SAG_F_ROBOT + 4) = R.vy; SF(SAG_F_ROBOT + 5) = R.w;
+      // groups 0 and 1 whole (the goal half of group 1 is rewritten by the reward block if it moves)
+      float4* __restrict__ W4 = reinterpret_cast<float4*>(S);
+      W4[(size_t)0 * N + i] = make_float4(R.x, R.y, yaw, R.vx);
+      W4[(size_t)1 * N + i] = make_float4(R.vy, R.w, gB.z, gB.w);
     }
     if constexpr (CAR) {
 #pragma unroll
@@ -1370,13 +1438,13 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     for (uint32_t m = dirty; m; m &= m - 1) {
       const int k = __ffs(m) - 1;
-      const int f = k == BOX_ID ? SAG_F_BOX : SAG_F_VASES + 6 * k;
-      SF(f) = LP(LS_X, k); SF(f + 1) = LP(LS_Y, k); SF(f + 2) = LP(LS_YAW, k);
+      const int f = DV_POS + 3 * k, fv = DV_VEL + 3 * k;
+      SD(f) = LP(LS_X, k); SD(f + 1) = LP(LS_Y, k); SD(f + 2) = LP(LS_YAW, k);
       const int d = dy.slot(k);
-      if (d >= 0) { SF(f + 3) = POOL(d, 0); SF(f + 4) = POOL(d, 1); SF(f + 5) = POOL(d, 2); }
+      if (d >= 0) { SD(fv) = POOL(d, 0); SD(fv + 1) = POOL(d, 1); SD(fv + 2) = POOL(d, 2); }
     }
     step += 1;
-    I[(size_t)DI_STEP * N + i] = step;
+    I[iaddr(DI_STEP, (size_t)N, (size_t)i)] = step;
   }
   tstate = (tstate & ~(TS_AWAKE_BITS << TS_AWAKE_SHIFT)) | (awake & TS_AWAKE_BITS) << TS_AWAKE_SHIFT;
   // ---- classification for the NEXT step (QUIET / BUSY split): busy unless provably nothing can
@@ -1413,12 +1481,20 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   // hazards are only needed from here on (cost, lidar): loading them late keeps 18 registers
   // free during the physics; the reward arithmetic below covers the latency
   float hzx[SAG_MAX_HAZARDS], hzy[SAG_MAX_HAZARDS];
+  float hsz;
+  {
+    float hz[20];  // 9 x (x, y), hazard_size, bound: five groups
 #pragma unroll
-  for (int k = 0; k < SAG_MAX_HAZARDS; k++) {
-    hzx[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k) : 0.f;
-    hzy[k] = k < capH ? SF(SAG_F_HAZARDS + 2 * k + 1) : 0.f;
+    for (int g = 0; g < 5; g++) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g == 4 || 2 * g < capH) v = G4(DG_HAZ + g);
+      hz[4 * g] = v.x; hz[4 * g + 1] = v.y; hz[4 * g + 2] = v.z; hz[4 * g + 3] = v.w;
+    }
+    static_assert(SAG_MAX_HAZARDS == 9, "hazards + size fill five groups");
+#pragma unroll
+    for (int k = 0; k < SAG_MAX_HAZARDS; k++) { hzx[k] = k < capH ? hz[2 * k] : 0.f; hzy[k] = k < capH ? hz[2 * k + 1] : 0.f; }
+    hsz = hz[18];
   }
-  const float hsz = SF(SAG_F_HAZARD_SIZE);
 
   // ---- PhysicsError branch (safe_adaptation_gym.py:73-75) -------------------------
   bool bad = false;
@@ -1444,7 +1520,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   if (!p.observe_only && !bad) {
     if (task == SAG_TASK_PRESS_BUTTONS || task == SAG_TASK_PRESS_BUTTONS_SCARCE) {
       int gb = tstate & 7, bstate = tstate >> 3 & 1, timer = tstate >> 4 & 7;
-      double gd = dist2d(rx, ry, SF(SAG_F_BUTTONS + 2 * gb), SF(SAG_F_BUTTONS + 2 * gb + 1));
+      double gd = dist2d(rx, ry, SD(112 + 2 * gb), SD(113 + 2 * gb));
       double r = task == SAG_TASK_PRESS_BUTTONS ? (double)last0 - gd : 0.0;
       float last = (float)gd;
       if (btn_mask >> gb & 1) {
@@ -1452,7 +1528,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         gb = (int)(rng.word() & 3u);
         if (rng.exhausted) flags |= 2;
         timer = 5;
-        last = (float)dist2d(rx, ry, SF(SAG_F_BUTTONS + 2 * gb), SF(SAG_F_BUTTONS + 2 * gb + 1));
+        last = (float)dist2d(rx, ry, SD(112 + 2 * gb), SD(113 + 2 * gb));
         bstate = 0;
       }
       if (bstate == 0) {
@@ -1534,9 +1610,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       const int s_pos0 = __shfl(rng.pos, src), s_len = __shfl(rng.len, src);
       const uint32_t s_env = __shfl(rng.env, src), s_step = __shfl(rng.step, src);
       const uint32_t* s_tape = p.tape ? p.tape + (size_t)s_i * p.tape_len : nullptr;
-      const double k_robot = S[(size_t)SAG_F_KEEPOUT * N + s_i], k_haz = S[(size_t)(SAG_F_KEEPOUT + 1) * N + s_i],
-                   k_vase = S[(size_t)(SAG_F_KEEPOUT + 2) * N + s_i], k_pil = S[(size_t)(SAG_F_KEEPOUT + 3) * N + s_i],
-                   k_box = S[(size_t)(SAG_F_KEEPOUT + 4) * N + s_i];
+      const double k_robot = S[saddr(SAG_F_KEEPOUT, (size_t)N, (size_t)s_i)], k_haz = S[saddr(SAG_F_KEEPOUT + 1, (size_t)N, (size_t)s_i)],
+                   k_vase = S[saddr(SAG_F_KEEPOUT + 2, (size_t)N, (size_t)s_i)], k_pil = S[saddr(SAG_F_KEEPOUT + 3, (size_t)N, (size_t)s_i)],
+                   k_box = S[saddr(SAG_F_KEEPOUT + 4, (size_t)N, (size_t)s_i)];
       int winner = -1, exhausted = 0;
       float w_gx = 0, w_gy = 0;
 #pragma unroll 1
@@ -1618,7 +1694,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       SF(SAG_F_GOAL) = goalx; SF(SAG_F_GOAL + 1) = goaly;
     }
   }
-  if (!p.observe_only && live) I[(size_t)DI_TSTATE * N + i] = (int32_t)tstate;
+  if (!p.observe_only && live) I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)] = (int32_t)tstate;
 
   // ---- cost (world.py:144-155): hazard test in fp32 unless within 1e-5 of the threshold,
   //      where the reference's fp64 expression decides -----------------------------------
@@ -1637,7 +1713,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     cost = c > 0;
   }
-  if (flags && live) I[(size_t)DI_FLAGS * N + i] |= flags;
+  if (flags && live) I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)] |= flags;
 
   CYC(CY_COST);
   // ---- observation (safe_adaptation_gym.py:120-139, 225-237): four column chunks
@@ -1797,7 +1873,7 @@ __global__ __launch_bounds__(WAVE, SAG_QUIET_MIN_WAVES) void k_step_quiet(StepAr
   __shared__ float lds[QSLOTS * WAVE];
   const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
   const bool in = gi < p.N;
-  const bool busy = in && ((uint32_t)p.I[(size_t)DI_TSTATE * p.N + gi] & (TS_BUSY_BIT << p.phase));
+  const bool busy = in && ((uint32_t)p.I[iaddr(DI_TSTATE, (size_t)p.N, (size_t)gi)] & (TS_BUSY_BIT << p.phase));
   const uint64_t skip = __ballot(busy || !in);
   if (skip == ~0ull) return;  // wave-uniform: nothing quiet here
   const bool live = in && !busy;
@@ -1818,7 +1894,7 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int ph
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int e = e0 + j * WAVE + lane;
-    b[j] = e < N && ((uint32_t)I[(size_t)DI_TSTATE * N + e] & (TS_BUSY_BIT << phase));
+    b[j] = e < N && ((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] & (TS_BUSY_BIT << phase));
     const uint64_t m = __ballot(b[j]);
     pre[j] = __popcll(m & ((1ull << lane) - 1));
     if (lane == 0) wave_tot[wv][j] = __popcll(m);
@@ -1870,7 +1946,7 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
   int i = env_ids ? env_ids[j] : j;
   const float* rf = rec_f + (size_t)j * SAG_REC_FLOATS;
   const int32_t* ri = rec_i + (size_t)j * SAG_REC_INTS;
-  for (int k = 0; k < SAG_REC_FLOATS; k++) S[(size_t)k * N + i] = rf[k];
+  for (int k = 0; k < SAG_REC_FLOATS; k++) S[saddr(k, (size_t)N, (size_t)i)] = rf[k];
   // derived word: which free bodies must be looked at (moving, or possibly overlapping something,
   // in which case the first substeps resolve it); the others are asleep and are skipped
   uint32_t awake = 0;
@@ -1903,12 +1979,12 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
       }
     }
   }
-  I[(size_t)DI_META * N + i] = (int32_t)pack_meta(ri);
+  I[iaddr(DI_META, (size_t)N, (size_t)i)] = (int32_t)pack_meta(ri);
   // the first step after an install runs in BUSY mode (nothing has been classified yet)
-  I[(size_t)DI_TSTATE * N + i] = (int32_t)(pack_tstate(ri) | awake << TS_AWAKE_SHIFT | TS_BUSY_BIT | TS_BUSY_BIT << 1);
-  I[(size_t)DI_STEP * N + i] = ri[SAG_I_STEP];
-  I[(size_t)DI_ENVID * N + i] = ri[SAG_I_ENV_ID];
-  I[(size_t)DI_FLAGS * N + i] = ri[SAG_I_FLAGS];
+  I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)] = (int32_t)(pack_tstate(ri) | awake << TS_AWAKE_SHIFT | TS_BUSY_BIT | TS_BUSY_BIT << 1);
+  I[iaddr(DI_STEP, (size_t)N, (size_t)i)] = ri[SAG_I_STEP];
+  I[iaddr(DI_ENVID, (size_t)N, (size_t)i)] = ri[SAG_I_ENV_ID];
+  I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)] = ri[SAG_I_FLAGS];
   if (init_task) {
     // task.reset() as run by World.reset right after rebuild (world.py:167-170):
     // `last` distances from the installed positions (go_to_goal.py:54-55,
@@ -1918,13 +1994,13 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
     bool buttons = task == SAG_TASK_PRESS_BUTTONS || task == SAG_TASK_PRESS_BUTTONS_SCARCE;
     if (buttons) {
       int b = ri[SAG_I_GOAL_BUTTON];
-      S[(size_t)SAG_F_LAST * N + i] = (float)dist2d(rx, ry, rf[SAG_F_BUTTONS + 2 * b], rf[SAG_F_BUTTONS + 2 * b + 1]);
+      S[saddr(SAG_F_LAST, (size_t)N, (size_t)i)] = (float)dist2d(rx, ry, rf[SAG_F_BUTTONS + 2 * b], rf[SAG_F_BUTTONS + 2 * b + 1]);
     } else if (task != SAG_TASK_COLLECT) {
-      S[(size_t)SAG_F_LAST * N + i] = (float)dist2d(rx, ry, rf[SAG_F_GOAL], rf[SAG_F_GOAL + 1]);
+      S[saddr(SAG_F_LAST, (size_t)N, (size_t)i)] = (float)dist2d(rx, ry, rf[SAG_F_GOAL], rf[SAG_F_GOAL + 1]);
     }
     if (ri[SAG_I_BOX_KIND] != SAG_BOX_NONE) {  // PushBox.reset (push_box.py:94-100)
-      S[(size_t)(SAG_F_LAST + 2) * N + i] = (float)dist2d(rf[SAG_F_GOAL], rf[SAG_F_GOAL + 1], rf[SAG_F_BOX], rf[SAG_F_BOX + 1]);
-      S[(size_t)(SAG_F_LAST + 1) * N + i] = (float)dist2d(rx, ry, rf[SAG_F_BOX], rf[SAG_F_BOX + 1]);
+      S[saddr(SAG_F_LAST + 2, (size_t)N, (size_t)i)] = (float)dist2d(rf[SAG_F_GOAL], rf[SAG_F_GOAL + 1], rf[SAG_F_BOX], rf[SAG_F_BOX + 1]);
+      S[saddr(SAG_F_LAST + 1, (size_t)N, (size_t)i)] = (float)dist2d(rx, ry, rf[SAG_F_BOX], rf[SAG_F_BOX + 1]);
     }
   }
 }
@@ -1936,13 +2012,13 @@ __global__ void k_extract(const float* S, const int32_t* I, int N, const int32_t
   int i = env_ids ? env_ids[j] : j;
   float* rf = rec_f + (size_t)j * SAG_REC_FLOATS;
   int32_t* ri = rec_i + (size_t)j * SAG_REC_INTS;
-  for (int k = 0; k < SAG_REC_FLOATS; k++) rf[k] = S[(size_t)k * N + i];
+  for (int k = 0; k < SAG_REC_FLOATS; k++) rf[k] = S[saddr(k, (size_t)N, (size_t)i)];
   for (int k = 0; k < SAG_REC_INTS; k++) ri[k] = 0;
-  unpack_meta((uint32_t)I[(size_t)DI_META * N + i], ri);
-  unpack_tstate((uint32_t)I[(size_t)DI_TSTATE * N + i], ri);
-  ri[SAG_I_STEP] = I[(size_t)DI_STEP * N + i];
-  ri[SAG_I_ENV_ID] = I[(size_t)DI_ENVID * N + i];
-  ri[SAG_I_FLAGS] = I[(size_t)DI_FLAGS * N + i];
+  unpack_meta((uint32_t)I[iaddr(DI_META, (size_t)N, (size_t)i)], ri);
+  unpack_tstate((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)], ri);
+  ri[SAG_I_STEP] = I[iaddr(DI_STEP, (size_t)N, (size_t)i)];
+  ri[SAG_I_ENV_ID] = I[iaddr(DI_ENVID, (size_t)N, (size_t)i)];
+  ri[SAG_I_FLAGS] = I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)];
 }
 
 // ---------------------------------------------------------------------------
@@ -1985,7 +2061,7 @@ __global__ void k_fill_actions(float* actions, const int32_t* I, int N, int nu, 
                                uint32_t k1, uint32_t step_index) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  uint32_t env = (uint32_t)I[(size_t)DI_ENVID * N + i];
+  uint32_t env = (uint32_t)I[iaddr(DI_ENVID, (size_t)N, (size_t)i)];
   for (int j = 0; j < nu; j += 4) {
     uint32_t c[4] = {env, step_index, (uint32_t)(j >> 2), 2u};
     philox4x32_10(c, k0, k1);

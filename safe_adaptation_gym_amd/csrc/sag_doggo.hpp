@@ -105,7 +105,7 @@ __device__ inline void dg_axis_rot(const double* u, double ang, double* R) {
 
 // record fields -> state.  A zero quaternion means "upright at ROBOT yaw, z = .22, joints 0" (sag.h)
 __device__ inline void dg_load(DgState& D, const float* S, size_t N, size_t i) {
-  auto F = [&](int k) { return (double)S[(size_t)k * N + i]; };
+  auto F = [&](int k) { return (double)S[saddr(k, N, i)]; };
   D.pos[0] = F(SAG_F_ROBOT); D.pos[1] = F(SAG_F_ROBOT + 1); D.pos[2] = F(SAG_F_ROBOT_EXT);
   for (int k = 0; k < 4; k++) D.quat[k] = F(SAG_F_ROBOT_EXT + 1 + k);
   const double n2 = D.quat[0] * D.quat[0] + D.quat[1] * D.quat[1] + D.quat[2] * D.quat[2] + D.quat[3] * D.quat[3];
@@ -126,7 +126,7 @@ __device__ inline void dg_store(const DgState& D, float* S, size_t N, size_t i, 
   double R[9], ww[3];
   dg_quat2mat(D.quat, R);
   dg_matvec(R, D.wloc, ww);
-  auto W = [&](int k, double v) { S[(size_t)k * N + i] = (float)v; };
+  auto W = [&](int k, double v) { S[saddr(k, N, i)] = (float)v; };
   yaw_out = (float)atan2(R[3], R[0]); wz_out = (float)ww[2];
   W(SAG_F_ROBOT, D.pos[0]); W(SAG_F_ROBOT + 1, D.pos[1]); W(SAG_F_ROBOT + 2, yaw_out);
   W(SAG_F_ROBOT + 3, D.vlin[0]); W(SAG_F_ROBOT + 4, D.vlin[1]); W(SAG_F_ROBOT + 5, wz_out);
