@@ -312,6 +312,22 @@ def main(argv=None, run_factory=None, emit=print):
       res['c4_doggo_multitask_4096'] = {'value': 4096 * 30 / t, 'unit': 'env-steps/s', 'kernel_ms': ms,
                                         'note': 'per GPU; fp64 articulated solve, 12 substeps, latency-bound (one wavefront per CU)'}
       r4.close()
+      # BASELINE config 5 (stretch): Doggo / haul_box with rgb_observation: step + 64x64x3 render per env
+      r5 = DeviceRun('haul_box', 4096, device, 0, robot='doggo')
+      d_img = r5.ctx.dev_alloc(4096 * 64 * 64 * 3)
+      r5.burn_in(10)
+      import time as _t
+      r5.ctx.render_rgb_device(d_img); r5.wait()
+      t0 = _t.perf_counter()
+      for _ in range(20):
+        r5.ctx.render_rgb_device(d_img)
+      r5.wait()
+      t_render = (_t.perf_counter() - t0) / 20
+      t = timed(r5, 20, 2, lambda: None)
+      res['c5_doggo_haul_box_rgb_4096'] = {'render_ms': t_render * 1e3, 'step_ms': t / 20 * 1e3,
+                                           'value': 4096 / (t / 20 + t_render), 'unit': 'env-steps/s',
+                                           'note': 'per GPU: one step + one 64x64x3 uint8 first-person image per env'}
+      r5.close()
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(args.task)
   if rank == 0:

@@ -234,6 +234,12 @@ int sag_dev_fill_actions(sag_ctx* ctx, float* d_actions, uint32_t step_index);
  * stream: mean milliseconds per launch over the launches since the last call
  * with reset != 0.  Feeds bench.py's roofline.achieved. */
 int sag_kernel_time_ms(sag_ctx* ctx, int32_t reset, double* mean_ms, int64_t* launches);
+/* rgb_observation (safe_adaptation_gym.py:122-126 `physics.render(height=64, width=64,
+ * camera_id='vision')`): the first-person image of every env at its current state,
+ * out[n_envs][64][64][3] uint8 (row 0 = top).  Host buffer / device buffer variants. */
+int sag_render_rgb(sag_ctx* ctx, uint8_t* out);
+int sag_render_rgb_device(sag_ctx* ctx, void* d_out);
+
 /* Diagnostic: how many envs the last split step handed to the busy kernel (0 for the
  * single-kernel form).  Synchronises the context stream. */
 int sag_busy_count(sag_ctx* ctx, int32_t* count);

@@ -1339,6 +1339,8 @@ static void observe(const OEnv* e, int robot, const real qacc[3], real* obs) {
   }
 }
 
+#include "sag_oracle_render.inc"
+
 /* hazard part of World.compute_cost (world.py:147-153), fp64 on the stored poses */
 static int hazard_cost(const OEnv* e, double* margin) {
   const real* f = e->f;

@@ -71,6 +71,7 @@ struct sag_ctx {
   bool timing = false;
   int phase = 0;       // busy-bit copy read by the next step launch
   int n_cu = 256;      // compute units of the device
+  uint8_t* d_rgb = nullptr;  // [N][64][64][3], allocated by the first sag_render_rgb
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
@@ -395,7 +396,7 @@ int sag_destroy(sag_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
-                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch};
+                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -681,6 +682,26 @@ int sag_debug_cycles(sag_ctx* c, int32_t reset, uint64_t* out, int32_t n) {
   for (int k = 0; k < n; k++) out[k] = 0;
   return SAG_ERR_UNSUPPORTED;
 #endif
+}
+
+// rgb_observation: [n_envs][64][64][3] uint8 image of the robot camera at the current state
+int sag_render_rgb_device(sag_ctx* c, void* d_out) {
+  if (!c || !d_out) return c ? fail(c, SAG_ERR_ARG, "null argument") : SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipLaunchKernelGGL(k_render_rgb, dim3(c->N), dim3(256), 0, c->stream, c->S, c->I, c->N, c->cfg.robot, (uint8_t*)d_out);
+  HIPCHK(c, hipGetLastError());
+  return SAG_OK;
+}
+int sag_render_rgb(sag_ctx* c, uint8_t* out) {
+  if (!c || !out) return c ? fail(c, SAG_ERR_ARG, "null argument") : SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const size_t bytes = (size_t)c->N * 64 * 64 * 3;
+  if (!c->d_rgb) HIPCHK(c, hipMalloc(&c->d_rgb, bytes));
+  int rc = sag_render_rgb_device(c, c->d_rgb);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(out, c->d_rgb, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
 }
 
 int sag_busy_count(sag_ctx* c, int32_t* count) {

@@ -2071,3 +2071,4 @@ __global__ void k_fill_actions(float* actions, const int32_t* I, int N, int nu, 
 }
 
 }  // namespace sag
+#include "sag_render.hpp"

@@ -52,8 +52,9 @@ class BatchedSafeAdaptationGym:
 
   def __init__(self, robot_base, n_envs=1, rgb_observation=False, config=None, devices=None,
                parity_rng=False, device_seed=0):
-    if rgb_observation:
-      raise NotImplementedError('rgb_observation (SURVEY 8f rank 3) is not built yet')
+    # rgb_observation: the observation is the robot camera's 64 x 64 x 3 uint8 image
+    # (safe_adaptation_gym.py:122-126,148-149), ray-cast on the device
+    self._rgb_observation = bool(rgb_observation)
     self.robot = Robot(robot_base)
     self.n_envs = int(n_envs)
     self.base_config = config
@@ -79,6 +80,8 @@ class BatchedSafeAdaptationGym:
   # -- reference surface ----------------------------------------------------------
   @property
   def observation_space(self):
+    if self._observation_space is None and self._rgb_observation:
+      self._observation_space = Box(0, 255, (64, 64, 3), np.uint8)
     if self._observation_space is None:
       d = self.robot.obs_dim
       lidar = 3 * self.NUM_LIDAR_BINS
@@ -132,6 +135,8 @@ class BatchedSafeAdaptationGym:
     outs = self._map(lambda c, s, e: c.step(a[s:e], None if noise is None else noise[s:e],
                                             None if tapes is None else tapes[s:e]))
     obs = np.concatenate([o[0] for o in outs])
+    if self._rgb_observation:
+      obs = self._render_rgb()
     rew = np.concatenate([o[1] for o in outs])
     cost = np.concatenate([o[2] for o in outs]).astype(np.float32)
     done = np.concatenate([o[3] for o in outs]).astype(bool)
@@ -146,6 +151,9 @@ class BatchedSafeAdaptationGym:
     reward = rew if self._reward_dim == 2 else rew[:, 0]
     info = {'cost': cost, 'bound': self._bounds, 'goal_met': met}
     return obs, reward, done, info
+
+  def _render_rgb(self):
+    return np.concatenate(self._map(lambda c, s, e: c.render_rgb()))
 
   def render(self, mode='human'):
     raise NotImplementedError('rendering is out of scope (SURVEY 8f rank 4)')
@@ -219,6 +227,8 @@ class BatchedSafeAdaptationGym:
     }
 
   def _observe(self):
+    if self._rgb_observation:
+      return self._render_rgb()
     return np.concatenate(self._map(lambda c, s, e: c.observe()))
 
 

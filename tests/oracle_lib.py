@@ -86,10 +86,16 @@ class Oracle:
     lib.sago_actions.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, fp]
     lib.sago_philox.argtypes = [up, up, up]
     lib.sago_robot_info.argtypes = [C.c_int, ip, dp]
+    lib.sago_render_rgb.argtypes = [C.POINTER(OEnv), C.c_int, bp]
     lib.sago_doggo_substeps.argtypes = [C.POINTER(OEnv), dp, C.c_int, C.c_double]
     lib.sago_doggo_energy.argtypes = [C.POINTER(OEnv)]
     lib.sago_doggo_energy.restype = C.c_double
     lib.sago_doggo_debug.argtypes = [C.POINTER(OEnv), dp, dp, dp, dp, dp]
+
+  def render_rgb(self, e, robot):
+    img = np.zeros((64, 64, 3), np.uint8)
+    self.lib.sago_render_rgb(C.byref(e), robot, img.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return img
 
   # -- doggo diagnostics -----------------------------------------------------
   def doggo_substeps(self, e, ctrl12, nstep, h=0.012):

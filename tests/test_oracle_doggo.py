@@ -217,3 +217,39 @@ def test_observation_layout(oracle):
   rf[ol.F_GOAL:ol.F_GOAL + 2] = [np.cos(yaw), np.sin(yaw)]
   obs = np.array(oracle.observe(oracle.env(rf, ri), DOGGO).obs)
   assert obs[32] == pytest.approx(0.8, abs=1e-9)
+
+
+# ---- rgb_observation specification (oracle/sag_oracle_render.inc) ---------------------------
+def test_render_known_answers(oracle):
+  """Camera of point.xml:14 (fovy 90, looking along +x, pitched 21.8 deg down): the top rows see
+  the sky (blue gradient), the bottom rows the grey checker floor; a pillar 1 m straight ahead
+  fills the image centre with its colour (.5 .5 1) x shade; a hazard disc under the view tints the
+  floor blue by alpha .25."""
+  from golden_util import base_record
+  rf, ri = base_record('go_to_goal', ['robot', 'goal'], {'robot': 0.4})
+  rf[ol.F_GOAL:ol.F_GOAL + 2] = [-3.0, 0.0]   # behind the camera
+  img = oracle.render_rgb(oracle.env(rf, ri), 0)
+  top, bottom = img[0].astype(int), img[-1].astype(int)
+  assert (top[:, 2] > top[:, 0] + 50).all() and (np.abs(bottom[:, 0] - bottom[:, 1]) <= 1).all()
+  assert set(np.unique(bottom[:, 0])) <= {int(0.7 * 255 + .5), int(0.8 * 255 + .5)}
+  # pillar ahead
+  rf2, ri2 = base_record('go_to_goal', ['robot', 'goal', 'pillars0'], {'robot': 0.4})
+  rf2[ol.F_GOAL:ol.F_GOAL + 2] = [-3.0, 0.0]
+  rf2[ol.F_PILLARS:ol.F_PILLARS + 2] = [1.0, 0.0]
+  img2 = oracle.render_rgb(oracle.env(rf2, ri2), 0)
+  centre = img2[20, 32].astype(float) / 255
+  assert centre[2] > 0.55 and abs(centre[0] - centre[1]) < 0.01 and abs(centre[0] / centre[2] - 0.5) < 0.02
+  assert (img2[20, 2] == img[20, 2]).all()       # far left column unchanged
+  # hazard disc on the floor ahead
+  rf3, ri3 = base_record('go_to_goal', ['robot', 'goal', 'hazards0'], {'robot': 0.4})
+  rf3[ol.F_GOAL:ol.F_GOAL + 2] = [-3.0, 0.0]
+  rf3[ol.F_HAZARDS:ol.F_HAZARDS + 2] = [0.5, 0.0]
+  img3 = oracle.render_rgb(oracle.env(rf3, ri3), 0)
+  row = 40
+  px = img3[row, 32].astype(int)
+  assert px[2] > px[0] + 20 and (img3[row, 2] == img[row, 2]).all()
+  # yaw rotates the view: a pillar at +y is centred after turning the robot by 90 degrees
+  rf4 = rf2.copy(); rf4[ol.F_PILLARS:ol.F_PILLARS + 2] = [0.0, 1.0]; rf4[ol.F_ROBOT + 2] = np.pi / 2
+  img4 = oracle.render_rgb(oracle.env(rf4, ri2), 0)
+  assert np.abs(img4[:19].astype(int) - img2[:19].astype(int)).max() <= 1   # above the horizon: sky + pillar (the floor pattern is world-fixed)
+  assert np.abs(img4[19:24, 31:33].astype(int) - img2[19:24, 31:33].astype(int)).max() <= 1      # the pillar's centre line
