@@ -50,7 +50,15 @@ struct sag_ctx {
   float* S = nullptr;
   int32_t* I = nullptr;
   float* G = nullptr;  // [3][NBODY][N] spill of body accelerations beyond the LDS pool
-  int32_t* d_rows = nullptr; int32_t* d_count = nullptr;  // compacted busy list (split launches)
+  // busy lists (split launches): [2][N] rows and two counters, used alternately by `phase`.  A step
+  // consumes list[phase] and its classification appends list[phase ^ 1]; k_compact rebuilds
+  // list[phase] from the busy bits whenever state was installed from outside (list_valid = false)
+  int32_t* d_rows = nullptr; int32_t* d_count = nullptr;
+  bool list_valid = false;
+  // SAG_INKERNEL_LIST=1: the step kernels append the next busy list themselves and k_compact only runs
+  // after installs.  Measured no faster (0.37 vs 0.35 ms at 1M envs): the 15 us saved are lost to the
+  // worse row locality of chunks in arrival order (k_compact emits rows sorted per 1024-env block).
+  bool inkernel_list = false;
   // last installed layout (sag_reset)
   float* L_f = nullptr;   // [N][SAG_REC_FLOATS] AoS, device
   int32_t* L_i = nullptr; // [N][SAG_REC_INTS]
@@ -70,6 +78,7 @@ struct sag_ctx {
   double ev_ms = 0; int64_t ev_n = 0;
   bool timing = false;
   int phase = 0;       // busy-bit copy read by the next step launch
+  int phase_used = 0;  // (the phase of the launch being built)
   int n_cu = 256;      // compute units of the device
   uint8_t* d_rgb = nullptr;  // [N][64][64][3], allocated by the first sag_render_rgb
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
@@ -218,7 +227,8 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   a.has_box = c->cfg.has_box; a.G = c->G;
-  a.phase = c->phase; a.rows = c->d_rows; a.count = c->d_count;
+  a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
+  a.rows_next = nullptr; a.count_next = nullptr;
   {
     // one Doggo wavefront per CU (its LDS working set): aim for one resident round over the chip
     int epw = 64;
@@ -226,6 +236,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     if (const char* e = getenv("SAG_DOGGO_EPW")) epw = atoi(e);
     a.envs_per_wave = epw < 1 ? 1 : (epw > 64 ? 64 : epw);
   }
+  c->phase_used = c->phase;
   if (!observe_only) c->phase ^= 1;
   const int blocks = (c->N + WAVE - 1) / WAVE;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -251,9 +262,15 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   const bool split = c->split && !observe_only && c->cfg.robot != SAG_ROBOT_DOGGO;
   hipStream_t quiet_stream = c->stream;
   if (split) {
-    HIPCHK(c, hipMemsetAsync(c->d_count, 0, sizeof(int32_t), c->stream));
-    hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
-                       c->d_rows, c->d_count);
+    a.rows_next = c->d_rows + (size_t)(c->phase_used ^ 1) * c->N; a.count_next = c->d_count + (c->phase_used ^ 1);
+    if (!c->inkernel_list) { a.rows_next = nullptr; a.count_next = nullptr; c->list_valid = false; }
+    else HIPCHK(c, hipMemsetAsync(a.count_next, 0, sizeof(int32_t), c->stream));
+    if (!c->list_valid) {
+      HIPCHK(c, hipMemsetAsync(a.count, 0, sizeof(int32_t), c->stream));
+      hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
+                         a.rows, a.count);
+    }
+    c->list_valid = true;
     if (c->overlap) {
       HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
       HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
@@ -355,6 +372,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("SAG_OVERLAP")) c->overlap = atoi(e) != 0;
+  if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -362,7 +380,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->S, N * DEV_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->I, N * DI_COUNT * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
-  CREATE_CHK(hipMalloc(&c->d_rows, N * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->d_rows, 2 * N * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->d_count, 4 * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->L_f, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->L_i, N * SAG_REC_INTS * sizeof(int32_t)));
@@ -438,6 +456,7 @@ int sag_set_layout(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* r
   if (rc) return rc;
   hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 1);
+  c->list_valid = false;  // busy bits changed outside a step
   // keep a copy for sag_reset: read the installed state back into the AoS layout store
   hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i);
@@ -466,6 +485,7 @@ int sag_set_state(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* re
   if (rc) return rc;
   hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 0);
+  c->list_valid = false;  // busy bits changed outside a step
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_layout = true;
@@ -498,6 +518,7 @@ int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
   if (!env_ids) {
     hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                        (const int32_t*)nullptr, n, c->L_f, c->L_i, 0);
+  c->list_valid = false;  // busy bits changed outside a step
   } else {
     for (int k = 0; k < n; k++)
       if (env_ids[k] < 0 || env_ids[k] >= c->N) return fail(c, SAG_ERR_ARG, "env id %d out of range", env_ids[k]);
@@ -511,6 +532,7 @@ int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
     HIPCHK(c, hipMemcpyAsync(c->st_ids, env_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                        c->st_ids, n, c->st_f, c->st_i, 0);
+  c->list_valid = false;  // busy bits changed outside a step
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -708,7 +730,7 @@ int sag_busy_count(sag_ctx* c, int32_t* count) {
   if (!c || !count) return SAG_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(count, c->d_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(count, c->d_count + (c->phase ^ 1), sizeof(int32_t), hipMemcpyDeviceToHost));  // the list the last step consumed
   return SAG_OK;
 }
 

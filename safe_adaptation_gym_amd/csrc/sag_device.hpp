@@ -117,6 +117,8 @@ struct StepArgs {
   int32_t phase;          // which copy of the busy bit this launch reads (0 / 1)
   int32_t* rows;          // [N] env ids of the busy envs, compacted (k_compact)
   int32_t* count;         // number of entries in rows
+  int32_t* rows_next;     // split form: the busy list of the NEXT step, appended to by the classification
+  int32_t* count_next;    //   (nullptr: not built; the host then runs k_compact)
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
 };
@@ -1475,6 +1477,17 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     const uint32_t nbit = TS_BUSY_BIT << (p.phase ^ 1);
     tstate = busy ? (tstate | nbit) : (tstate & ~nbit);
+    // next step's busy list, built here instead of by a separate compaction pass: one atomic per
+    // wavefront claims a contiguous chunk (a chunk keeps the env neighbourhood of its wavefront)
+    if (MODE != MODE_ALL && p.rows_next) {
+      const uint64_t bm = __ballot(busy && live);
+      if (bm) {
+        int chunk = 0;
+        if (lane == __ffsll((unsigned long long)bm) - 1) chunk = atomicAdd(p.count_next, __popcll(bm));
+        chunk = __shfl(chunk, __ffsll((unsigned long long)bm) - 1);
+        if (busy && live) p.rows_next[chunk + __popcll(bm & ((1ull << lane) - 1))] = i;
+      }
+    }
   }
 
   CYC(CY_WRITEBACK);
