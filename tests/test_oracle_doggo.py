@@ -253,3 +253,33 @@ def test_render_known_answers(oracle):
   img4 = oracle.render_rgb(oracle.env(rf4, ri2), 0)
   assert np.abs(img4[:19].astype(int) - img2[:19].astype(int)).max() <= 1   # above the horizon: sky + pillar (the floor pattern is world-fixed)
   assert np.abs(img4[19:24, 31:33].astype(int) - img2[19:24, 31:33].astype(int)).max() <= 1      # the pillar's centre line
+
+
+def test_doggo_lidar_uses_the_reference_pinned_routine(oracle):
+  """The Doggo observation computes its lidar from the base quaternion; it must equal the general
+  routine `sago_lidar(robot_pos, robot_mat, points)` that tests/golden/lidar.npz pins against the
+  reference's `_lidar` (tilted-base cases included), for arbitrary base orientations."""
+  rng = np.random.RandomState(4)
+  names = ['robot', 'goal'] + [f'hazards{k}' for k in range(4)] + [f'vases{k}' for k in range(3)] + ['pillars0']
+  for _ in range(20):
+    rf, ri = base_record('go_to_goal', names, {'robot': 0.4}, robot='doggo')
+    rf[EXT:EXT + 40] = 0
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    pos = np.r_[rng.uniform(-1, 1, 2), rng.uniform(0.1, 0.3)]
+    rf[ol.F_ROBOT:ol.F_ROBOT + 2] = pos[:2]; rf[EXT] = pos[2]; rf[EXT + 1:EXT + 5] = q
+    haz = rng.uniform(-2, 2, (4, 2)); vas = rng.uniform(-2, 2, (3, 2)); pil = rng.uniform(-2, 2, (1, 2))
+    goal = rng.uniform(-1.5, 1.5, 2)
+    rf[ol.F_HAZARDS:ol.F_HAZARDS + 8] = haz.ravel()
+    for k in range(3):
+      rf[ol.F_VASES + 6 * k:ol.F_VASES + 6 * k + 2] = vas[k]
+    rf[ol.F_PILLARS:ol.F_PILLARS + 2] = pil[0]
+    rf[ol.F_GOAL:ol.F_GOAL + 2] = goal
+    obs = np.array(oracle.observe(oracle.env(rf, ri), DOGGO).obs)
+    w, x, y, z = q
+    R = np.array([[w*w+x*x-y*y-z*z, 2*(x*y-w*z), 2*(x*z+w*y)], [2*(x*y+w*z), w*w-x*x+y*y-z*z, 2*(y*z-w*x)],
+                  [2*(x*z-w*y), 2*(y*z+w*x), w*w-x*x-y*y+z*z]])
+    obst, _ = oracle.lidar(pos, R, np.vstack([haz, vas, pil]))
+    gl, _ = oracle.lidar(pos, R, goal[None])
+    np.testing.assert_allclose(obs[:16], obst, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(obs[16:32], 0, atol=0)
+    np.testing.assert_allclose(obs[32:48], gl, rtol=0, atol=1e-14)
