@@ -569,3 +569,29 @@ def test_rgb_observation_env_api(nat):
   sky = obs[:, 0].reshape(-1, 3).astype(int)
   assert (sky[:, 2] > sky[:, 0]).all()        # top row: sky, blue dominates
   env.close()
+
+
+def test_doggo_long_run_is_stable(nat):
+  """300 steps (3600 substeps) of random torques on the config-4 task mix: every state stays
+  finite, no env reports a physics failure, the base stays between the floor and a jump height,
+  the joints stay near their ranges (soft limits), quaternions stay normalised."""
+  from safe_adaptation_gym_amd import benchmark
+  n = 256
+  names = [nm for nm, _ in benchmark.make('multitask', batch_size=n, seed=7).train_tasks]
+  rf, ri = bu.sample_records_native('doggo', names, n, seed=99)
+  ctx = nat.Context('doggo', n, seed=11)
+  ctx.set_layout(rf, ri)
+  rng = np.random.RandomState(0)
+  E = 144
+  for t in range(300):
+    obs, rew, cost, done, met, _ = ctx.step(rng.uniform(-1, 1, (n, 12)).astype(np.float32))
+    assert not done.any(), f'physics failure at step {t}'
+  rf, ri = ctx.get_state()
+  assert np.isfinite(rf).all() and np.isfinite(obs).all()
+  z = rf[:, E]
+  assert (z > 0.02).all() and (z < 0.6).all(), (z.min(), z.max())
+  np.testing.assert_allclose(np.linalg.norm(rf[:, E + 1:E + 5], axis=1), 1.0, atol=1e-5)
+  q = np.rad2deg(rf[:, E + 9:E + 22])
+  assert q.min() > -110 and q.max() < 170, (q.min(), q.max())
+  assert np.abs(rf[:, :2]).max() < 4.0     # nobody left the arena at speed
+  ctx.close()
