@@ -234,6 +234,10 @@ int sag_dev_fill_actions(sag_ctx* ctx, float* d_actions, uint32_t step_index);
  * stream: mean milliseconds per launch over the launches since the last call
  * with reset != 0.  Feeds bench.py's roofline.achieved. */
 int sag_kernel_time_ms(sag_ctx* ctx, int32_t reset, double* mean_ms, int64_t* launches);
+/* Diagnostic (tests): Doggo mass matrix [19x19], bias [19], contact-free qacc [19] and M^-1 [19x19]
+ * per env from the wave-cooperative routines; out[n_envs][760] doubles. */
+int sag_debug_doggo_coop(sag_ctx* ctx, double* out);
+
 /* rgb_observation (safe_adaptation_gym.py:122-126 `physics.render(height=64, width=64,
  * camera_id='vision')`): the first-person image of every env at its current state,
  * out[n_envs][64][64][3] uint8 (row 0 = top).  Host buffer / device buffer variants. */

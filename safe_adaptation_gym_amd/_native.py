@@ -31,7 +31,7 @@ EXPORTS = [
     'sag_robot_info', 'sag_create', 'sag_destroy', 'sag_last_error', 'sag_set_layout',
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
     'sag_observe', 'sag_lidar_cost', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
-    'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device',
+    'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device', 'sag_debug_doggo_coop',
     'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts'
 ]
 
@@ -94,6 +94,7 @@ def load():
   lib.sag_busy_count.argtypes = [vp, C.POINTER(C.c_int32)]
   lib.sag_render_rgb.argtypes = [vp, C.POINTER(C.c_uint8)]
   lib.sag_render_rgb_device.argtypes = [vp, vp]
+  lib.sag_debug_doggo_coop.argtypes = [vp, C.POINTER(C.c_double)]
   lib.sag_debug_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]
   lib.sag_world_config_default.argtypes = [C.POINTER(WorldConfig)]
   lib.sag_world_config_default.restype = None
@@ -319,6 +320,11 @@ class Context:
     img = np.zeros((self.n_envs, 64, 64, 3), np.uint8)
     self._check(self.lib.sag_render_rgb(self.h, img.ctypes.data_as(C.POINTER(C.c_uint8))), 'sag_render_rgb')
     return img
+
+  def debug_doggo_coop(self):
+    out = np.zeros((self.n_envs, 760), np.float64)
+    self._check(self.lib.sag_debug_doggo_coop(self.h, out.ctypes.data_as(C.POINTER(C.c_double))), 'sag_debug_doggo_coop')
+    return out[:, :361].reshape(-1, 19, 19), out[:, 361:380], out[:, 380:399], out[:, 399:].reshape(-1, 19, 19)
 
   def render_rgb_device(self, d_out):
     self._check(self.lib.sag_render_rgb_device(self.h, d_out), 'sag_render_rgb_device')

@@ -706,6 +706,23 @@ int sag_debug_cycles(sag_ctx* c, int32_t reset, uint64_t* out, int32_t n) {
 #endif
 }
 
+// diagnostic (tests): mass matrix, bias, contact-free qacc and M^-1 of every Doggo env from the
+// wave-cooperative routines; out[n_envs][2*361 + 38] doubles (host)
+int sag_debug_doggo_coop(sag_ctx* c, double* out) {
+  if (!c || !out) return SAG_ERR_ARG;
+  if (c->cfg.robot != SAG_ROBOT_DOGGO) return fail(c, SAG_ERR_ARG, "not a doggo context");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  const size_t bytes = (size_t)c->N * (2 * DG_NV * DG_NV + 2 * DG_NV) * sizeof(double);
+  double* d = nullptr;
+  HIPCHK(c, hipMalloc(&d, bytes));
+  hipLaunchKernelGGL(k_doggo_coop_debug, dim3((c->N + 1) / 2), dim3(64), 0, c->stream, c->S, c->N, d);
+  hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  HIPCHK(c, e);
+  return SAG_OK;
+}
+
 // rgb_observation: [n_envs][64][64][3] uint8 image of the robot camera at the current state
 int sag_render_rgb_device(sag_ctx* c, void* d_out) {
   if (!c || !d_out) return c ? fail(c, SAG_ERR_ARG, "null argument") : SAG_ERR_ARG;

@@ -1750,7 +1750,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     // gyro, magnetometer, 8 touch, 12 joint rates, 12 x (sin, cos)
     float dsens[DOGGO ? 56 : 1] = {};
     if constexpr (DOGGO) {
-      const double a3[3] = {bad ? 0.0 : dgr.qacc_lin[0], bad ? 0.0 : dgr.qacc_lin[1], (bad ? 0.0 : dgr.qacc_lin[2]) + (double)GRAV};
+      const double a3[3] = {bad ? 0.0 : dgr.qacc_lin[0], bad ? 0.0 : dgr.qacc_lin[1], (bad ? 0.0 : dgr.qacc_lin[2]) + DG_GRAV};
       const double m3[3] = {0, -0.5, 0};
       for (int k = 0; k < 3; k++) {
         dsens[k] = (float)(dg_rot[k] * a3[0] + dg_rot[3 + k] * a3[1] + dg_rot[6 + k] * a3[2]);
@@ -2085,3 +2085,4 @@ __global__ void k_fill_actions(float* actions, const int32_t* I, int N, int nu, 
 
 }  // namespace sag
 #include "sag_render.hpp"
+#include "sag_doggo_coop.hpp"

@@ -17,7 +17,7 @@ namespace sag {
 
 constexpr int DG_NB = 10, DG_NV = 19, DG_NJ = 13, DG_NS = 17, DG_MAXROWS = 3 * 12 + DG_NJ + 1;
 constexpr int DG_PGS_ITERS = 4;
-constexpr double DG_GEAR = 0.0125, DG_STIFF = 0.01, DG_Z0 = 0.22, DG_PI = 3.14159265358979323846;
+constexpr double DG_GEAR = 0.0125, DG_STIFF = 0.01, DG_Z0 = 0.22, DG_PI = 3.14159265358979323846, DG_GRAV = 9.81;
 
 // model tables, built on the host in fp64 (sag_api.hip: dg_build_model) from the XML numbers
 struct DgModel {
@@ -252,7 +252,7 @@ __device__ __attribute__((noinline)) void dg_bias(const DgState& D, const DgWork
   for (int k = 0; k < 3; k++)
     for (int c = 0; c < 3; c++) v[0].a[c] += K.S[3 + k].a[c] * D.wloc[k];
   dg_cross(D.vlin, v[0].a, a[0].l);
-  a[0].l[2] += (double)GRAV;
+  a[0].l[2] += DG_GRAV;
   int dof = 6;
 #pragma unroll 1
   for (int b = 1; b < DG_NB; b++) {

@@ -595,3 +595,30 @@ def test_doggo_long_run_is_stable(nat):
   assert q.min() > -110 and q.max() < 170, (q.min(), q.max())
   assert np.abs(rf[:, :2]).max() < 4.0     # nobody left the arena at speed
   ctx.close()
+
+
+def test_doggo_cooperative_linear_algebra(nat, oracle):
+  """The wave-cooperative Doggo routines (32 lanes per env: kinematics, composite inertias, mass
+  matrix, RNEA bias, Cholesky, smooth solve, explicit inverse) against the oracle's serial fp64
+  ones on tumbling mid-air states: same numbers up to summation order."""
+  n = 37   # odd: the last wavefront is half filled
+  rng = np.random.RandomState(12)
+  rf, ri = bu.sample_records_native('doggo', 'go_to_goal', n, seed=1)
+  E = 144
+  for k in range(n):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    rf[k, E] = rng.uniform(1, 2); rf[k, E + 1:E + 5] = q
+    rf[k, E + 5] = rng.normal(); rf[k, E + 6:E + 9] = rng.normal(size=3)
+    rf[k, 3:5] = rng.normal(size=2)
+    rf[k, E + 9:E + 22] = np.deg2rad(rng.uniform(-20, 20, 13)); rf[k, E + 22:E + 35] = rng.normal(size=13)
+  ctx = nat.Context('doggo', n, seed=3)
+  ctx.set_state(rf, ri)
+  M, bias, qacc, Minv = ctx.debug_doggo_coop()
+  rf, ri = ctx.get_state()
+  for k in range(n):
+    oM, obias, _, _, oqacc = oracle.doggo_debug(oracle.env(rf[k], ri[k]))
+    np.testing.assert_allclose(M[k], oM, rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(bias[k], obias, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(qacc[k], oqacc, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(Minv[k] @ oM, np.eye(19), atol=1e-7)
+  ctx.close()
