@@ -81,6 +81,8 @@ struct sag_ctx {
   int phase_used = 0;  // (the phase of the launch being built)
   int n_cu = 256;      // compute units of the device
   uint8_t* d_rgb = nullptr;  // [N][64][64][3], allocated by the first sag_render_rgb
+  double* d_dr = nullptr;    // Doggo cooperative form: per-env result block of the physics kernel
+  bool doggo_coop = false;   // SAG_DOGGO_COOP=1
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
@@ -228,7 +230,9 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   a.has_box = c->cfg.has_box; a.G = c->G;
   a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
-  a.rows_next = nullptr; a.count_next = nullptr;
+  a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr;
+  a.debug = 0;
+  if (const char* e = getenv("SAG_DC_DEBUG")) a.debug = atoi(e);
   {
     // one Doggo wavefront per CU (its LDS working set): aim for one resident round over the chip
     int epw = 64;
@@ -295,7 +299,13 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   } while (0)
   if (c->cfg.robot == SAG_ROBOT_POINT) SAG_LAUNCH(SAG_ROBOT_POINT);
   else if (c->cfg.robot == SAG_ROBOT_CAR) SAG_LAUNCH(SAG_ROBOT_CAR);
-  else {  // Doggo: one (buttons + task object) instance, single-launch form
+  else if (c->doggo_coop) {
+    // Doggo, wave-cooperative physics (32 lanes per env) + the generic step without physics
+    if (!c->d_dr) HIPCHK(c, hipMalloc(&c->d_dr, (size_t)c->N * DR_STRIDE * sizeof(double)));
+    a.DR = c->d_dr;
+    hipLaunchKernelGGL(k_doggo_physics, dim3((c->N + 1) / 2), dim3(WAVE), 0, c->stream, a, c->d_dr);
+    hipLaunchKernelGGL((k_step_doggo_post<true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
+  } else {  // Doggo, lane-per-env form: one (buttons + task object) instance, single launch
     hipLaunchKernelGGL((k_step<SAG_ROBOT_DOGGO, true, true>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave),
                        dim3(WAVE), 0, c->stream, a);
   }
@@ -373,6 +383,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("SAG_OVERLAP")) c->overlap = atoi(e) != 0;
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
+  if (const char* e = getenv("SAG_DOGGO_COOP")) c->doggo_coop = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -414,7 +425,7 @@ int sag_destroy(sag_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
-                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb};
+                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }

@@ -121,7 +121,11 @@ struct StepArgs {
   int32_t* count_next;    //   (nullptr: not built; the host then runs k_compact)
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
+  int32_t debug;          // SAG_DC_DEBUG bisect switches of k_doggo_physics (0 in normal use)
+  double* DR;             // Doggo, cooperative form: per-env result block of k_doggo_physics [N][DR_STRIDE]
+                          // (k_step<DOGGO> with DR set skips the physics and reads it); else nullptr
 };
+constexpr int DR_STRIDE = 20;  // qacc_lin 3, touch 8, comvel 4, cost_contacts, btn_mask, pad
 
 // ---- constants of the Point robot (assets/xmls/point.xml) -------------------
 constexpr float PT_M_SPHERE = 4.0f / 3.0f * 3.14159265358979323846f * 0.001f;
@@ -1111,12 +1115,19 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     for (int k = 0; k < 8; k++) dgr.touch[k] = 0;
     for (int k = 0; k < 4; k++) dgr.comvel[k] = 1;
     dgr.cost_contacts = 0; dgr.btn_mask = 0;
-    if (live)  // padding lanes of a partly filled wavefront stay out of the divergence union
+    const bool post = p.DR != nullptr;   // cooperative form: k_doggo_physics has run, its results are in DR and S
+    if (post) {
+      const double* dr = p.DR + (size_t)i * DR_STRIDE;
+      for (int k = 0; k < 3; k++) dgr.qacc_lin[k] = dr[k];
+      for (int k = 0; k < 8; k++) dgr.touch[k] = dr[3 + k];
+      for (int k = 0; k < 4; k++) dgr.comvel[k] = dr[11 + k];
+      dgr.cost_contacts = (int)dr[15]; dgr.btn_mask = (uint32_t)dr[16];
+    } else if (live)  // padding lanes of a partly filled wavefront stay out of the divergence union
       doggo_physics(dgs, Wd, dgr, (lds_f64*)dgL + lane, ctrl12, nsub, h, stx, sty, nP, nB, psz, vsz, vk, bk, sol0, solb, nV,
                     has_box, HAS_TBOX && task == SAG_TASK_HAUL_BOX);
     cost_contacts = dgr.cost_contacts; btn_mask = dgr.btn_mask;
     float wz;
-    if (!p.observe_only && live) dg_store(dgs, S, (size_t)N, (size_t)i, yaw, wz);
+    if (!p.observe_only && live && !post) dg_store(dgs, S, (size_t)N, (size_t)i, yaw, wz);
     else { double Rm[9], ww[3]; dg_quat2mat(dgs.quat, Rm); dg_matvec(Rm, dgs.wloc, ww); yaw = (float)atan2(Rm[3], Rm[0]); wz = (float)ww[2]; }
     {
       double Rm[9];
@@ -1131,7 +1142,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (isb ? !has_box : k >= nV) continue;
       LP(LS_X, k) = Wd.fb[k][0]; LP(LS_Y, k) = Wd.fb[k][1]; LP(LS_YAW, k) = Wd.fb[k][2];
       if (Wd.fb[k][3] != 0 || Wd.fb[k][4] != 0 || Wd.fb[k][5] != 0) awake |= 1u << k;
-      if (!p.observe_only && live) {
+      if (!p.observe_only && live && !post) {
         for (int c = 0; c < 3; c++) { SD(DV_POS + 3 * k + c) = Wd.fb[k][c]; SD(DV_VEL + 3 * k + c) = Wd.fb[k][3 + c]; }
       }
     }
@@ -1872,6 +1883,16 @@ __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_DOGGO ? 1 : SAG_STEP_MIN_W
   const bool live = gi < p.N && lane < epw;
   step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_ALL>(p, lds, lane, live ? gi : p.N - 1, live, base,
                                                  min(epw, p.N - base), 0ull, nullptr, dgL);
+}
+
+// Doggo, cooperative form: the generic step after k_doggo_physics (p.DR set): no physics, no factor in LDS
+template <bool HAS_BTN, bool HAS_TBOX>
+__global__ __launch_bounds__(WAVE, 1) void k_step_doggo_post(StepArgs p) {
+  __shared__ float lds[LDS_FLOATS];
+  const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
+  const bool live = gi < p.N;
+  step_body<SAG_ROBOT_DOGGO, HAS_BTN, HAS_TBOX, MODE_ALL>(p, lds, lane, live ? gi : p.N - 1, live, base, min(WAVE, p.N - base),
+                                                           0ull, nullptr, nullptr);
 }
 
 #ifndef SAG_QUIET_MIN_WAVES

@@ -20,7 +20,7 @@
 
 namespace sag {
 
-constexpr int DC_ROWS = 48;                     // max constraint rows per env
+constexpr int DC_ROWS = DG_MAXROWS;              // max constraint rows per env (same cap as the lane-per-env form)
 struct DcEnv {                                  // one env's working set in LDS
   double pos[3], quat[4], q[DG_NJ], vlin[3], wloc[3], qd[DG_NJ];
   double R[DG_NB][9], p[DG_NB][3];
@@ -33,7 +33,9 @@ struct DcEnv {                                  // one env's working set in LDS
   double bias[DG_NV], tau[DG_NV], qacc[DG_NV], qdv[DG_NV], col[DG_NV];
   double sph[DG_NS][3];
   double touch[8];
-  float rJ[DC_ROWS][DG_NV], rW[DC_ROWS][DG_NV];
+  float rJ[DC_ROWS][DG_NV];
+  double rW[DC_ROWS][DG_NV];
+  double Mlin[2][DG_NV];                        // rows 0, 1 of the mass matrix (momentum, Unsupervised)
   double rA[DC_ROWS], rAref[DC_ROWS], rImp[DC_ROWS], rF[DC_ROWS], rMu[DC_ROWS];
   float rOu[DC_ROWS][3], rOd[DC_ROWS][2], rOrx[DC_ROWS], rOry[DC_ROWS];
   short rParent[DC_ROWS], rOther[DC_ROWS], rTouch[DC_ROWS];
@@ -65,7 +67,7 @@ __device__ inline void dc_rot_apply(double* R, const double* axis, double ang) {
 }
 
 // phase 1: frames, motion vectors, inertias about O = base origin, sphere centres.  `u` = lane in the half.
-__device__ inline void dc_kinematics(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_kinematics(DcEnv& E, int u) {
   const DgModel& M = g_dg;
   double R0[9];
   dg_quat2mat(E.quat, R0);
@@ -125,7 +127,7 @@ __device__ inline void dc_kinematics(DcEnv& E, int u) {
   }
 }
 // sphere centres (needs E.R / E.p)
-__device__ inline void dc_spheres(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_spheres(DcEnv& E, int u) {
   if (u < DG_NS) {
     const int b = g_dg.sph_body[u];
     double o[3];
@@ -159,7 +161,7 @@ __device__ inline void dc_mcross(const double* v, const double* s, double* o) {
 }
 
 // phases 3-6 need barriers between them; the caller owns the barriers (one wavefront per workgroup)
-__device__ inline void dc_composite(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_composite(DcEnv& E, int u) {
   if (u < DG_NB) {
     double acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
@@ -169,10 +171,10 @@ __device__ inline void dc_composite(DcEnv& E, int u) {
     for (int k = 0; k < 10; k++) E.Ic[u][k] = acc[k];
   }
 }
-__device__ inline void dc_crba_f(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_crba_f(DcEnv& E, int u) {
   if (u < DG_NV) dc_inertia_apply(E.Ic[g_dg.dof_body[u]], E.S[u], E.F[u]);
 }
-__device__ inline void dc_crba_rows(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_crba_rows(DcEnv& E, int u) {
   if (u < DG_NV) {
     const int bi = g_dg.dof_body[u];
     for (int j = 0; j < DG_NV; j++) {
@@ -185,7 +187,7 @@ __device__ inline void dc_crba_rows(DcEnv& E, int u) {
   }
 }
 // body velocities / accelerations (qacc = 0) and the body wrenches
-__device__ inline void dc_rnea_bodies(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_rnea_bodies(DcEnv& E, int u) {
   if (u < DG_NB) {
     double v[6], a[6];
     for (int k = 0; k < 3; k++) { v[k] = 0; v[3 + k] = E.vlin[k]; a[k] = 0; }
@@ -213,7 +215,7 @@ __device__ inline void dc_rnea_bodies(DcEnv& E, int u) {
     for (int k = 0; k < 6; k++) E.fb[u][k] = f[k];
   }
 }
-__device__ inline void dc_rnea_bias(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_rnea_bias(DcEnv& E, int u) {
   if (u < DG_NV) {
     const int b = g_dg.dof_body[u];
     double F[6] = {0, 0, 0, 0, 0, 0};
@@ -225,7 +227,7 @@ __device__ inline void dc_rnea_bias(DcEnv& E, int u) {
 }
 
 // Cholesky of E.M in place (lower), right-looking; lane i updates row i.  Barriers inside.
-__device__ inline void dc_cholesky(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_cholesky(DcEnv& E, int u) {
 #pragma unroll 1
   for (int j = 0; j < DG_NV; j++) {
     if (u == j) {
@@ -244,7 +246,7 @@ __device__ inline void dc_cholesky(DcEnv& E, int u) {
   }
 }
 // x <- (L L^T)^-1 b, component i of b / x in lane i's register `x`; E.col is the broadcast slot
-__device__ inline double dc_solve1(DcEnv& E, int u, double x) {
+__device__ __attribute__((noinline)) double dc_solve1(DcEnv& E, int u, double x) {
 #pragma unroll 1
   for (int j = 0; j < DG_NV; j++) {   // forward: L y = b
     if (u == j) { x = x / E.M[j][j]; E.col[0] = x; }
@@ -262,7 +264,7 @@ __device__ inline double dc_solve1(DcEnv& E, int u, double x) {
   return x;
 }
 // M^-1: 19 right-hand sides (identity), lane i holds component i of each; result row i -> E.Minv[i][:]
-__device__ inline void dc_inverse(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_inverse(DcEnv& E, int u) {
   double x[DG_NV];
 #pragma unroll
   for (int r = 0; r < DG_NV; r++) x[r] = (u == r) ? 1.0 : 0.0;
@@ -368,6 +370,529 @@ __global__ __launch_bounds__(64) void k_doggo_coop_debug(const float* __restrict
   if (live && u < DG_NV) {
     o[DG_NV * DG_NV + DG_NV + u] = x;
     for (int j = 0; j < DG_NV; j++) o[DG_NV * DG_NV + 2 * DG_NV + u * DG_NV + j] = E.Minv[u][j];
+  }
+}
+
+}  // namespace sag
+
+// =====================================================================================
+// constraint rows, PGS, planar world, integration: the full cooperative physics kernel
+// =====================================================================================
+namespace sag {
+
+// exclusive prefix sum over the 32 lanes of a half (u = lane in the half)
+__device__ inline int dc_scan32(int c, int u, int& total) {
+  int x = c;
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) {
+    const int t = __shfl_up(x, d, 32);
+    if (u >= d) x += t;
+  }
+  total = __shfl(x, 31, 32);
+  return x - c;
+}
+// sum over the 32 lanes of a half, result in every lane
+__device__ inline double dc_sum32(double v) {
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 32);
+  return v;
+}
+
+// Row r from a Jacobian in registers (owner lane): stores J (fp32), W = M^-1 J^T, A (+ other body),
+// velocity along the row; returns that velocity
+__device__ __attribute__((noinline)) double dc_build_row(DcEnv& E, int r, const double* J, int other, double dx, double dy, double px, double py) {
+  float Jf[DG_NV];
+  double vel = 0;
+#pragma unroll 1
+  for (int i = 0; i < DG_NV; i++) { Jf[i] = (float)J[i]; E.rJ[r][i] = Jf[i]; vel += (double)Jf[i] * E.qdv[i]; }
+  double A = 0;
+#pragma unroll 1
+  for (int i = 0; i < DG_NV; i++) {
+    double w = 0;
+    for (int k = 0; k < DG_NV; k++)
+      if (Jf[k] != 0.f) w += E.Minv[i][k] * (double)Jf[k];
+    E.rW[r][i] = w;
+    A += (double)Jf[i] * w;
+  }
+  E.rOther[r] = (short)other; E.rParent[r] = -1; E.rTouch[r] = -1; E.rF[r] = 0; E.rMu[r] = 0;
+  float ou0 = 0, ou1 = 0, ou2 = 0, od0 = 0, od1 = 0, orx = 0, ory = 0;
+  if (other >= 0) {
+    const float* m = E.wminv[other];
+    const float* B = E.wfb[other];
+    orx = (float)(px - (double)B[0]); ory = (float)(py - (double)B[1]);
+    od0 = (float)dx; od1 = (float)dy;
+    const float rxd = orx * od1 - ory * od0;
+    ou0 = m[0] * od0 + m[1] * od1 + m[2] * rxd;
+    ou1 = m[1] * od0 + m[3] * od1 + m[4] * rxd;
+    ou2 = m[2] * od0 + m[4] * od1 + m[5] * rxd;
+    A += (double)(od0 * ou0 + od1 * ou1 + rxd * ou2);
+    vel += (double)((B[3] - B[5] * ory) * od0 + (B[4] + B[5] * orx) * od1);
+  }
+  E.rOu[r][0] = ou0; E.rOu[r][1] = ou1; E.rOu[r][2] = ou2; E.rOd[r][0] = od0; E.rOd[r][1] = od1;
+  E.rOrx[r] = orx; E.rOry[r] = ory;
+  E.rA[r] = A;
+  return vel;
+}
+
+// Jacobian of point c on body b along d (registers)
+__device__ inline void dc_jac(const DcEnv& E, int b, const double* c, const double* d, double* J) {
+  const double r[3] = {c[0] - E.pos[0], c[1] - E.pos[1], c[2] - E.pos[2]};
+#pragma unroll 1
+  for (int i = 0; i < DG_NV; i++) {
+    double v = 0;
+    if (g_dg.anc[b] >> g_dg.dof_body[i] & 1u) {
+      double t[3];
+      dg_cross(E.S[i], r, t);
+      v = d[0] * (E.S[i][3] + t[0]) + d[1] * (E.S[i][4] + t[1]) + d[2] * (E.S[i][5] + t[2]);
+    }
+    J[i] = v;
+  }
+}
+
+// the three rows of one contact, built by its owner lane at rows [base, base + 3)
+__device__ __attribute__((noinline)) void dc_contact_rows(DcEnv& E, int base, int s, const double* n, const double* c, double depth, int other,
+                                       double bcoef, double kcoef, double mu) {
+  const int b = g_dg.sph_body[s];
+  double dir[3][3];
+  for (int k = 0; k < 3; k++) dir[0][k] = n[k];
+  if (fabs(n[2]) > 0.5) { dir[1][0] = 1; dir[1][1] = 0; dir[1][2] = 0; }
+  else { dir[1][0] = -n[1]; dir[1][1] = n[0]; dir[1][2] = 0; }
+  dg_cross(dir[0], dir[1], dir[2]);
+  const double imp = dg_impedance(depth);
+#pragma unroll 1
+  for (int k = 0; k < 3; k++) {
+    double J[DG_NV];
+    dc_jac(E, b, c, dir[k], J);
+    const double vel = dc_build_row(E, base + k, J, other, -dir[k][0], -dir[k][1], c[0], c[1]);
+    E.rImp[base + k] = imp;
+    if (k == 0) { E.rAref[base] = -bcoef * vel + kcoef * depth; E.rTouch[base] = (short)g_dg.sph_touch[s]; }
+    else { E.rAref[base + k] = -bcoef * vel; E.rParent[base + k] = (short)base; E.rMu[base + k] = mu; }
+  }
+}
+
+// spheres of the robot (one per lane) vs one planar body: appends the contact rows in (sphere, geom)
+// order; returns the number of contacts (uniform in the half)
+__device__ __attribute__((noinline)) int dc_collide_body(DcEnv& E, int u, int& nrows, int fbi, int shape, float bx, float by, float byaw,
+                                      float rbound, float vsz, float rstatic, double top, double bcoef, double kcoef, double mu) {
+  DgHit hits[5];
+  int cnt = 0;
+  double cz = 0;
+  if (u < DG_NS) {
+    const double* c = E.sph[u];
+    double r = g_dg.sph_r[u];
+    cz = c[2];
+    bool go = c[2] - r < top;
+    if (go && c[2] > top) r = sqrt(r * r - (c[2] - top) * (c[2] - top));
+    const double dx = (double)bx - c[0], dy = (double)by - c[1], rs = r + (double)rbound;
+    go = go && dx * dx + dy * dy <= rs * rs;
+    if (go) {
+      float cb = 1, sb = 0;
+      if (fbi >= 0) sincosf(byaw, &sb, &cb);
+      const int ng = shape_ngeom(shape);
+      for (int g = 0; g < ng && cnt < 5; g++) {
+        const Geom ge = shape_geom(shape, g, vsz, rstatic);
+        const float gx = bx + cb * ge.ox - sb * ge.oy, gy = by + sb * ge.ox + cb * ge.oy;
+        DgHit h;
+        if (dg_circle_geom((float)c[0], (float)c[1], (float)r, ge, gx, gy, cb, sb, h)) hits[cnt++] = h;
+      }
+    }
+  }
+  int total;
+  const int excl = dc_scan32(cnt, u, total);
+  if (total == 0) return 0;
+  const int fit = min(total, (DC_ROWS - nrows) / 3);
+  for (int k = 0; k < cnt; k++) {
+    const int idx = excl + k;
+    if (idx < fit) {
+      const double nn[3] = {-(double)hits[k].nx, -(double)hits[k].ny, 0}, pc[3] = {(double)hits[k].px, (double)hits[k].py, cz};
+      dc_contact_rows(E, nrows + 3 * idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu);
+    }
+  }
+  nrows += 3 * fit;
+  return total;
+}
+
+// inputs of the planar world shared by the lanes of a half
+struct DcWorldK {
+  int nV, nP, nB, task;
+  bool has_box, haul;
+  float vsz, psz;
+  BodyK vk, bk;
+  Sol sol0, solb;
+};
+
+__global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __restrict__ DR) {
+  __shared__ DcEnv env[2];
+  __shared__ float ctrl_s[2][12];
+  __shared__ float stx_s[2][SAG_MAX_PILLARS + SAG_MAX_BUTTONS], sty_s[2][SAG_MAX_PILLARS + SAG_MAX_BUTTONS];
+  const int lane = threadIdx.x, half = lane >> 5, u = lane & 31;
+  const size_t N = (size_t)p.N;
+  const size_t gi = (size_t)blockIdx.x * 2 + half;
+  const bool live = gi < N;
+  const size_t i = live ? gi : N - 1;
+  DcEnv& E = env[half];
+  float* __restrict__ S = p.S;
+  const float* stx = stx_s[half];
+  const float* sty = sty_s[half];
+
+  // ---- per-env constants (every lane reads the same words: broadcast loads) ----------------
+  const uint32_t meta = (uint32_t)p.I[iaddr(DI_META, N, i)];
+  DcWorldK W;
+  W.task = meta & 15; W.nV = meta >> 8 & 15; W.nP = meta >> 12 & 3; W.nB = meta >> 14 & 7;
+  const int box_kind = meta >> 17 & 3;
+  W.has_box = box_kind != SAG_BOX_NONE;
+  W.haul = W.task == SAG_TASK_HAUL_BOX;
+  W.vsz = S[saddr(SAG_F_VASE_SIZE, N, i)]; W.psz = S[saddr(SAG_F_PILLAR_SIZE, N, i)];
+  const float h = p.h;
+  {
+    const float tc = fmaxf(0.02f, 2.0f * h);
+    W.sol0.bcoef = 2.0f / (SOL_D1 * tc); W.sol0.kcoef = 1.0f / (SOL_D1 * SOL_D1 * tc * tc); W.sol0.mu = MU;
+    W.solb = W.sol0;
+    if (box_kind == SAG_BOX_ROD || box_kind == SAG_BOX_BALL) W.solb.mu = 1.2f;
+    if (box_kind == SAG_BOX_BALL) {
+      const float tcb = fmaxf(0.018f, 2.0f * h);
+      W.solb.bcoef = 2.0f / (SOL_D1 * tcb); W.solb.kcoef = 1.0f / (SOL_D1 * SOL_D1 * tcb * tcb * 0.2f * 0.2f);
+    }
+    const float vsz = W.vsz;
+    W.vk.sh = SH_VASE; W.vk.m = VASE_DENSITY * 8 * vsz * vsz * vsz; W.vk.I = W.vk.m * (8 * vsz * vsz) / 12;
+    W.vk.reff = vsz * 1.41421356237309504880f;
+    W.bk.sh = SH_BOX; W.bk.m = 1; W.bk.I = 1; W.bk.reff = 0.2f * 1.41421356237309504880f;
+    if (box_kind == SAG_BOX_BOX) {
+      const float m0 = 0.001f * 0.064f, m1 = 0.001f * 0.016f;
+      W.bk.m = m0 + 4 * m1; W.bk.I = m0 * 0.32f / 12 + 4 * (m1 * 0.08f / 12 + m1 * 0.08f);
+    } else if (box_kind == SAG_BOX_ROD) {
+      W.bk.sh = SH_ROD; W.bk.m = 0.0005f * (3.14159265358979323846f * 0.08f * 0.08f * 0.6f);
+      W.bk.I = W.bk.m * (3 * 0.08f * 0.08f + 0.36f) / 12;
+    } else if (box_kind == SAG_BOX_BALL) {
+      W.bk.sh = SH_BALL; W.bk.m = 0.0005f * (4.0f / 3.0f * 3.14159265358979323846f * 0.14f * 0.14f * 0.14f);
+      W.bk.I = 0.4f * W.bk.m * 0.14f * 0.14f;
+    }
+  }
+  const float vase_r = W.vk.reff, box_r = shape_bound(W.bk.sh, W.vsz, 0);
+  const double top_vase = 2.0 * (double)W.vsz;
+  const double top_box = W.bk.sh == SH_ROD ? 0.16 : (W.bk.sh == SH_BALL ? 0.28 : 0.4);
+
+  // ---- load: robot state (lane 0), planar bodies (lane k), statics, controls ----------------
+  dc_load_state(E, u, S, N, i);
+  if (u < NBODY) {
+    const int k = u;
+    const bool isb = k == BOX_ID, on = isb ? W.has_box : k < W.nV;
+    for (int c = 0; c < 3; c++) {
+      E.wfb[k][c] = on ? S[((size_t)((DV_POS + 3 * k + c) >> 2) * N + i) * 4 + ((DV_POS + 3 * k + c) & 3)] : 0.f;
+      E.wfb[k][3 + c] = on ? S[((size_t)((DV_VEL + 3 * k + c) >> 2) * N + i) * 4 + ((DV_VEL + 3 * k + c) & 3)] : 0.f;
+      E.wfb[k][6 + c] = 0.f;
+    }
+    for (int c = 0; c < 6; c++) E.wminv[k][c] = 0;
+    if (!isb) { E.wminv[k][0] = E.wminv[k][3] = 1.0f / W.vk.m; E.wminv[k][5] = 1.0f / W.vk.I; }
+    else {
+      E.wminv[k][5] = 1.0f / W.bk.I;
+      E.wminv[k][0] = E.wminv[k][3] = W.bk.sh == SH_BALL ? 1.0f / (1.4f * W.bk.m) : 1.0f / W.bk.m;
+    }
+  }
+  if (u < SAG_MAX_PILLARS + SAG_MAX_BUTTONS) {
+    const int f = u < SAG_MAX_PILLARS ? SAG_F_PILLARS + 2 * u : SAG_F_BUTTONS + 2 * (u - SAG_MAX_PILLARS);
+    stx_s[half][u] = S[saddr(f, N, i)]; sty_s[half][u] = S[saddr(f + 1, N, i)];
+  }
+  if (u < 12) {
+    float c = 0;
+    if (!p.observe_only) {
+      float z;
+      if (p.noise) z = p.noise[i * 12 + u];
+      else {
+        const uint32_t env_id = (uint32_t)p.I[iaddr(DI_ENVID, N, i)], step = (uint32_t)p.I[iaddr(DI_STEP, N, i)];
+        uint32_t cc[4] = {env_id, step, (uint32_t)(u >> 1), 1u};
+        philox4x32_10(cc, p.key0, p.key1);
+        const float u1 = ((float)(cc[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(cc[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1)), a = 6.28318530717958647692f * u2;
+        z = (u & 1) ? r * sinf(a) : r * cosf(a);
+      }
+      const float an = S[saddr(SAG_F_ACTION_NOISE, N, i)], lim = S[saddr(SAG_F_CTRL_SCALE + u, N, i)];
+      c = clampf(p.actions[i * 12 + u] + an * z, -lim, lim);
+    }
+    ctrl_s[half][u] = c;
+  }
+  __syncthreads();
+
+  const int nsub = p.observe_only ? 0 : ((p.debug & 32) ? 1 : p.nstep);
+  int cost_contacts = 0;
+  uint32_t btn_mask = 0;
+  double qacc_u = 0;
+#pragma unroll 1
+  for (int sub = 0; sub <= nsub; sub++) {
+    if (u < NBODY) { E.wfb[u][6] = 0; E.wfb[u][7] = 0; E.wfb[u][8] = 0; }
+    if (u == BOX_ID && W.has_box && W.bk.sh == SH_ROD) {
+      float c, s; sincosf(E.wfb[BOX_ID][2], &s, &c);
+      const float ix = 1.0f / (1.5f * W.bk.m), iy = 1.0f / W.bk.m;
+      E.wminv[BOX_ID][0] = c * c * ix + s * s * iy; E.wminv[BOX_ID][1] = c * s * (ix - iy);
+      E.wminv[BOX_ID][3] = s * s * ix + c * c * iy;
+    }
+    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d top: pos0 %g\n", sub, E.pos[0]);
+    dc_smooth(E, u, ctrl_s[half]);
+    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after smooth: pos0 %g\n", sub, E.pos[0]);
+    if (u < 2)
+      for (int j = 0; j < DG_NV; j++) E.Mlin[u][j] = j >= u ? E.M[u][j] : 0.0;
+    __syncthreads();
+    dc_cholesky(E, u);
+    qacc_u = dc_solve1(E, u, u < DG_NV ? E.tau[u] : 0.0);
+    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after solve: pos0 %g\n", sub, E.pos[0]);
+    dc_inverse(E, u);
+    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after inverse: pos0 %g\n", sub, E.pos[0]);
+    if (u < 8) E.touch[u] = 0;
+    int nrows = 0;
+    // ---- rows: joint limits (lane j), in ascending joint order ---------------------------------
+    {
+      double depth = 0, sign = 0;
+      if (u < DG_NJ) {
+        if (E.q[u] < g_dg.lo[u]) { depth = g_dg.lo[u] - E.q[u]; sign = 1; }
+        else if (E.q[u] > g_dg.hi[u]) { depth = E.q[u] - g_dg.hi[u]; sign = -1; }
+      }
+      int total;
+      const int excl = dc_scan32(sign != 0 ? 1 : 0, u, total);
+      const int fit = min(total, DC_ROWS - nrows);
+      if (sign != 0 && excl < fit) {
+        double J[DG_NV];
+        for (int k = 0; k < DG_NV; k++) J[k] = 0;
+        J[6 + u] = sign;
+        const int r = nrows + excl;
+        const double vel = dc_build_row(E, r, J, -1, 0, 0, 0, 0);
+        E.rImp[r] = dg_impedance(depth);
+        E.rAref[r] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * depth;
+      }
+      nrows += fit;
+    }
+    // ---- floor (lane s) --------------------------------------------------------------------
+    {
+      double depth = 0;
+      if (u < DG_NS) depth = g_dg.sph_r[u] - E.sph[u][2];
+      int total;
+      const int excl = dc_scan32(depth > 0 ? 1 : 0, u, total);
+      const int fit = min(total, (DC_ROWS - nrows) / 3);
+      if (depth > 0 && excl < fit) {
+        const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dg.sph_r[u])};
+        dc_contact_rows(E, nrows + 3 * excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
+      }
+      nrows += 3 * fit;
+    }
+    // ---- world objects, in the specification's order -------------------------------------------
+    int cc = 0;
+    uint32_t mask = 0;
+    auto near = [&](float bx, float by, float rb) {
+      const double dx = (double)bx - E.pos[0], dy = (double)by - E.pos[1], rs = 0.6 + (double)rb;
+      return dx * dx + dy * dy <= rs * rs;
+    };
+#pragma unroll 1
+    for (int q = 0; q < W.nP; q++)
+      if (near(stx[q], sty[q], W.psz))
+        cc += dc_collide_body(E, u, nrows, -1, SH_STATIC, stx[q], sty[q], 0.f, W.psz, W.vsz, W.psz, 1.0,
+                              (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
+#pragma unroll 1
+    for (int b = 0; b < W.nB; b++)
+      if (near(stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], BUTTON_R) &&
+          dc_collide_body(E, u, nrows, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f, BUTTON_R, W.vsz,
+                          BUTTON_R, 0.2, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu))
+        mask |= 1u << b;
+#pragma unroll 1
+    for (int k = 0; k < W.nV; k++)
+      if (near(E.wfb[k][0], E.wfb[k][1], vase_r))
+        cc += dc_collide_body(E, u, nrows, k, SH_VASE, E.wfb[k][0], E.wfb[k][1], E.wfb[k][2], vase_r, W.vsz, 0.f, top_vase,
+                              (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
+    if (W.has_box) {
+      if (near(E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], box_r))
+        dc_collide_body(E, u, nrows, BOX_ID, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], E.wfb[BOX_ID][2], box_r, W.vsz, 0.f,
+                        top_box, (double)W.solb.bcoef, (double)W.solb.kcoef, (double)W.solb.mu);
+      if (W.haul && nrows < DC_ROWS) {   // haul_box.py:21-29: tendon base site <-> box site (z .2), range [0, .75]
+        const double dx = (double)E.wfb[BOX_ID][0] - E.pos[0], dy = (double)E.wfb[BOX_ID][1] - E.pos[1], dz = 0.2 - E.pos[2];
+        const double d2 = dx * dx + dy * dy, Lt = sqrt(d2 + dz * dz), viol = Lt - 0.75;
+        if (viol > 0 && d2 >= 1e-18) {
+          if (u == 0) {
+            const double j[3] = {dx / Lt, dy / Lt, dz / Lt};
+            double J[DG_NV];
+            dc_jac(E, 0, E.pos, j, J);
+            const double vel = dc_build_row(E, nrows, J, BOX_ID, -j[0], -j[1], (double)E.wfb[BOX_ID][0], (double)E.wfb[BOX_ID][1]);
+            E.rImp[nrows] = dg_impedance(viol);
+            E.rAref[nrows] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * viol;
+          }
+          nrows += 1;
+        }
+      }
+    }
+    __syncthreads();
+    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after rows: pos0 %g nrows %d\n", sub, E.pos[0], nrows);
+    // ---- projected Gauss-Seidel: rows in sequence, the dot product J.qacc across the lanes ---
+    int nmax = max(nrows, __shfl(nrows, (lane + 32) & 63));   // both halves walk the longer list
+    if (p.debug & 1) nmax = 0;
+#pragma unroll 1
+    for (int it = 0; it < DG_PGS_ITERS; it++)
+#pragma unroll 1
+      for (int r = 0; r < nmax; r++) {
+        const bool on = r < nrows;
+        const int rr = on ? r : 0;
+        double part = (on && u < DG_NV) ? (double)E.rJ[rr][u] * qacc_u : 0.0;
+        double acc = dc_sum32(part);
+        const int other = on ? (int)E.rOther[rr] : -1;
+        if (other >= 0) {
+          const float* B = E.wfb[other];
+          acc += (double)((B[6] - B[8] * E.rOry[rr]) * E.rOd[rr][0] + (B[7] + B[8] * E.rOrx[rr]) * E.rOd[rr][1]);
+        }
+        const double A = E.rA[rr], imp = E.rImp[rr], f = E.rF[rr];
+        double df = 0;
+        if (on && A > 0) {
+          const double reg = A * (1 - imp) / imp;
+          double fnew = f + (E.rAref[rr] - acc - reg * f) / (A + reg);
+          double lo = 0, hi = 1e30;
+          const int par = E.rParent[rr];
+          if (par >= 0) { const double fn = E.rF[par]; lo = -E.rMu[rr] * fn; hi = E.rMu[rr] * fn; }
+          if (fnew < lo) fnew = lo;
+          if (fnew > hi) fnew = hi;
+          df = fnew - f;
+        }
+        __syncthreads();   // every lane has read f / the body accelerations of this row
+        if (df != 0) {
+          if (u < DG_NV) qacc_u += E.rW[rr][u] * df;
+          if (u == 0) {
+            E.rF[rr] = f + df;
+            if (other >= 0) {
+              float* B = E.wfb[other];
+              B[6] += (float)((double)E.rOu[rr][0] * df); B[7] += (float)((double)E.rOu[rr][1] * df); B[8] += (float)((double)E.rOu[rr][2] * df);
+            }
+          }
+        }
+        __syncthreads();
+      }
+    if (u < DG_NV) E.qacc[u] = qacc_u;
+    if (u < 8) {
+      double t = 0;
+      for (int r = 0; r < nrows; r++)
+        if (E.rTouch[r] == u && E.rParent[r] < 0) t += E.rF[r];
+      E.touch[u] = t;
+    }
+    cost_contacts = cc; btn_mask = mask;
+    __syncthreads();
+    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after pgs: pos0 %g\n", sub, E.pos[0]);
+    if (sub == nsub) break;
+    // ---- planar world: body k on lane k vs the statics; pairs on lane 0; friction + integration --
+    if (u < NBODY && !(p.debug & 2)) {
+      const int k = u;
+      const bool isb = k == BOX_ID;
+      if (isb ? W.has_box : k < W.nV) {
+        const float br = isb ? box_r : vase_r;
+        for (int q = 0; q < SAG_MAX_PILLARS + W.nB; q++) {
+          if (q == W.nP && q < SAG_MAX_PILLARS) q = SAG_MAX_PILLARS;
+          if (q >= SAG_MAX_PILLARS + W.nB) break;
+          const bool is_p = q < SAG_MAX_PILLARS;
+          const float sr = is_p ? W.psz : BUTTON_R;
+          const float dx = stx[q] - E.wfb[k][0], dyy = sty[q] - E.wfb[k][1], rs = br + sr;
+          if (dx * dx + dyy * dyy > rs * rs) continue;
+          BV V; float cv, sv;
+          {
+            const float* B = E.wfb[k]; const float* m = E.wminv[k];
+            V.x = B[0]; V.y = B[1]; V.vx = B[3]; V.vy = B[4]; V.w = B[5]; V.ax = B[6]; V.ay = B[7]; V.aw = B[8];
+            sincosf(B[2], &sv, &cv);
+            V.m0 = m[0]; V.m1 = m[1]; V.m2 = m[2]; V.m3 = m[3]; V.m4 = m[4]; V.m5 = m[5]; V.dyn = 1;
+          }
+          BV St; St.x = stx[q]; St.y = sty[q]; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
+          St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
+          collide_shapes(V, isb ? W.bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, W.vsz, sr, isb ? W.solb : W.sol0);
+          E.wfb[k][6] = V.ax; E.wfb[k][7] = V.ay; E.wfb[k][8] = V.aw;
+        }
+      }
+    }
+    __syncthreads();
+    if (u == 0 && !(p.debug & 4)) {
+      for (int a = 0; a < W.nV; a++)
+        for (int b = a + 1; b < NBODY; b++) {
+          const bool isb = b == BOX_ID;
+          if (isb ? !W.has_box : b >= W.nV) continue;
+          const float dx = E.wfb[b][0] - E.wfb[a][0], dyy = E.wfb[b][1] - E.wfb[a][1], rs = vase_r + (isb ? box_r : vase_r);
+          if (dx * dx + dyy * dyy > rs * rs) continue;
+          BV A, B; float ca, sa, cb, sb;
+          {
+            const float* P = E.wfb[a]; const float* m = E.wminv[a];
+            A.x = P[0]; A.y = P[1]; A.vx = P[3]; A.vy = P[4]; A.w = P[5]; A.ax = P[6]; A.ay = P[7]; A.aw = P[8];
+            sincosf(P[2], &sa, &ca);
+            A.m0 = m[0]; A.m1 = m[1]; A.m2 = m[2]; A.m3 = m[3]; A.m4 = m[4]; A.m5 = m[5]; A.dyn = 1;
+          }
+          {
+            const float* P = E.wfb[b]; const float* m = E.wminv[b];
+            B.x = P[0]; B.y = P[1]; B.vx = P[3]; B.vy = P[4]; B.w = P[5]; B.ax = P[6]; B.ay = P[7]; B.aw = P[8];
+            sincosf(P[2], &sb, &cb);
+            B.m0 = m[0]; B.m1 = m[1]; B.m2 = m[2]; B.m3 = m[3]; B.m4 = m[4]; B.m5 = m[5]; B.dyn = 1;
+          }
+          if (collide_shapes(A, SH_VASE, ca, sa, B, isb ? W.bk.sh : SH_VASE, cb, sb, W.vsz, 0.f, isb ? W.solb : W.sol0)) {
+            E.wfb[a][6] = A.ax; E.wfb[a][7] = A.ay; E.wfb[a][8] = A.aw;
+            E.wfb[b][6] = B.ax; E.wfb[b][7] = B.ay; E.wfb[b][8] = B.aw;
+          }
+        }
+    }
+    __syncthreads();
+    if (u < NBODY && !(p.debug & 8)) {
+      const bool isb = u == BOX_ID;
+      if (isb ? W.has_box : u < W.nV) {
+        float B[9];
+        for (int c = 0; c < 9; c++) B[c] = E.wfb[u][c];
+        dg_free_body_finish(B, isb, W.vk, W.bk, W.sol0.bcoef, h);
+        for (int c = 0; c < 6; c++) E.wfb[u][c] = B[c];
+      }
+    }
+    // ---- robot: semi-implicit Euler --------------------------------------------------------
+    if (u < DG_NV && !(p.debug & 16)) {
+      const double v = E.qdv[u] + (double)h * qacc_u;
+      if (u < 3) { E.vlin[u] = v; E.pos[u] += (double)h * v; }
+      else if (u < 6) E.wloc[u - 3] = v;
+      else { E.qd[u - 6] = v; E.q[u - 6] += (double)h * v; }
+    }
+    __syncthreads();
+    if (u == 0) {
+      const double wn = sqrt(dg_dot(E.wloc, E.wloc));
+      if (wn > 0) {
+        const double ang = 0.5 * (double)h * wn, s = sin(ang) / wn, c = cos(ang);
+        const double dq[4] = {c, s * E.wloc[0], s * E.wloc[1], s * E.wloc[2]};
+        const double q0 = E.quat[0], q1 = E.quat[1], q2 = E.quat[2], q3 = E.quat[3];
+        const double o[4] = {q0 * dq[0] - q1 * dq[1] - q2 * dq[2] - q3 * dq[3], q0 * dq[1] + q1 * dq[0] + q2 * dq[3] - q3 * dq[2],
+                             q0 * dq[2] - q1 * dq[3] + q2 * dq[0] + q3 * dq[1], q0 * dq[3] + q1 * dq[2] - q2 * dq[1] + q3 * dq[0]};
+        const double nn = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+        for (int k = 0; k < 4; k++) E.quat[k] = o[k] / nn;
+      }
+      if (E.flag) E.pos[0] = __longlong_as_double(0x7ff8000000000000ll);   // not positive definite: PhysicsError
+    }
+    __syncthreads();
+  }
+
+  // ---- results: per-env block for the post kernel, state back to HBM ---------------------------
+  if (live) {
+    double* dr = DR + gi * DR_STRIDE;
+    if (u < 3) dr[u] = E.qacc[u];
+    if (u < 8) dr[3 + u] = E.touch[u];
+    if (u == 0) {
+      double m = 0, mc[2] = {0, 0};
+      for (int b = 0; b < DG_NB; b++) { m += E.Ib[b][0]; mc[0] += E.Ib[b][1]; mc[1] += E.Ib[b][2]; }
+      dr[11] = E.pos[0] + mc[0] / m; dr[12] = E.pos[1] + mc[1] / m;
+      for (int k = 0; k < 2; k++) {
+        double P = m * E.qdv[k];
+        for (int j = 3; j < DG_NV; j++) P += E.Mlin[k][j] * E.qdv[j];
+        dr[13 + k] = P / m;
+      }
+      dr[15] = (double)cost_contacts; dr[16] = (double)btn_mask;
+    }
+    if (!p.observe_only) {
+      if (u == 0) {
+        DgState D;
+        for (int k = 0; k < 3; k++) { D.pos[k] = E.pos[k]; D.vlin[k] = E.vlin[k]; D.wloc[k] = E.wloc[k]; }
+        for (int k = 0; k < 4; k++) D.quat[k] = E.quat[k];
+        for (int j = 0; j < DG_NJ; j++) { D.q[j] = E.q[j]; D.qd[j] = E.qd[j]; }
+        float yaw, wz;
+        dg_store(D, S, N, gi, yaw, wz);
+      }
+      if (u < NBODY) {
+        const bool isb = u == BOX_ID;
+        if (isb ? W.has_box : u < W.nV)
+          for (int c = 0; c < 3; c++) {
+            S[((size_t)((DV_POS + 3 * u + c) >> 2) * N + gi) * 4 + ((DV_POS + 3 * u + c) & 3)] = E.wfb[u][c];
+            S[((size_t)((DV_VEL + 3 * u + c) >> 2) * N + gi) * 4 + ((DV_VEL + 3 * u + c) & 3)] = E.wfb[u][3 + c];
+          }
+      }
+    }
   }
 }
 
