@@ -82,7 +82,10 @@ struct sag_ctx {
   int n_cu = 256;      // compute units of the device
   uint8_t* d_rgb = nullptr;  // [N][64][64][3], allocated by the first sag_render_rgb
   double* d_dr = nullptr;    // Doggo cooperative form: per-env result block of the physics kernel
-  bool doggo_coop = false;   // SAG_DOGGO_COOP=1
+  // Doggo: wave-cooperative physics kernel (2 envs per wavefront, 3 wavefronts per CU) for batches up
+  // to ~12k envs (measured 8.4 vs 16.8 ms at 4096), the lane-per-env kernel above that (36 vs 48 ms at
+  // 32768: it keeps 64 envs per wavefront busy).  SAG_DOGGO_COOP=0/1 forces one.
+  bool doggo_coop = false;
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
@@ -383,6 +386,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("SAG_OVERLAP")) c->overlap = atoi(e) != 0;
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
+  c->doggo_coop = cfg->robot == SAG_ROBOT_DOGGO && cfg->n_envs <= 12288;
   if (const char* e = getenv("SAG_DOGGO_COOP")) c->doggo_coop = atoi(e) != 0;
   {
     hipDeviceProp_t prop;

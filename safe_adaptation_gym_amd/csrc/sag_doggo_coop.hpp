@@ -27,28 +27,36 @@ struct DcEnv {                                  // one env's working set in LDS
   double S[DG_NV][6];                           // [a; l]
   double Ib[DG_NB][10], Ic[DG_NB][10];          // m, mc[3], I[6]
   double F[DG_NV][6];                           // CRBA: Ic[body(j)] S_j ; RNEA: scratch
-  double vb[DG_NB][6], ab[DG_NB][6], fb[DG_NB][6];
+  double fb[DG_NB][6];
   double M[DG_NV][DG_NV + 1];                   // mass matrix, then its Cholesky factor (lower); +1: bank padding
   double Minv[DG_NV][DG_NV + 1];
   double bias[DG_NV], tau[DG_NV], qacc[DG_NV], qdv[DG_NV], col[DG_NV];
   double sph[DG_NS][3];
   double touch[8];
-  float rJ[DC_ROWS][DG_NV];
-  double rW[DC_ROWS][DG_NV];
+  float rJ[DC_ROWS][DG_NV], rW[DC_ROWS][DG_NV];   // W in fp32 like J: 51 KB per wavefront -> three per CU
   double Mlin[2][DG_NV];                        // rows 0, 1 of the mass matrix (momentum, Unsupervised)
   double rA[DC_ROWS], rAref[DC_ROWS], rImp[DC_ROWS], rF[DC_ROWS], rMu[DC_ROWS];
+  double rReg[DC_ROWS], rInv[DC_ROWS];           // A (1 - d) / d and 1 / (A + reg): no division inside the PGS sweeps
   float rOu[DC_ROWS][3], rOd[DC_ROWS][2], rOrx[DC_ROWS], rOry[DC_ROWS];
   short rParent[DC_ROWS], rOther[DC_ROWS], rTouch[DC_ROWS];
   float wfb[NBODY][9], wminv[NBODY][6];         // planar free bodies
   int nrows, flag;
 };
 
+// Both envs of the wavefront.  File scope, so that the (non-inlined) phase functions address it as LDS:
+// through a `DcEnv&` parameter every access would be a flat instruction.
+__shared__ DcEnv g_dc_env[2];
+#define DC_ENV DcEnv& E = g_dc_env[hf]
+
 // paths of the kinematic tree (static): bodies from the root's child down to b
-__device__ inline int dc_path(int b, int* path) {  // returns length; path excludes the root
-  int n = 0, tmp[4];
-  for (int c = b; c > 0; c = g_dg.parent[c]) tmp[n++] = c;
-  for (int k = 0; k < n; k++) path[k] = tmp[n - 1 - k];
-  return n;
+struct DcPath { int n, c0, c1, c2; __device__ int at(int s) const { return s == 0 ? c0 : (s == 1 ? c1 : c2); } };
+__device__ inline int dc_path(int b, DcPath& path) {  // bodies from the root's child down to b (depth <= 3), in registers
+  const int a1 = b, a2 = b > 0 ? g_dg.parent[a1] : 0, a3 = a2 > 0 ? g_dg.parent[a2] : 0;
+  if (b <= 0) { path.n = 0; path.c0 = path.c1 = path.c2 = 0; }
+  else if (a2 <= 0) { path.n = 1; path.c0 = a1; path.c1 = path.c2 = 0; }
+  else if (a3 <= 0) { path.n = 2; path.c0 = a2; path.c1 = a1; path.c2 = 0; }
+  else { path.n = 3; path.c0 = a3; path.c1 = a2; path.c2 = a1; }
+  return path.n;
 }
 __device__ inline int dc_first_dof(int b) {  // first dof of body b (b >= 1)
   const int T[DG_NB] = {0, 6, 8, 9, 11, 12, 13, 15, 16, 18};
@@ -67,7 +75,8 @@ __device__ inline void dc_rot_apply(double* R, const double* axis, double ang) {
 }
 
 // phase 1: frames, motion vectors, inertias about O = base origin, sphere centres.  `u` = lane in the half.
-__device__ __attribute__((noinline)) void dc_kinematics(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_kinematics(int hf, int u) {
+  DC_ENV;
   const DgModel& M = g_dg;
   double R0[9];
   dg_quat2mat(E.quat, R0);
@@ -78,12 +87,12 @@ __device__ __attribute__((noinline)) void dc_kinematics(DcEnv& E, int u) {
     else if (u < 6) { a[0] = R0[u - 3]; a[1] = R0[3 + u - 3]; a[2] = R0[6 + u - 3]; }
     else {
       const int b = M.dof_body[u];
-      int path[4];
+      DcPath path;
       const int n = dc_path(b, path);
       double R[9], p[3] = {E.pos[0], E.pos[1], E.pos[2]};
       for (int k = 0; k < 9; k++) R[k] = R0[k];
       for (int s = 0; s < n; s++) {
-        const int c = path[s];
+        const int c = path.at(s);
         double off[3];
         dg_matvec(R, M.bpos[c], off);
         for (int k = 0; k < 3; k++) p[k] += off[k];
@@ -98,12 +107,12 @@ __device__ __attribute__((noinline)) void dc_kinematics(DcEnv& E, int u) {
   }
   // body role
   if (u < DG_NB) {
-    int path[4];
+    DcPath path;
     const int n = dc_path(u, path);
     double R[9], p[3] = {E.pos[0], E.pos[1], E.pos[2]};
     for (int k = 0; k < 9; k++) R[k] = R0[k];
     for (int s = 0; s < n; s++) {
-      const int c = path[s];
+      const int c = path.at(s);
       double off[3];
       dg_matvec(R, M.bpos[c], off);
       for (int k = 0; k < 3; k++) p[k] += off[k];
@@ -127,7 +136,8 @@ __device__ __attribute__((noinline)) void dc_kinematics(DcEnv& E, int u) {
   }
 }
 // sphere centres (needs E.R / E.p)
-__device__ __attribute__((noinline)) void dc_spheres(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_spheres(int hf, int u) {
+  DC_ENV;
   if (u < DG_NS) {
     const int b = g_dg.sph_body[u];
     double o[3];
@@ -161,7 +171,8 @@ __device__ inline void dc_mcross(const double* v, const double* s, double* o) {
 }
 
 // phases 3-6 need barriers between them; the caller owns the barriers (one wavefront per workgroup)
-__device__ __attribute__((noinline)) void dc_composite(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_composite(int hf, int u) {
+  DC_ENV;
   if (u < DG_NB) {
     double acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
@@ -171,10 +182,12 @@ __device__ __attribute__((noinline)) void dc_composite(DcEnv& E, int u) {
     for (int k = 0; k < 10; k++) E.Ic[u][k] = acc[k];
   }
 }
-__device__ __attribute__((noinline)) void dc_crba_f(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_crba_f(int hf, int u) {
+  DC_ENV;
   if (u < DG_NV) dc_inertia_apply(E.Ic[g_dg.dof_body[u]], E.S[u], E.F[u]);
 }
-__device__ __attribute__((noinline)) void dc_crba_rows(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_crba_rows(int hf, int u) {
+  DC_ENV;
   if (u < DG_NV) {
     const int bi = g_dg.dof_body[u];
     for (int j = 0; j < DG_NV; j++) {
@@ -187,7 +200,8 @@ __device__ __attribute__((noinline)) void dc_crba_rows(DcEnv& E, int u) {
   }
 }
 // body velocities / accelerations (qacc = 0) and the body wrenches
-__device__ __attribute__((noinline)) void dc_rnea_bodies(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_rnea_bodies(int hf, int u) {
+  DC_ENV;
   if (u < DG_NB) {
     double v[6], a[6];
     for (int k = 0; k < 3; k++) { v[k] = 0; v[3 + k] = E.vlin[k]; a[k] = 0; }
@@ -195,10 +209,10 @@ __device__ __attribute__((noinline)) void dc_rnea_bodies(DcEnv& E, int u) {
       for (int c = 0; c < 3; c++) v[c] += E.S[3 + k][c] * E.wloc[k];
     dg_cross(E.vlin, v, a + 3);
     a[5] += DG_GRAV;
-    int path[4];
+    DcPath path;
     const int n = dc_path(u, path);
     for (int s = 0; s < n; s++) {
-      const int c = path[s], d0 = dc_first_dof(c), nd = dc_ndof(c);
+      const int c = path.at(s), d0 = dc_first_dof(c), nd = dc_ndof(c);
       for (int d = d0; d < d0 + nd; d++) {
         double sd[6];
         dc_mcross(v, E.S[d], sd);
@@ -215,7 +229,8 @@ __device__ __attribute__((noinline)) void dc_rnea_bodies(DcEnv& E, int u) {
     for (int k = 0; k < 6; k++) E.fb[u][k] = f[k];
   }
 }
-__device__ __attribute__((noinline)) void dc_rnea_bias(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_rnea_bias(int hf, int u) {
+  DC_ENV;
   if (u < DG_NV) {
     const int b = g_dg.dof_body[u];
     double F[6] = {0, 0, 0, 0, 0, 0};
@@ -226,27 +241,39 @@ __device__ __attribute__((noinline)) void dc_rnea_bias(DcEnv& E, int u) {
   }
 }
 
-// Cholesky of E.M in place (lower), right-looking; lane i updates row i.  Barriers inside.
-__device__ __attribute__((noinline)) void dc_cholesky(DcEnv& E, int u) {
+// Cholesky of E.M in place (lower), right-looking; lane i holds row i in registers (static indices,
+// k loops unrolled) and publishes column j to LDS for the rank-1 update.  Barriers inside.
+__device__ __attribute__((noinline)) void dc_cholesky(int hf, int u) {
+  DC_ENV;
+  double row[DG_NV];
+  const int ur = u < DG_NV ? u : 0;
+#pragma unroll
+  for (int k = 0; k < DG_NV; k++) row[k] = E.M[ur][k];
 #pragma unroll 1
   for (int j = 0; j < DG_NV; j++) {
+    double rj = 0;   // row[j] without a run-time register index
+#pragma unroll
+    for (int k = 0; k < DG_NV; k++) rj = k == j ? row[k] : rj;
     if (u == j) {
-      const double d = E.M[j][j];
-      if (!(d > 0)) E.flag = 1;
-      E.M[j][j] = sqrt(d);
+      if (!(rj > 0)) E.flag = 1;
+      E.col[0] = sqrt(rj);
     }
     __syncthreads();
-    if (u > j && u < DG_NV) E.M[u][j] = E.M[u][j] / E.M[j][j];
+    const double d = E.col[0];
+    const double lij = u == j ? d : rj / d;     // column j of L, entry of this lane's row
+    if (u >= j && u < DG_NV) E.M[u][j] = lij;   // published: E.M[k][j] for k >= j is final
     __syncthreads();
     if (u > j && u < DG_NV) {
-      const double lij = E.M[u][j];
-      for (int k = j + 1; k <= u; k++) E.M[u][k] -= lij * E.M[k][j];
+#pragma unroll
+      for (int k = 0; k < DG_NV; k++)
+        if (k > j && k <= u) row[k] -= lij * E.M[k][j];
     }
     __syncthreads();
   }
 }
 // x <- (L L^T)^-1 b, component i of b / x in lane i's register `x`; E.col is the broadcast slot
-__device__ __attribute__((noinline)) double dc_solve1(DcEnv& E, int u, double x) {
+__device__ __attribute__((noinline)) double dc_solve1(int hf, int u, double x) {
+  DC_ENV;
 #pragma unroll 1
   for (int j = 0; j < DG_NV; j++) {   // forward: L y = b
     if (u == j) { x = x / E.M[j][j]; E.col[0] = x; }
@@ -264,7 +291,8 @@ __device__ __attribute__((noinline)) double dc_solve1(DcEnv& E, int u, double x)
   return x;
 }
 // M^-1: 19 right-hand sides (identity), lane i holds component i of each; result row i -> E.Minv[i][:]
-__device__ __attribute__((noinline)) void dc_inverse(DcEnv& E, int u) {
+__device__ __attribute__((noinline)) void dc_inverse(int hf, int u) {
+  DC_ENV;
   double x[DG_NV];
 #pragma unroll
   for (int r = 0; r < DG_NV; r++) x[r] = (u == r) ? 1.0 : 0.0;
@@ -310,7 +338,8 @@ __device__ __attribute__((noinline)) void dc_inverse(DcEnv& E, int u) {
 namespace sag {
 
 // load the env's robot state into LDS (lane 0 of the half), zero flags
-__device__ inline void dc_load_state(DcEnv& E, int u, const float* S, size_t N, size_t i) {
+__device__ inline void dc_load_state(int hf, int u, const float* S, size_t N, size_t i) {
+  DC_ENV;
   if (u == 0) {
     DgState D;
     dg_load(D, S, N, i);
@@ -322,17 +351,18 @@ __device__ inline void dc_load_state(DcEnv& E, int u, const float* S, size_t N, 
 }
 
 // smooth dynamics: everything up to qacc0 = M^-1 (tau - bias).  ctrl12: LDS/global pointer or nullptr (zero)
-__device__ inline void dc_smooth(DcEnv& E, int u, const float* ctrl12) {
-  dc_kinematics(E, u);
+__device__ inline void dc_smooth(int hf, int u, const float* ctrl12) {
+  DC_ENV;
+  dc_kinematics(hf, u);
   __syncthreads();
-  dc_spheres(E, u);
-  dc_composite(E, u);
-  dc_rnea_bodies(E, u);
+  dc_spheres(hf, u);
+  dc_composite(hf, u);
+  dc_rnea_bodies(hf, u);
   __syncthreads();
-  dc_crba_f(E, u);
-  dc_rnea_bias(E, u);
+  dc_crba_f(hf, u);
+  dc_rnea_bias(hf, u);
   __syncthreads();
-  dc_crba_rows(E, u);
+  dc_crba_rows(hf, u);
   if (u < DG_NV) {
     double t = 0;
     if (u >= 6) {
@@ -350,23 +380,23 @@ __device__ inline void dc_smooth(DcEnv& E, int u, const float* ctrl12) {
 
 // debug: mass matrix [19x19], bias [19], qacc0 [19], Minv [19x19] per env -> out[N][19*19*2 + 38]
 __global__ __launch_bounds__(64) void k_doggo_coop_debug(const float* __restrict__ S, int N, double* __restrict__ out) {
-  __shared__ DcEnv env[2];
   const int lane = threadIdx.x, half = lane >> 5, u = lane & 31;
   const size_t i = (size_t)blockIdx.x * 2 + half;
   const bool live = i < (size_t)N;
-  DcEnv& E = env[half];
-  dc_load_state(E, u, S, (size_t)N, live ? i : (size_t)N - 1);
+  const int hf = half;
+  DC_ENV;
+  dc_load_state(hf, u, S, (size_t)N, live ? i : (size_t)N - 1);
   __syncthreads();
-  dc_smooth(E, u, nullptr);
+  dc_smooth(hf, u, nullptr);
   double* o = out + (live ? i : 0) * (size_t)(2 * DG_NV * DG_NV + 2 * DG_NV);
   if (live && u < DG_NV) {
     for (int j = 0; j < DG_NV; j++) o[u * DG_NV + j] = E.M[u][j];
     o[DG_NV * DG_NV + u] = E.bias[u];
   }
   __syncthreads();
-  dc_cholesky(E, u);
-  const double x = dc_solve1(E, u, u < DG_NV ? E.tau[u] : 0.0);
-  dc_inverse(E, u);
+  dc_cholesky(hf, u);
+  const double x = dc_solve1(hf, u, u < DG_NV ? E.tau[u] : 0.0);
+  dc_inverse(hf, u);
   if (live && u < DG_NV) {
     o[DG_NV * DG_NV + DG_NV + u] = x;
     for (int j = 0; j < DG_NV; j++) o[DG_NV * DG_NV + 2 * DG_NV + u * DG_NV + j] = E.Minv[u][j];
@@ -398,21 +428,27 @@ __device__ inline double dc_sum32(double v) {
   return v;
 }
 
-// Row r from a Jacobian in registers (owner lane): stores J (fp32), W = M^-1 J^T, A (+ other body),
-// velocity along the row; returns that velocity
-__device__ __attribute__((noinline)) double dc_build_row(DcEnv& E, int r, const double* J, int other, double dx, double dy, double px, double py) {
-  float Jf[DG_NV];
+// Row r whose Jacobian the owner lane has already written to E.rJ[r] (fp32): W = M^-1 J^T, A (+ other
+// body), velocity along the row (returned).  Everything indexed at run time lives in LDS - a private
+// array indexed by a loop variable would go to scratch memory.
+__device__ __attribute__((noinline)) double dc_build_row(int hf, int r, int other, double dx, double dy, double px, double py) {
+  DC_ENV;
+  // the row's Jacobian in registers (static indices: every loop over it is fully unrolled), so the
+  // LDS reads of a product are issued together instead of one round trip per multiply-add
+  double Jr[DG_NV];
+#pragma unroll
+  for (int k = 0; k < DG_NV; k++) Jr[k] = (double)E.rJ[r][k];
   double vel = 0;
-#pragma unroll 1
-  for (int i = 0; i < DG_NV; i++) { Jf[i] = (float)J[i]; E.rJ[r][i] = Jf[i]; vel += (double)Jf[i] * E.qdv[i]; }
+#pragma unroll
+  for (int k = 0; k < DG_NV; k++) vel += Jr[k] * E.qdv[k];
   double A = 0;
 #pragma unroll 1
   for (int i = 0; i < DG_NV; i++) {
     double w = 0;
-    for (int k = 0; k < DG_NV; k++)
-      if (Jf[k] != 0.f) w += E.Minv[i][k] * (double)Jf[k];
-    E.rW[r][i] = w;
-    A += (double)Jf[i] * w;
+#pragma unroll
+    for (int k = 0; k < DG_NV; k++) w += E.Minv[i][k] * Jr[k];
+    E.rW[r][i] = (float)w;
+    A += (double)E.rJ[r][i] * w;
   }
   E.rOther[r] = (short)other; E.rParent[r] = -1; E.rTouch[r] = -1; E.rF[r] = 0; E.rMu[r] = 0;
   float ou0 = 0, ou1 = 0, ou2 = 0, od0 = 0, od1 = 0, orx = 0, ory = 0;
@@ -434,24 +470,26 @@ __device__ __attribute__((noinline)) double dc_build_row(DcEnv& E, int r, const 
   return vel;
 }
 
-// Jacobian of point c on body b along d (registers)
-__device__ inline void dc_jac(const DcEnv& E, int b, const double* c, const double* d, double* J) {
-  const double r[3] = {c[0] - E.pos[0], c[1] - E.pos[1], c[2] - E.pos[2]};
+// Jacobian of point c on body b along d, written to E.rJ[r] (fp32)
+__device__ inline void dc_jac(int hf, int r, int b, const double* c, const double* d) {
+  DC_ENV;
+  const double rr[3] = {c[0] - E.pos[0], c[1] - E.pos[1], c[2] - E.pos[2]};
 #pragma unroll 1
   for (int i = 0; i < DG_NV; i++) {
     double v = 0;
     if (g_dg.anc[b] >> g_dg.dof_body[i] & 1u) {
       double t[3];
-      dg_cross(E.S[i], r, t);
+      dg_cross(E.S[i], rr, t);
       v = d[0] * (E.S[i][3] + t[0]) + d[1] * (E.S[i][4] + t[1]) + d[2] * (E.S[i][5] + t[2]);
     }
-    J[i] = v;
+    E.rJ[r][i] = (float)v;
   }
 }
 
 // the three rows of one contact, built by its owner lane at rows [base, base + 3)
-__device__ __attribute__((noinline)) void dc_contact_rows(DcEnv& E, int base, int s, const double* n, const double* c, double depth, int other,
+__device__ __attribute__((noinline)) void dc_contact_rows(int hf, int base, int s, const double* n, const double* c, double depth, int other,
                                        double bcoef, double kcoef, double mu) {
+  DC_ENV;
   const int b = g_dg.sph_body[s];
   double dir[3][3];
   for (int k = 0; k < 3; k++) dir[0][k] = n[k];
@@ -461,10 +499,10 @@ __device__ __attribute__((noinline)) void dc_contact_rows(DcEnv& E, int base, in
   const double imp = dg_impedance(depth);
 #pragma unroll 1
   for (int k = 0; k < 3; k++) {
-    double J[DG_NV];
-    dc_jac(E, b, c, dir[k], J);
-    const double vel = dc_build_row(E, base + k, J, other, -dir[k][0], -dir[k][1], c[0], c[1]);
+    dc_jac(hf, base + k, b, c, dir[k]);
+    const double vel = dc_build_row(hf, base + k, other, -dir[k][0], -dir[k][1], c[0], c[1]);
     E.rImp[base + k] = imp;
+    { const double A_ = E.rA[base + k], reg_ = A_ * (1 - imp) / imp; E.rReg[base + k] = reg_; E.rInv[base + k] = 1.0 / (A_ + reg_); }
     if (k == 0) { E.rAref[base] = -bcoef * vel + kcoef * depth; E.rTouch[base] = (short)g_dg.sph_touch[s]; }
     else { E.rAref[base + k] = -bcoef * vel; E.rParent[base + k] = (short)base; E.rMu[base + k] = mu; }
   }
@@ -472,8 +510,9 @@ __device__ __attribute__((noinline)) void dc_contact_rows(DcEnv& E, int base, in
 
 // spheres of the robot (one per lane) vs one planar body: appends the contact rows in (sphere, geom)
 // order; returns the number of contacts (uniform in the half)
-__device__ __attribute__((noinline)) int dc_collide_body(DcEnv& E, int u, int& nrows, int fbi, int shape, float bx, float by, float byaw,
+__device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int& nrows, int fbi, int shape, float bx, float by, float byaw,
                                       float rbound, float vsz, float rstatic, double top, double bcoef, double kcoef, double mu) {
+  DC_ENV;
   DgHit hits[5];
   int cnt = 0;
   double cz = 0;
@@ -505,7 +544,7 @@ __device__ __attribute__((noinline)) int dc_collide_body(DcEnv& E, int u, int& n
     const int idx = excl + k;
     if (idx < fit) {
       const double nn[3] = {-(double)hits[k].nx, -(double)hits[k].ny, 0}, pc[3] = {(double)hits[k].px, (double)hits[k].py, cz};
-      dc_contact_rows(E, nrows + 3 * idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu);
+      dc_contact_rows(hf, nrows + 3 * idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu);
     }
   }
   nrows += 3 * fit;
@@ -522,7 +561,6 @@ struct DcWorldK {
 };
 
 __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __restrict__ DR) {
-  __shared__ DcEnv env[2];
   __shared__ float ctrl_s[2][12];
   __shared__ float stx_s[2][SAG_MAX_PILLARS + SAG_MAX_BUTTONS], sty_s[2][SAG_MAX_PILLARS + SAG_MAX_BUTTONS];
   const int lane = threadIdx.x, half = lane >> 5, u = lane & 31;
@@ -530,7 +568,8 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
   const size_t gi = (size_t)blockIdx.x * 2 + half;
   const bool live = gi < N;
   const size_t i = live ? gi : N - 1;
-  DcEnv& E = env[half];
+  const int hf = half;
+  DC_ENV;
   float* __restrict__ S = p.S;
   const float* stx = stx_s[half];
   const float* sty = sty_s[half];
@@ -573,7 +612,7 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
   const double top_box = W.bk.sh == SH_ROD ? 0.16 : (W.bk.sh == SH_BALL ? 0.28 : 0.4);
 
   // ---- load: robot state (lane 0), planar bodies (lane k), statics, controls ----------------
-  dc_load_state(E, u, S, N, i);
+  dc_load_state(hf, u, S, N, i);
   if (u < NBODY) {
     const int k = u;
     const bool isb = k == BOX_ID, on = isb ? W.has_box : k < W.nV;
@@ -614,6 +653,8 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
   }
   __syncthreads();
 
+  long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64();
+#define TK(k) do { const long long t_ = clock64(); tk[k] += t_ - t0; t0 = t_; } while (0)
   const int nsub = p.observe_only ? 0 : ((p.debug & 32) ? 1 : p.nstep);
   int cost_contacts = 0;
   uint32_t btn_mask = 0;
@@ -627,17 +668,18 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
       E.wminv[BOX_ID][0] = c * c * ix + s * s * iy; E.wminv[BOX_ID][1] = c * s * (ix - iy);
       E.wminv[BOX_ID][3] = s * s * ix + c * c * iy;
     }
-    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d top: pos0 %g\n", sub, E.pos[0]);
-    dc_smooth(E, u, ctrl_s[half]);
-    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after smooth: pos0 %g\n", sub, E.pos[0]);
+    TK(9);
+    dc_smooth(hf, u, ctrl_s[half]);
+    TK(0);
     if (u < 2)
       for (int j = 0; j < DG_NV; j++) E.Mlin[u][j] = j >= u ? E.M[u][j] : 0.0;
     __syncthreads();
-    dc_cholesky(E, u);
-    qacc_u = dc_solve1(E, u, u < DG_NV ? E.tau[u] : 0.0);
-    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after solve: pos0 %g\n", sub, E.pos[0]);
-    dc_inverse(E, u);
-    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after inverse: pos0 %g\n", sub, E.pos[0]);
+    dc_cholesky(hf, u);
+    TK(1);
+    qacc_u = dc_solve1(hf, u, u < DG_NV ? E.tau[u] : 0.0);
+    TK(2);
+    dc_inverse(hf, u);
+    TK(3);
     if (u < 8) E.touch[u] = 0;
     int nrows = 0;
     // ---- rows: joint limits (lane j), in ascending joint order ---------------------------------
@@ -651,12 +693,11 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
       const int excl = dc_scan32(sign != 0 ? 1 : 0, u, total);
       const int fit = min(total, DC_ROWS - nrows);
       if (sign != 0 && excl < fit) {
-        double J[DG_NV];
-        for (int k = 0; k < DG_NV; k++) J[k] = 0;
-        J[6 + u] = sign;
         const int r = nrows + excl;
-        const double vel = dc_build_row(E, r, J, -1, 0, 0, 0, 0);
+        for (int k = 0; k < DG_NV; k++) E.rJ[r][k] = k == 6 + u ? (float)sign : 0.f;
+        const double vel = dc_build_row(hf, r, -1, 0, 0, 0, 0);
         E.rImp[r] = dg_impedance(depth);
+        { const double A_ = E.rA[r], im_ = E.rImp[r], reg_ = A_ * (1 - im_) / im_; E.rReg[r] = reg_; E.rInv[r] = 1.0 / (A_ + reg_); }
         E.rAref[r] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * depth;
       }
       nrows += fit;
@@ -670,7 +711,7 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
       const int fit = min(total, (DC_ROWS - nrows) / 3);
       if (depth > 0 && excl < fit) {
         const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dg.sph_r[u])};
-        dc_contact_rows(E, nrows + 3 * excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
+        dc_contact_rows(hf, nrows + 3 * excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
       }
       nrows += 3 * fit;
     }
@@ -684,22 +725,22 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
 #pragma unroll 1
     for (int q = 0; q < W.nP; q++)
       if (near(stx[q], sty[q], W.psz))
-        cc += dc_collide_body(E, u, nrows, -1, SH_STATIC, stx[q], sty[q], 0.f, W.psz, W.vsz, W.psz, 1.0,
+        cc += dc_collide_body(hf, u, nrows, -1, SH_STATIC, stx[q], sty[q], 0.f, W.psz, W.vsz, W.psz, 1.0,
                               (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
 #pragma unroll 1
     for (int b = 0; b < W.nB; b++)
       if (near(stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], BUTTON_R) &&
-          dc_collide_body(E, u, nrows, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f, BUTTON_R, W.vsz,
+          dc_collide_body(hf, u, nrows, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f, BUTTON_R, W.vsz,
                           BUTTON_R, 0.2, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu))
         mask |= 1u << b;
 #pragma unroll 1
     for (int k = 0; k < W.nV; k++)
       if (near(E.wfb[k][0], E.wfb[k][1], vase_r))
-        cc += dc_collide_body(E, u, nrows, k, SH_VASE, E.wfb[k][0], E.wfb[k][1], E.wfb[k][2], vase_r, W.vsz, 0.f, top_vase,
+        cc += dc_collide_body(hf, u, nrows, k, SH_VASE, E.wfb[k][0], E.wfb[k][1], E.wfb[k][2], vase_r, W.vsz, 0.f, top_vase,
                               (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
     if (W.has_box) {
       if (near(E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], box_r))
-        dc_collide_body(E, u, nrows, BOX_ID, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], E.wfb[BOX_ID][2], box_r, W.vsz, 0.f,
+        dc_collide_body(hf, u, nrows, BOX_ID, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], E.wfb[BOX_ID][2], box_r, W.vsz, 0.f,
                         top_box, (double)W.solb.bcoef, (double)W.solb.kcoef, (double)W.solb.mu);
       if (W.haul && nrows < DC_ROWS) {   // haul_box.py:21-29: tendon base site <-> box site (z .2), range [0, .75]
         const double dx = (double)E.wfb[BOX_ID][0] - E.pos[0], dy = (double)E.wfb[BOX_ID][1] - E.pos[1], dz = 0.2 - E.pos[2];
@@ -707,10 +748,10 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
         if (viol > 0 && d2 >= 1e-18) {
           if (u == 0) {
             const double j[3] = {dx / Lt, dy / Lt, dz / Lt};
-            double J[DG_NV];
-            dc_jac(E, 0, E.pos, j, J);
-            const double vel = dc_build_row(E, nrows, J, BOX_ID, -j[0], -j[1], (double)E.wfb[BOX_ID][0], (double)E.wfb[BOX_ID][1]);
+            dc_jac(hf, nrows, 0, E.pos, j);
+            const double vel = dc_build_row(hf, nrows, BOX_ID, -j[0], -j[1], (double)E.wfb[BOX_ID][0], (double)E.wfb[BOX_ID][1]);
             E.rImp[nrows] = dg_impedance(viol);
+            { const double A_ = E.rA[nrows], im_ = E.rImp[nrows], reg_ = A_ * (1 - im_) / im_; E.rReg[nrows] = reg_; E.rInv[nrows] = 1.0 / (A_ + reg_); }
             E.rAref[nrows] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * viol;
           }
           nrows += 1;
@@ -718,7 +759,7 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
       }
     }
     __syncthreads();
-    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after rows: pos0 %g nrows %d\n", sub, E.pos[0], nrows);
+    TK(4);
     // ---- projected Gauss-Seidel: rows in sequence, the dot product J.qacc across the lanes ---
     int nmax = max(nrows, __shfl(nrows, (lane + 32) & 63));   // both halves walk the longer list
     if (p.debug & 1) nmax = 0;
@@ -728,18 +769,22 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
       for (int r = 0; r < nmax; r++) {
         const bool on = r < nrows;
         const int rr = on ? r : 0;
-        double part = (on && u < DG_NV) ? (double)E.rJ[rr][u] * qacc_u : 0.0;
-        double acc = dc_sum32(part);
+        // J.qacc: partial products to LDS, every lane sums the 19 (reads issued together; a 5-step
+        // butterfly of cross-lane permutes costs three times the latency)
+        if (u < DG_NV) E.col[u] = on ? (double)E.rJ[rr][u] * qacc_u : 0.0;
+        __syncthreads();
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < DG_NV; k++) acc += E.col[k];
         const int other = on ? (int)E.rOther[rr] : -1;
         if (other >= 0) {
           const float* B = E.wfb[other];
           acc += (double)((B[6] - B[8] * E.rOry[rr]) * E.rOd[rr][0] + (B[7] + B[8] * E.rOrx[rr]) * E.rOd[rr][1]);
         }
-        const double A = E.rA[rr], imp = E.rImp[rr], f = E.rF[rr];
+        const double A = E.rA[rr], f = E.rF[rr];
         double df = 0;
         if (on && A > 0) {
-          const double reg = A * (1 - imp) / imp;
-          double fnew = f + (E.rAref[rr] - acc - reg * f) / (A + reg);
+          double fnew = f + (E.rAref[rr] - acc - E.rReg[rr] * f) * E.rInv[rr];
           double lo = 0, hi = 1e30;
           const int par = E.rParent[rr];
           if (par >= 0) { const double fn = E.rF[par]; lo = -E.rMu[rr] * fn; hi = E.rMu[rr] * fn; }
@@ -749,7 +794,7 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
         }
         __syncthreads();   // every lane has read f / the body accelerations of this row
         if (df != 0) {
-          if (u < DG_NV) qacc_u += E.rW[rr][u] * df;
+          if (u < DG_NV) qacc_u += (double)E.rW[rr][u] * df;
           if (u == 0) {
             E.rF[rr] = f + df;
             if (other >= 0) {
@@ -769,7 +814,7 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
     }
     cost_contacts = cc; btn_mask = mask;
     __syncthreads();
-    if ((p.debug & 64) && u == 0 && gi == 0) printf("sub %d after pgs: pos0 %g\n", sub, E.pos[0]);
+    TK(5);
     if (sub == nsub) break;
     // ---- planar world: body k on lane k vs the statics; pairs on lane 0; friction + integration --
     if (u < NBODY && !(p.debug & 2)) {
@@ -835,6 +880,7 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
         for (int c = 0; c < 6; c++) E.wfb[u][c] = B[c];
       }
     }
+    TK(6);
     // ---- robot: semi-implicit Euler --------------------------------------------------------
     if (u < DG_NV && !(p.debug & 16)) {
       const double v = E.qdv[u] + (double)h * qacc_u;
@@ -859,6 +905,10 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
     __syncthreads();
   }
 
+  TK(7);
+  if ((p.debug & 128) && lane == 0 && blockIdx.x == 0)
+    printf("ticks: smooth %lld chol %lld solve %lld inverse %lld rows %lld pgs %lld world %lld tail %lld head %lld\n", tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], tk[9]);
+#undef TK
   // ---- results: per-env block for the post kernel, state back to HBM ---------------------------
   if (live) {
     double* dr = DR + gi * DR_STRIDE;

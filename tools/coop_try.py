@@ -7,6 +7,9 @@ from safe_adaptation_gym_amd import _native as nat
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 task = sys.argv[2] if len(sys.argv) > 2 else 'go_to_goal'
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+if task == 'multitask':
+  from safe_adaptation_gym_amd import benchmark
+  task = [nm for nm, _ in benchmark.make('multitask', batch_size=n, seed=666).train_tasks]
 rf, ri = bu.sample_records_native('doggo', task, n, seed=666)
 ctxs = []
 for flag in ('0', '1'):
