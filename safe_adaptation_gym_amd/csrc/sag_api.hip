@@ -306,7 +306,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     // Doggo, wave-cooperative physics (32 lanes per env) + the generic step without physics
     if (!c->d_dr) HIPCHK(c, hipMalloc(&c->d_dr, (size_t)c->N * DR_STRIDE * sizeof(double)));
     a.DR = c->d_dr;
-    hipLaunchKernelGGL(k_doggo_physics, dim3((c->N + 1) / 2), dim3(WAVE), 0, c->stream, a, c->d_dr);
+    hipLaunchKernelGGL(k_doggo_physics, dim3((c->N + DC_EPW - 1) / DC_EPW), dim3(32 * DC_EPW), 0, c->stream, a, c->d_dr);
     hipLaunchKernelGGL((k_step_doggo_post<true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
   } else {  // Doggo, lane-per-env form: one (buttons + task object) instance, single launch
     hipLaunchKernelGGL((k_step<SAG_ROBOT_DOGGO, true, true>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave),
@@ -730,7 +730,7 @@ int sag_debug_doggo_coop(sag_ctx* c, double* out) {
   const size_t bytes = (size_t)c->N * (2 * DG_NV * DG_NV + 2 * DG_NV) * sizeof(double);
   double* d = nullptr;
   HIPCHK(c, hipMalloc(&d, bytes));
-  hipLaunchKernelGGL(k_doggo_coop_debug, dim3((c->N + 1) / 2), dim3(64), 0, c->stream, c->S, c->N, d);
+  hipLaunchKernelGGL(k_doggo_coop_debug, dim3((c->N + DC_EPW - 1) / DC_EPW), dim3(32 * DC_EPW), 0, c->stream, c->S, c->N, d);
   hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   (void)hipFree(d);

@@ -45,7 +45,12 @@ struct DcEnv {                                  // one env's working set in LDS
 
 // Both envs of the wavefront.  File scope, so that the (non-inlined) phase functions address it as LDS:
 // through a `DcEnv&` parameter every access would be a flat instruction.
-__shared__ DcEnv g_dc_env[2];
+// DC_EPW envs per wavefront (32 lanes each): 2 = 51 KB of LDS per wavefront, three wavefronts per CU.
+// 1 (a 32-thread workgroup per env, six per CU) was measured slower: 10.4 vs 8.4 ms at 4096 envs.
+#ifndef DC_EPW
+#define DC_EPW 2
+#endif
+__shared__ DcEnv g_dc_env[DC_EPW];
 #define DC_ENV DcEnv& E = g_dc_env[hf]
 
 // paths of the kinematic tree (static): bodies from the root's child down to b
@@ -379,9 +384,9 @@ __device__ inline void dc_smooth(int hf, int u, const float* ctrl12) {
 }
 
 // debug: mass matrix [19x19], bias [19], qacc0 [19], Minv [19x19] per env -> out[N][19*19*2 + 38]
-__global__ __launch_bounds__(64) void k_doggo_coop_debug(const float* __restrict__ S, int N, double* __restrict__ out) {
+__global__ __launch_bounds__(32 * DC_EPW) void k_doggo_coop_debug(const float* __restrict__ S, int N, double* __restrict__ out) {
   const int lane = threadIdx.x, half = lane >> 5, u = lane & 31;
-  const size_t i = (size_t)blockIdx.x * 2 + half;
+  const size_t i = (size_t)blockIdx.x * DC_EPW + half;
   const bool live = i < (size_t)N;
   const int hf = half;
   DC_ENV;
@@ -560,12 +565,12 @@ struct DcWorldK {
   Sol sol0, solb;
 };
 
-__global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __restrict__ DR) {
-  __shared__ float ctrl_s[2][12];
-  __shared__ float stx_s[2][SAG_MAX_PILLARS + SAG_MAX_BUTTONS], sty_s[2][SAG_MAX_PILLARS + SAG_MAX_BUTTONS];
+__global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, double* __restrict__ DR) {
+  __shared__ float ctrl_s[DC_EPW][12];
+  __shared__ float stx_s[DC_EPW][SAG_MAX_PILLARS + SAG_MAX_BUTTONS], sty_s[DC_EPW][SAG_MAX_PILLARS + SAG_MAX_BUTTONS];
   const int lane = threadIdx.x, half = lane >> 5, u = lane & 31;
   const size_t N = (size_t)p.N;
-  const size_t gi = (size_t)blockIdx.x * 2 + half;
+  const size_t gi = (size_t)blockIdx.x * DC_EPW + half;
   const bool live = gi < N;
   const size_t i = live ? gi : N - 1;
   const int hf = half;
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(64) void k_doggo_physics(StepArgs p, double* __rest
     __syncthreads();
     TK(4);
     // ---- projected Gauss-Seidel: rows in sequence, the dot product J.qacc across the lanes ---
-    int nmax = max(nrows, __shfl(nrows, (lane + 32) & 63));   // both halves walk the longer list
+    int nmax = DC_EPW == 2 ? max(nrows, __shfl(nrows, (lane + 32) & 63)) : nrows;   // both halves walk the longer list
     if (p.debug & 1) nmax = 0;
 #pragma unroll 1
     for (int it = 0; it < DG_PGS_ITERS; it++)
