@@ -310,7 +310,7 @@ def main(argv=None, run_factory=None, emit=print):
       t = timed(r4, 30, 5, lambda: None)
       ms, _ = r4.kernel_time_ms()
       res['c4_doggo_multitask_4096'] = {'value': 4096 * 30 / t, 'unit': 'env-steps/s', 'kernel_ms': ms,
-                                        'note': 'per GPU; fp64 articulated solve, 12 substeps, latency-bound (one wavefront per CU)'}
+                                        'note': 'per GPU; wave-cooperative fp64 articulated solve (32 lanes per env), 12 substeps'}
       r4.close()
       # BASELINE config 5 (stretch): Doggo / haul_box with rgb_observation: step + 64x64x3 render per env
       r5 = DeviceRun('haul_box', 4096, device, 0, robot='doggo')
