@@ -1442,8 +1442,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     if constexpr (!DOGGO) {
       // groups 0 and 1 whole (the goal half of group 1 is rewritten by the reward block if it moves)
       float4* __restrict__ W4 = reinterpret_cast<float4*>(S);
-      W4[(size_t)0 * N + i] = make_float4(R.x, R.y, yaw, R.vx);
-      W4[(size_t)1 * N + i] = make_float4(R.vy, R.w, gB.z, gB.w);
+      W4[(size_t)0 * N + i] = make_float4(R.x, R.y, yaw, R.vx);   // (group 1 follows the reward block: it carries the goal)
     }
     if constexpr (CAR) {
 #pragma unroll
@@ -1457,7 +1456,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (d >= 0) { SD(fv) = POOL(d, 0); SD(fv + 1) = POOL(d, 1); SD(fv + 2) = POOL(d, 2); }
     }
     step += 1;
-    I[iaddr(DI_STEP, (size_t)N, (size_t)i)] = step;
+    // whole int4 (meta, step, envid, flags): a 4-byte store at a 16-byte stride would leave partial lines
+    reinterpret_cast<int4*>(I + N)[i] = make_int4(iw.x, step, iw.z, iw.w);
   }
   tstate = (tstate & ~(TS_AWAKE_BITS << TS_AWAKE_SHIFT)) | (awake & TS_AWAKE_BITS) << TS_AWAKE_SHIFT;
   // ---- classification for the NEXT step (QUIET / BUSY split): busy unless provably nothing can
@@ -1714,8 +1714,19 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     if (live) {
       if (has_box) { SF(SAG_F_LAST + 1) = box_last1; SF(SAG_F_LAST + 2) = box_last2; }
-      SF(SAG_F_LAST) = last0;
-      SF(SAG_F_GOAL) = goalx; SF(SAG_F_GOAL + 1) = goaly;
+      if constexpr (DOGGO) {
+        SF(SAG_F_LAST) = last0;
+        SF(SAG_F_GOAL) = goalx; SF(SAG_F_GOAL + 1) = goaly;
+      }
+    }
+  }
+  if constexpr (!DOGGO) {
+    // groups 1 (vy w goal) and 2 (last0 gear damp noise) as whole float4: full lines instead of
+    // scattered dwords.  A failed env (PhysicsError) keeps its old goal and `last`.
+    if (!p.observe_only && live) {
+      float4* __restrict__ W4 = reinterpret_cast<float4*>(S);
+      W4[(size_t)1 * N + i] = make_float4(R.vy, R.w, bad ? gB.z : goalx, bad ? gB.w : goaly);
+      W4[(size_t)2 * N + i] = make_float4(bad ? gC.x : last0, gC.y, gC.z, gC.w);
     }
   }
   if (!p.observe_only && live) I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)] = (int32_t)tstate;
