@@ -55,6 +55,8 @@ struct sag_ctx {
   // list[phase] from the busy bits whenever state was installed from outside (list_valid = false)
   int32_t* d_rows = nullptr; int32_t* d_count = nullptr;
   bool list_valid = false;
+  float* d_hot = nullptr;     // [N][HOT_FLOATS] hot records (split form), see sag_device.hpp
+  bool hot_valid = false, use_hot = true;   // SAG_HOT=0 disables
   // SAG_INKERNEL_LIST=1: the step kernels append the next busy list themselves and k_compact only runs
   // after installs.  Measured no faster (0.37 vs 0.35 ms at 1M envs): the 15 us saved are lost to the
   // worse row locality of chunks in arrival order (k_compact emits rows sorted per 1024-env block).
@@ -234,7 +236,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.has_box = c->cfg.has_box; a.G = c->G;
   a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
   a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr;
-  a.debug = 0;
+  a.debug = 0; a.hot = nullptr;
   if (const char* e = getenv("SAG_DC_DEBUG")) a.debug = atoi(e);
   {
     // one Doggo wavefront per CU (its LDS working set): aim for one resident round over the chip
@@ -270,6 +272,14 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   hipStream_t quiet_stream = c->stream;
   if (split) {
     a.rows_next = c->d_rows + (size_t)(c->phase_used ^ 1) * c->N; a.count_next = c->d_count + (c->phase_used ^ 1);
+    if (c->use_hot) {
+      if (!c->d_hot) HIPCHK(c, hipMalloc(&c->d_hot, (size_t)c->N * HOT_FLOATS * sizeof(float)));
+      a.hot = c->d_hot;
+      if (!c->hot_valid) {
+        hipLaunchKernelGGL(k_hot_refresh, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N, c->d_hot);
+        c->hot_valid = true;
+      }
+    }
     if (!c->inkernel_list) { a.rows_next = nullptr; a.count_next = nullptr; c->list_valid = false; }
     else HIPCHK(c, hipMemsetAsync(a.count_next, 0, sizeof(int32_t), c->stream));
     if (!c->list_valid) {
@@ -386,6 +396,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("SAG_OVERLAP")) c->overlap = atoi(e) != 0;
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
+  if (const char* e = getenv("SAG_HOT")) c->use_hot = atoi(e) != 0;
   c->doggo_coop = cfg->robot == SAG_ROBOT_DOGGO && cfg->n_envs <= 12288;
   if (const char* e = getenv("SAG_DOGGO_COOP")) c->doggo_coop = atoi(e) != 0;
   {
@@ -429,7 +440,7 @@ int sag_destroy(sag_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
-                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr};
+                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr, c->d_hot};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -471,7 +482,7 @@ int sag_set_layout(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* r
   if (rc) return rc;
   hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 1);
-  c->list_valid = false;  // busy bits changed outside a step
+  c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   // keep a copy for sag_reset: read the installed state back into the AoS layout store
   hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i);
@@ -500,7 +511,7 @@ int sag_set_state(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* re
   if (rc) return rc;
   hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 0);
-  c->list_valid = false;  // busy bits changed outside a step
+  c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_layout = true;
@@ -533,7 +544,7 @@ int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
   if (!env_ids) {
     hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                        (const int32_t*)nullptr, n, c->L_f, c->L_i, 0);
-  c->list_valid = false;  // busy bits changed outside a step
+  c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   } else {
     for (int k = 0; k < n; k++)
       if (env_ids[k] < 0 || env_ids[k] >= c->N) return fail(c, SAG_ERR_ARG, "env id %d out of range", env_ids[k]);
@@ -547,7 +558,7 @@ int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
     HIPCHK(c, hipMemcpyAsync(c->st_ids, env_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                        c->st_ids, n, c->st_f, c->st_i, 0);
-  c->list_valid = false;  // busy bits changed outside a step
+  c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -122,9 +122,16 @@ struct StepArgs {
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
   int32_t debug;          // SAG_DC_DEBUG bisect switches of k_doggo_physics (0 in normal use)
+  float* hot;             // split form: [N][HOT_FLOATS] env-major copy of what the busy prologue reads, or nullptr
   double* DR;             // Doggo, cooperative form: per-env result block of k_doggo_physics [N][DR_STRIDE]
                           // (k_step<DOGGO> with DR set skips the physics and reads it); else nullptr
 };
+// "Hot record": the 16 float4 a busy env's prologue needs (groups 0-4, the nine position groups, the int4
+// words and tstate), contiguous per env = two cache lines.  The busy kernel reads compacted, scattered
+// envs: from the group-major state that is one cache line per group (~16 per env); the hot record is
+// written by whichever kernel classifies an env busy for the next step (~10 % of the envs) and by
+// k_hot_refresh after an install.
+constexpr int HOT_GROUPS = 16, HOT_FLOATS = 4 * HOT_GROUPS;
 constexpr int DR_STRIDE = 20;  // qacc_lin 3, touch 8, comvel 4, cost_contacts, btn_mask, pad
 
 // ---- constants of the Point robot (assets/xmls/point.xml) -------------------
@@ -897,12 +904,25 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   // vector loads: one int4 and a handful of float4 per env (device layout: didx / iaddr)
   const float4* __restrict__ S4 = reinterpret_cast<const float4*>(S);
   auto G4 = [&](int g) { return S4[(size_t)g * N + i]; };
-  const int4 iw = reinterpret_cast<const int4*>(I + N)[i];
+  const bool use_hot = MODE == MODE_BUSY && p.hot != nullptr;
+  const float4* __restrict__ H4 = reinterpret_cast<const float4*>(p.hot) + (size_t)i * HOT_GROUPS;
+  // group g of this env: from the hot record (busy kernel; g < 14 covers 0-4 and the positions at
+  // 5 + (g - DG_POS)) or from the group-major state
+  auto GH = [&](int g, int hslot) { return use_hot ? H4[hslot] : G4(g); };
+  int4 iw;
+  uint32_t tstate;
+  if (use_hot) {
+    const float4 hi = H4[14], ht = H4[15];
+    iw = make_int4(__float_as_int(hi.x), __float_as_int(hi.y), __float_as_int(hi.z), __float_as_int(hi.w));
+    tstate = (uint32_t)__float_as_int(ht.x);
+  } else {
+    iw = reinterpret_cast<const int4*>(I + N)[i];
+    tstate = (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)];
+  }
   const uint32_t meta = (uint32_t)iw.x;
-  uint32_t tstate = (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)];
   int step = iw.y;
   const uint32_t env_id = (uint32_t)iw.z;
-  const float4 gA = G4(0), gB = G4(1), gC = G4(2), gD = G4(3);
+  const float4 gA = GH(0, 0), gB = GH(1, 1), gC = GH(2, 2), gD = GH(3, 3);
   BV R;
   R.x = gA.x; R.y = gA.y;
   float yaw = gA.z;
@@ -933,7 +953,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 #pragma unroll
     for (int g = 0; g < 9; g++) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < need) v = G4(DG_POS + g);
+      if (g < need) v = GH(DG_POS + g, 5 + g);
       vpos[4 * g] = v.x; vpos[4 * g + 1] = v.y; vpos[4 * g + 2] = v.z; vpos[4 * g + 3] = v.w;
     }
 #pragma unroll
@@ -947,7 +967,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   float stx[NSTAT], sty[NSTAT];
   {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (capP > 0) v = G4(DG_PILLARS);
+    if (capP > 0) v = GH(DG_PILLARS, 4);
     stx[0] = v.x; sty[0] = v.y; stx[1] = capP > 1 ? v.z : 0.f; sty[1] = capP > 1 ? v.w : 0.f;
     static_assert(SAG_MAX_PILLARS == 2, "pillars fill one group");
   }
@@ -1463,6 +1483,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   // ---- classification for the NEXT step (QUIET / BUSY split): busy unless provably nothing can
   //      touch the robot or move.  Reach of the robot within one step from the final state:
   //      |v| T + a_max T^2 (drive + contact-free dynamics only raise |v| by at most a_max T)
+  bool busy_next = false;
   if (!p.observe_only) {
     const float T = p.nstep_table * h;
     const float amax = CAR ? GRAV : 1.05f * gear * PT_FLIM / PT_MASS;
@@ -1488,6 +1509,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     const uint32_t nbit = TS_BUSY_BIT << (p.phase ^ 1);
     tstate = busy ? (tstate | nbit) : (tstate & ~nbit);
+    busy_next = busy;
     // next step's busy list, built here instead of by a separate compaction pass: one atomic per
     // wavefront claims a contiguous chunk (a chunk keeps the env neighbourhood of its wavefront)
     if (MODE != MODE_ALL && p.rows_next) {
@@ -1730,6 +1752,30 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
   }
   if (!p.observe_only && live) I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)] = (int32_t)tstate;
+  if constexpr (MODE != MODE_ALL && !DOGGO) {
+    // an env that will be busy next step leaves its hot record behind (positions still in LDS here:
+    // the observation staging below reuses the yaw rows)
+    if (p.hot && busy_next && live && !p.observe_only) {
+      float4* __restrict__ Hw = reinterpret_cast<float4*>(p.hot) + (size_t)i * HOT_GROUPS;
+      Hw[0] = make_float4(R.x, R.y, yaw, R.vx);
+      Hw[1] = make_float4(R.vy, R.w, bad ? gB.z : goalx, bad ? gB.w : goaly);
+      Hw[2] = make_float4(bad ? gC.x : last0, gC.y, gC.z, gC.w);
+      Hw[3] = gD;
+      Hw[4] = make_float4(stx[0], sty[0], stx[1], sty[1]);
+#pragma unroll
+      for (int g = 0; g < 9; g++) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int f = 4 * g + c, k = f / 3, comp = f % 3;   // float f of the position block = body k, x / y / yaw
+          v[c] = k < NBODY ? lds[((comp == 0 ? LS_X : (comp == 1 ? LS_Y : LS_YAW)) + k) * WAVE + lane] : 0.f;
+        }
+        Hw[5 + g] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      Hw[14] = make_float4(__int_as_float(iw.x), __int_as_float(step), __int_as_float(iw.z), __int_as_float(iw.w | flags));
+      Hw[15] = make_float4(__int_as_float((int)tstate), 0.f, 0.f, 0.f);
+    }
+  }
 
   // ---- cost (world.py:144-155): hazard test in fp32 unless within 1e-5 of the threshold,
   //      where the reference's fp64 expression decides -----------------------------------
@@ -1978,6 +2024,20 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs
   rows[lane] = i;
   __syncthreads();
   step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_BUSY>(p, lds, lane, i, live, 0, nval, 0ull, rows);
+}
+
+// hot records of every env from the group-major state (after an install: all envs start busy)
+__global__ __launch_bounds__(256) void k_hot_refresh(const float* __restrict__ S, const int32_t* __restrict__ I, int N,
+                                                      float* __restrict__ hot) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N) return;
+  const float4* S4 = reinterpret_cast<const float4*>(S);
+  float4* H = reinterpret_cast<float4*>(hot) + i * HOT_GROUPS;
+  for (int g = 0; g < 5; g++) H[g] = S4[(size_t)g * N + i];
+  for (int g = 0; g < 9; g++) H[5 + g] = S4[(size_t)(DG_POS + g) * N + i];
+  const int4 iw = reinterpret_cast<const int4*>(I + N)[i];
+  H[14] = make_float4(__int_as_float(iw.x), __int_as_float(iw.y), __int_as_float(iw.z), __int_as_float(iw.w));
+  H[15] = make_float4(__int_as_float(I[i]), 0.f, 0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------
