@@ -236,7 +236,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.has_box = c->cfg.has_box; a.G = c->G;
   a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
   a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr;
-  a.debug = 0; a.hot = nullptr;
+  a.debug = 0; a.hot = nullptr; a.hot_haz = nullptr;
   if (const char* e = getenv("SAG_DC_DEBUG")) a.debug = atoi(e);
   {
     // one Doggo wavefront per CU (its LDS working set): aim for one resident round over the chip
@@ -273,10 +273,10 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   if (split) {
     a.rows_next = c->d_rows + (size_t)(c->phase_used ^ 1) * c->N; a.count_next = c->d_count + (c->phase_used ^ 1);
     if (c->use_hot) {
-      if (!c->d_hot) HIPCHK(c, hipMalloc(&c->d_hot, (size_t)c->N * HOT_FLOATS * sizeof(float)));
-      a.hot = c->d_hot;
+      if (!c->d_hot) HIPCHK(c, hipMalloc(&c->d_hot, (size_t)c->N * (HOT_FLOATS + 20) * sizeof(float)));
+      a.hot = c->d_hot; a.hot_haz = c->d_hot + (size_t)c->N * HOT_FLOATS;
       if (!c->hot_valid) {
-        hipLaunchKernelGGL(k_hot_refresh, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N, c->d_hot);
+        hipLaunchKernelGGL(k_hot_refresh, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N, c->d_hot, c->d_hot + (size_t)c->N * HOT_FLOATS);
         c->hot_valid = true;
       }
     }

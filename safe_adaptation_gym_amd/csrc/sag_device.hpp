@@ -123,6 +123,7 @@ struct StepArgs {
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
   int32_t debug;          // SAG_DC_DEBUG bisect switches of k_doggo_physics (0 in normal use)
   float* hot;             // split form: [N][HOT_FLOATS] env-major copy of what the busy prologue reads, or nullptr
+  const float* hot_haz;   // [N][20]: the five hazard groups env-major (static: written by k_hot_refresh only)
   double* DR;             // Doggo, cooperative form: per-env result block of k_doggo_physics [N][DR_STRIDE]
                           // (k_step<DOGGO> with DR set skips the physics and reads it); else nullptr
 };
@@ -1533,7 +1534,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 #pragma unroll
     for (int g = 0; g < 5; g++) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g == 4 || 2 * g < capH) v = G4(DG_HAZ + g);
+      if (g == 4 || 2 * g < capH) v = use_hot ? reinterpret_cast<const float4*>(p.hot_haz)[(size_t)i * 5 + g] : G4(DG_HAZ + g);
       hz[4 * g] = v.x; hz[4 * g + 1] = v.y; hz[4 * g + 2] = v.z; hz[4 * g + 3] = v.w;
     }
     static_assert(SAG_MAX_HAZARDS == 9, "hazards + size fill five groups");
@@ -2028,7 +2029,7 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs
 
 // hot records of every env from the group-major state (after an install: all envs start busy)
 __global__ __launch_bounds__(256) void k_hot_refresh(const float* __restrict__ S, const int32_t* __restrict__ I, int N,
-                                                      float* __restrict__ hot) {
+                                                      float* __restrict__ hot, float* __restrict__ hot_haz) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)N) return;
   const float4* S4 = reinterpret_cast<const float4*>(S);
@@ -2038,6 +2039,8 @@ __global__ __launch_bounds__(256) void k_hot_refresh(const float* __restrict__ S
   const int4 iw = reinterpret_cast<const int4*>(I + N)[i];
   H[14] = make_float4(__int_as_float(iw.x), __int_as_float(iw.y), __int_as_float(iw.z), __int_as_float(iw.w));
   H[15] = make_float4(__int_as_float(I[i]), 0.f, 0.f, 0.f);
+  float4* Z = reinterpret_cast<float4*>(hot_haz) + i * 5;
+  for (int g = 0; g < 5; g++) Z[g] = S4[(size_t)(DG_HAZ + g) * N + i];
 }
 
 // ---------------------------------------------------------------------------
