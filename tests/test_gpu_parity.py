@@ -384,6 +384,17 @@ def test_split_launch_equals_single_launch(nat, monkeypatch, robot, task):
     sa, sb = ctxs[0].get_state(), ctxs[1].get_state()
     np.testing.assert_array_equal(sa[0], sb[0], err_msg=f'state step {t}')
     np.testing.assert_array_equal(sa[1], sb[1])
+    if t in (40, 41, 80):
+      # state installed from outside between steps (partial reset to the installed layout, then a
+      # set_state of a few envs): the busy lists and hot records of the split form must follow
+      ids = rng.choice(n, size=97, replace=False).astype(np.int32)
+      for c in ctxs:
+        c.reset(ids)
+      some = np.sort(rng.choice(n, size=33, replace=False)).astype(np.int32)
+      p_rf, p_ri = ctxs[0].get_state(some)
+      p_rf[:, 0] += 0.01
+      for c in ctxs:
+        c.set_state(p_rf, p_ri, some)
   assert outs[0][2].sum() > 0
   for c in ctxs:
     c.close()
