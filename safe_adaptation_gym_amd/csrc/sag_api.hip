@@ -236,8 +236,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.has_box = c->cfg.has_box; a.G = c->G;
   a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
   a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr;
-  a.debug = 0; a.hot = nullptr; a.hot_haz = nullptr;
-  if (const char* e = getenv("SAG_DC_DEBUG")) a.debug = atoi(e);
+  a.hot = nullptr; a.hot_haz = nullptr;
   {
     // one Doggo wavefront per CU (its LDS working set): aim for one resident round over the chip
     int epw = 64;

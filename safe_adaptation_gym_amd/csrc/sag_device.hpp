@@ -121,7 +121,6 @@ struct StepArgs {
   int32_t* count_next;    //   (nullptr: not built; the host then runs k_compact)
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
-  int32_t debug;          // SAG_DC_DEBUG bisect switches of k_doggo_physics (0 in normal use)
   float* hot;             // split form: [N][HOT_FLOATS] env-major copy of what the busy prologue reads, or nullptr
   const float* hot_haz;   // [N][20]: the five hazard groups env-major (static: written by k_hot_refresh only)
   double* DR;             // Doggo, cooperative form: per-env result block of k_doggo_physics [N][DR_STRIDE]

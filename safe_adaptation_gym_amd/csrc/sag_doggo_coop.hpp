@@ -658,9 +658,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
   }
   __syncthreads();
 
-  long long tk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0 = clock64();
-#define TK(k) do { const long long t_ = clock64(); tk[k] += t_ - t0; t0 = t_; } while (0)
-  const int nsub = p.observe_only ? 0 : ((p.debug & 32) ? 1 : p.nstep);
+  const int nsub = p.observe_only ? 0 : p.nstep;
   int cost_contacts = 0;
   uint32_t btn_mask = 0;
   double qacc_u = 0;
@@ -673,18 +671,13 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       E.wminv[BOX_ID][0] = c * c * ix + s * s * iy; E.wminv[BOX_ID][1] = c * s * (ix - iy);
       E.wminv[BOX_ID][3] = s * s * ix + c * c * iy;
     }
-    TK(9);
     dc_smooth(hf, u, ctrl_s[half]);
-    TK(0);
     if (u < 2)
       for (int j = 0; j < DG_NV; j++) E.Mlin[u][j] = j >= u ? E.M[u][j] : 0.0;
     __syncthreads();
     dc_cholesky(hf, u);
-    TK(1);
     qacc_u = dc_solve1(hf, u, u < DG_NV ? E.tau[u] : 0.0);
-    TK(2);
     dc_inverse(hf, u);
-    TK(3);
     if (u < 8) E.touch[u] = 0;
     int nrows = 0;
     // ---- rows: joint limits (lane j), in ascending joint order ---------------------------------
@@ -764,10 +757,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       }
     }
     __syncthreads();
-    TK(4);
     // ---- projected Gauss-Seidel: rows in sequence, the dot product J.qacc across the lanes ---
-    int nmax = DC_EPW == 2 ? max(nrows, __shfl(nrows, (lane + 32) & 63)) : nrows;   // both halves walk the longer list
-    if (p.debug & 1) nmax = 0;
+    const int nmax = DC_EPW == 2 ? max(nrows, __shfl(nrows, (lane + 32) & 63)) : nrows;   // both halves walk the longer list
 #pragma unroll 1
     for (int it = 0; it < DG_PGS_ITERS; it++)
 #pragma unroll 1
@@ -819,10 +810,9 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     }
     cost_contacts = cc; btn_mask = mask;
     __syncthreads();
-    TK(5);
     if (sub == nsub) break;
     // ---- planar world: body k on lane k vs the statics; pairs on lane 0; friction + integration --
-    if (u < NBODY && !(p.debug & 2)) {
+    if (u < NBODY) {
       const int k = u;
       const bool isb = k == BOX_ID;
       if (isb ? W.has_box : k < W.nV) {
@@ -849,7 +839,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       }
     }
     __syncthreads();
-    if (u == 0 && !(p.debug & 4)) {
+    if (u == 0) {
       for (int a = 0; a < W.nV; a++)
         for (int b = a + 1; b < NBODY; b++) {
           const bool isb = b == BOX_ID;
@@ -876,7 +866,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         }
     }
     __syncthreads();
-    if (u < NBODY && !(p.debug & 8)) {
+    if (u < NBODY) {
       const bool isb = u == BOX_ID;
       if (isb ? W.has_box : u < W.nV) {
         float B[9];
@@ -885,9 +875,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         for (int c = 0; c < 6; c++) E.wfb[u][c] = B[c];
       }
     }
-    TK(6);
     // ---- robot: semi-implicit Euler --------------------------------------------------------
-    if (u < DG_NV && !(p.debug & 16)) {
+    if (u < DG_NV) {
       const double v = E.qdv[u] + (double)h * qacc_u;
       if (u < 3) { E.vlin[u] = v; E.pos[u] += (double)h * v; }
       else if (u < 6) E.wloc[u - 3] = v;
@@ -910,10 +899,6 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     __syncthreads();
   }
 
-  TK(7);
-  if ((p.debug & 128) && lane == 0 && blockIdx.x == 0)
-    printf("ticks: smooth %lld chol %lld solve %lld inverse %lld rows %lld pgs %lld world %lld tail %lld head %lld\n", tk[0], tk[1], tk[2], tk[3], tk[4], tk[5], tk[6], tk[7], tk[9]);
-#undef TK
   // ---- results: per-env block for the post kernel, state back to HBM ---------------------------
   if (live) {
     double* dr = DR + gi * DR_STRIDE;
