@@ -238,10 +238,12 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr;
   a.hot = nullptr; a.hot_haz = nullptr;
   {
-    // one Doggo wavefront per CU (its LDS working set): aim for one resident round over the chip
+    // single-launch form: aim for four wavefronts per CU (Doggo: one - only one fits its LDS working
+    // set), down to 16 (Doggo 8) envs per wavefront (tools/epw_sweep.py: Car 4096 envs 0.58 -> 0.48 ms)
+    const bool dg = c->cfg.robot == SAG_ROBOT_DOGGO;
     int epw = 64;
-    while (epw > 8 && (c->N + epw - 1) / epw < c->n_cu) epw >>= 1;
-    if (const char* e = getenv("SAG_DOGGO_EPW")) epw = atoi(e);
+    while (epw > (dg ? 8 : 16) && (c->N + epw - 1) / epw < (dg ? 1 : 4) * c->n_cu) epw >>= 1;
+    if (const char* e = getenv("SAG_EPW")) epw = atoi(e);
     a.envs_per_wave = epw < 1 ? 1 : (epw > 64 ? 64 : epw);
   }
   c->phase_used = c->phase;
@@ -299,7 +301,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
       hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3((c->N + SAG_BUSY_ENVS - 1) / SAG_BUSY_ENVS), dim3(WAVE), 0, c->stream, a); \
       hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, quiet_stream, a);    \
     } else {                                                                                            \
-      hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, c->stream, a);             \
+      hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave), dim3(WAVE), 0, c->stream, a); \
     }                                                                                                   \
   } while (0)
 #define SAG_LAUNCH(ROB)                            \

@@ -94,7 +94,7 @@ __host__ __device__ inline void unpack_tstate(uint32_t t, int32_t* ri) {
 }
 
 struct StepArgs {
-  int envs_per_wave;  // Doggo only (k_step<DOGGO>): 8..64
+  int envs_per_wave;  // single-launch form (k_step): 8..64 envs per wavefront, by batch size
   float* S;          // [DEV_GROUPS][N] float4 (see didx)
   int32_t* I;        // tstate [N], then (meta, step, envid, flags) [N] int4 (see iaddr)
   int32_t N;
@@ -1097,7 +1097,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   };
 
   // ---- physics: nstep x (forward, integrate) + one forward at the final state ---
-  const int nsub = p.observe_only ? 0 : (ABL(ABL_NSUB1) ? 1 : p.nstep);
+  // padding lanes (they mirror another env so that loads stay in bounds) run no physics at all: they
+  // would widen the divergence union and, when the dynamic pool overflows, race on that env's state
+  const int nsub = !live ? -1 : (p.observe_only ? 0 : (ABL(ABL_NSUB1) ? 1 : p.nstep));
   // statics occupy [0, capP) and [SAG_MAX_PILLARS, SAG_MAX_PILLARS + capB) of stx/sty
   const int n_static = capB ? SAG_MAX_PILLARS + capB : capP;
   const uint32_t fmask = ((1u << nV) - 1) | (has_box ? 1u << BOX_ID : 0u);
@@ -1933,9 +1935,9 @@ __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_DOGGO ? 1 : SAG_STEP_MIN_W
   __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
   // Doggo: the Cholesky factor of the mass matrix, [190][64 lanes] fp64 = 95 KB (one wavefront per CU)
   __shared__ double dgL[ROBOT == SAG_ROBOT_DOGGO ? (DG_NTRI + 4 * DG_NV) * WAVE : 1];  // + 3 solve vectors, 1 / diagonal
-  // Doggo batches are small and its wavefronts long: fewer envs per wavefront (p.envs_per_wave)
-  // spread a batch over more CUs and shrink the divergence union; the idle lanes just mirror env N-1
-  const int epw = ROBOT == SAG_ROBOT_DOGGO ? p.envs_per_wave : WAVE;
+  // small batches (and Doggo, whose wavefronts are long): fewer envs per wavefront (p.envs_per_wave)
+  // spread the batch over more CUs and shrink the divergence union; the idle lanes just mirror env N-1
+  const int epw = p.envs_per_wave;   // 64 unless the batch is too small to give every CU a wavefront
   const int lane = threadIdx.x, base = blockIdx.x * epw, gi = base + lane;
   const bool live = gi < p.N && lane < epw;
   step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_ALL>(p, lds, lane, live ? gi : p.N - 1, live, base,
