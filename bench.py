@@ -287,7 +287,7 @@ def main(argv=None, run_factory=None, emit=print):
           'unit': 'env-steps/s',
           'ms_per_step': t / max(args.steps, 200) * 1e3,
           'kernel_ms': ms,
-          'note': 'BASELINE config-2 batch size (4096 envs on one GPU): launch/latency bound, 64 wavefronts'
+          'note': 'BASELINE config-2 batch size (4096 envs on one GPU): latency bound, 16 envs per wavefront x 256 wavefronts'
       }
       c2.close()
     if not args.no_c2:
