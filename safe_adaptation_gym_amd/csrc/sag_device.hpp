@@ -1811,6 +1811,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     // row of staging slot e: contiguous slice (ALL / QUIET) or the compacted list (BUSY);
     // slots of envs this launch does not own are skipped
     auto row_ok = [&](int e) { return e < nvalid && !(skip_mask >> e & 1ull); };
+    const bool obs_vec = (reinterpret_cast<uintptr_t>(o) & 15) == 0;   // (else: the caller's buffer is not 16-B aligned)
+    static_assert(OBS_DIM % 4 == 0 && NSENS % 4 == 0, "observation rows and chunks are whole float4s");
     auto row_of = [&](int e) { return (size_t)(MODE == MODE_BUSY ? rows[e] : base_env + e); };
     auto lid = [&](float px, float py) {
       if constexpr (DOGGO) lidar_point_tilted<STG_STRIDE>(lds, lane, dgs.pos, dg_rot, px, py);
@@ -1891,7 +1893,23 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       }
       __syncthreads();
       CYC(CY_LIDAR);
-      if (chunk < 3) {
+      if (obs_vec) {
+        // 16 B per lane per store: a quarter of the store instructions of the dword form (rows are 240 /
+        // 288 / 416 B and chunks 64 B or NSENS floats: every piece starts on a 16-B boundary)
+        constexpr int Q = OBS_DIM / 4;
+        const int nq = chunk < 3 ? 4 : NSENS / 4, q0 = chunk < 3 ? 4 * chunk : 12 + (chunk - 3) * (NSENS / 4);
+        float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
+#pragma unroll 1
+        for (int j = 0; j < nq; j++) {
+          const int e = j * WAVE + lane;
+          const int env = nq == 4 ? e >> 2 : (nq == 3 ? (int)(((uint32_t)e * 21846u) >> 16) : (nq == 6 ? (int)(((uint32_t)e * 10923u) >> 16)
+                                                                                                    : (int)(((uint32_t)e * 9363u) >> 16)));
+          const int c4 = e - env * nq;   // e / nq exact for e < 64 nq (nq = 3, 4, 6, 7)
+          const float* t = lds + STG_BASE + env * STG_STRIDE + 4 * c4;
+          const float4 v = make_float4(t[0], t[1], t[2], t[3]);
+          if (row_ok(env) && !ABL(ABL_NO_OBS_STORE)) o4[row_of(env) * Q + q0 + c4] = v;
+        }
+      } else if (chunk < 3) {
 #pragma unroll 4
         for (int j = 0; j < 16; j++) {
           const int e = j * WAVE + lane, env = e >> 4, col = e & 15;
