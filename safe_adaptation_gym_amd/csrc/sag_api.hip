@@ -55,6 +55,8 @@ struct sag_ctx {
   // list[phase] from the busy bits whenever state was installed from outside (list_valid = false)
   int32_t* d_rows = nullptr; int32_t* d_count = nullptr;
   bool list_valid = false;
+  int count_flip = 0;          // which of d_count[2], d_count[3] this step's compaction fills
+  int32_t* last_count = nullptr;
   float* d_hot = nullptr;     // [N][HOT_FLOATS] hot records (split form), see sag_device.hpp
   bool hot_valid = false, use_hot = true;   // SAG_HOT=0 disables
   // SAG_INKERNEL_LIST=1: the step kernels append the next busy list themselves and k_compact only runs
@@ -283,11 +285,18 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     }
     if (!c->inkernel_list) { a.rows_next = nullptr; a.count_next = nullptr; c->list_valid = false; }
     else HIPCHK(c, hipMemsetAsync(a.count_next, 0, sizeof(int32_t), c->stream));
-    if (!c->list_valid) {
+    if (!c->inkernel_list) {
+      // two counters used alternately: this step's compaction zeroes the one the next step will use
+      a.count = c->d_count + 2 + c->count_flip;
+      hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
+                         a.rows, a.count, c->d_count + 2 + (c->count_flip ^ 1));
+      c->count_flip ^= 1;
+    } else if (!c->list_valid) {
       HIPCHK(c, hipMemsetAsync(a.count, 0, sizeof(int32_t), c->stream));
       hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
-                         a.rows, a.count);
+                         a.rows, a.count, (int32_t*)nullptr);
     }
+    c->last_count = a.count;
     c->list_valid = true;
     if (c->overlap) {
       HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
@@ -409,6 +418,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->d_rows, 2 * N * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->d_count, 4 * sizeof(int32_t)));
+  CREATE_CHK(hipMemset(c->d_count, 0, 4 * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->L_f, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->L_i, N * SAG_REC_INTS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->st_f, N * SAG_REC_FLOATS * sizeof(float)));
@@ -774,7 +784,8 @@ int sag_busy_count(sag_ctx* c, int32_t* count) {
   if (!c || !count) return SAG_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(count, c->d_count + (c->phase ^ 1), sizeof(int32_t), hipMemcpyDeviceToHost));  // the list the last step consumed
+  if (!c->last_count) { *count = 0; return SAG_OK; }
+  HIPCHK(c, hipMemcpy(count, c->last_count, sizeof(int32_t), hipMemcpyDeviceToHost));  // the list the last step consumed
   return SAG_OK;
 }
 

@@ -1995,7 +1995,10 @@ __global__ __launch_bounds__(WAVE, SAG_QUIET_MIN_WAVES) void k_step_quiet(StepAr
 // busy envs -> dense list.  Each 256-thread block covers 1024 envs, orders its own busy ones by
 // index (ballot + prefix) and claims a contiguous segment with one atomic; segments of different
 // blocks land in arbitrary order, which only affects which wavefront processes an env.
-__global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int phase, int32_t* rows, int32_t* count) {
+__global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int phase, int32_t* rows, int32_t* count,
+                                                  int32_t* zero_for_next) {
+  // the counter the NEXT step's compaction will add to (saves a memset launch per step)
+  if (zero_for_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_for_next = 0;
   __shared__ int wave_tot[4][4];
   __shared__ int seg_base;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
