@@ -203,6 +203,16 @@ struct Rng {
   __device__ double uniform(double lo, double hi) { return lo + (hi - lo) * sample(); }
 };
 
+// two standard normals from two random words (throughput mode's action noise; the oracle's
+// sago_noise is the same transform in libm arithmetic).  Hardware log2 / sin / cos (1 ulp-class, the
+// trigonometric ones take revolutions): the draws are noise, nothing discrete depends on their last bits.
+__device__ inline void box_muller(uint32_t w0, uint32_t w1, float& z0, float& z1) {
+  const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float u2 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));  // -2 ln u1
+  z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
+}
+
 // ---- lidar (fp64, the reference's arithmetic) -------------------------------
 __device__ inline int lidar_accum(double ex, double ey, double* obs) {
   const double two_pi = PI_D * 2;
@@ -537,8 +547,8 @@ struct BodyK { int sh; float m, I, reff; };
 // bin boundary, so the bin index is always the fp64 one.
 struct LidarHit { int bin; float alias, sensor; };
 
-__device__ __attribute__((noinline)) LidarHit lidar_exact(double rx, double ry, double cd, double sd,
-                                                           float px, float py) {
+__device__ __attribute__((noinline)) LidarHit lidar_exact(float rxf, float ryf, float yawf, float px, float py) {
+  const double rx = rxf, ry = ryf, cd = cos((double)yawf), sd = sin((double)yawf);
   const double W0 = (double)px - rx, W1 = (double)py - ry;
   const double EX = W0 * cd + W1 * sd, EY = W0 * -sd + W1 * cd;
   const double two_pi = PI_D * 2, bin_size = two_pi / SAG_LIDAR_BINS;
@@ -553,20 +563,44 @@ __device__ __attribute__((noinline)) LidarHit lidar_exact(double rx, double ry, 
   return h;
 }
 
+// angle of (ex, ey) in lidar bins, [0, 16]: octant reduction + odd minimax polynomial for
+// atan(q) 8/pi on [0, 1] (|error| < 1e-6 bins in fp32 arithmetic, tools/fit_atan_bins.py); a quarter
+// of the instructions of atan2f, whose special cases (inf, nan, signed zeros) cannot occur or
+// are sent to the fp64 evaluation by the caller (0/0 -> NaN fails the caller's band test)
+__device__ inline float angle_bins(float ex, float ey) {
+  const float ax = fabsf(ex), ay = fabsf(ey);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float q = mn * __builtin_amdgcn_rcpf(mx), z = q * q;
+  float t = -1.017929272e-02f;
+  t = t * z + 5.515013699e-02f;
+  t = t * z + -1.416326720e-01f;
+  t = t * z + 2.449992122e-01f;
+  t = t * z + -3.539759922e-01f;
+  t = t * z + 5.078958901e-01f;
+  t = t * z + -8.487346847e-01f;
+  t = t * z + 2.546477322e+00f;
+  t *= q;
+  if (ay > ax) t = 4.0f - t;
+  if (ex < 0) t = 8.0f - t;
+  if (ey < 0) t = 16.0f - t;
+  return t;
+}
+
 template <int STG_STRIDE>
-__device__ inline void lidar_point(float* lds, int lane, double rx, double ry, double cd, double sd,
-                                   float rxf, float ryf, float cf, float sf, float px, float py) {
+__device__ inline void lidar_point(float* lds, int lane, float rxf, float ryf, float yawf, float cf, float sf,
+                                   float px, float py) {
   const float w0 = px - rxf, w1 = py - ryf;
   const float ex = w0 * cf + w1 * sf, ey = w1 * cf - w0 * sf;
-  const float dist = sqrtf(ex * ex + ey * ey);
-  float ang = atan2f(ey, ex);
-  if (ang < 0) ang += 6.28318530717958647692f;
-  float t = ang * (16.0f / 6.28318530717958647692f);
+  const float dist = __builtin_amdgcn_sqrtf(ex * ex + ey * ey);   // 1 ulp: feeds the closeness value only
+  const float t = angle_bins(ex, ey);
   int bin = (int)t;
   float alias = t - (float)bin;
   float sensor = fmaxf(5.0f - dist, 0.0f) * 0.2f;
-  if (alias < 2e-5f || alias > 1.0f - 2e-5f || bin > 15) {
-    const LidarHit h = lidar_exact(rx, ry, cd, sd, px, py);
+  // the fp32 estimate is off by < 4e-6 bins + 1e-6 / dist (rounding of the relative position);
+  // inside that band of a bin boundary (or NaN: the point is the robot's own position) fp64 decides
+  const float edge = fminf(alias, 1.0f - alias);
+  if (!(edge * dist >= 2e-5f * dist + 1.5e-6f) || bin > 15) {
+    const LidarHit h = lidar_exact(rxf, ryf, yawf, px, py);
     bin = h.bin; alias = h.alias; sensor = h.sensor;
   }
   const int bp = (bin + 1) & 15, bm = (bin + 15) & 15;
@@ -1009,10 +1043,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         else {
           uint32_t c[4] = {rng.env, rng.step, (uint32_t)(j >> 1), 1u};
           philox4x32_10(c, p.key0, p.key1);
-          const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-          const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-          const float r = sqrtf(-2.0f * logf(u1)), a = 6.28318530717958647692f * u2;
-          z0 = r * cosf(a); z1 = r * sinf(a);
+          box_muller(c[0], c[1], z0, z1);
         }
         const float l0 = SF(SAG_F_CTRL_SCALE + j), l1 = SF(SAG_F_CTRL_SCALE + j + 1);
         ctrl12[j] = clampf(p.actions[(size_t)i * 12 + j] + an * z0, -l0, l0);
@@ -1024,10 +1055,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     if (!p.noise && !DOGGO) {
       uint32_t c[4] = {rng.env, rng.step, 0u, 1u};
       philox4x32_10(c, p.key0, p.key1);
-      float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      float r = sqrtf(-2.0f * logf(u1)), a = 6.28318530717958647692f * u2;
-      n0 = r * cosf(a); n1 = r * sinf(a);
+      box_muller(c[0], c[1], n0, n1);
     }
     const float an = gC.w;
     const float cs0 = gD.x, cs1 = gD.y;
@@ -1803,8 +1831,10 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   //      [obstacles 16 | objects 16 | goal 16 | sensors 12], each staged in LDS [lane][17]
   //      and written back transposed -------------------------------------------------------
   if (p.obs) {
-    const double cd = cos((double)yaw), sd = sin((double)yaw);
-    const float cf = (float)cd, sf = (float)sd;
+    // cos / sin of the final yaw: the last pass of the substep loop (the forward evaluation at the
+    // final state) has them already; Doggo's lidar uses the base rotation matrix instead
+    float cf = cy, sf = sy;
+    if constexpr (DOGGO) sincosf(yaw, &sf, &cf);
     const int gb = tstate & 7, bstate = tstate >> 3 & 1;
     const uint32_t act = tstate >> 11 & 63;
     float* __restrict__ o = p.obs;
@@ -1816,7 +1846,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     auto row_of = [&](int e) { return (size_t)(MODE == MODE_BUSY ? rows[e] : base_env + e); };
     auto lid = [&](float px, float py) {
       if constexpr (DOGGO) lidar_point_tilted<STG_STRIDE>(lds, lane, dgs.pos, dg_rot, px, py);
-      else lidar_point<STG_STRIDE>(lds, lane, rx, ry, cd, sd, R.x, R.y, cf, sf, px, py);
+      else lidar_point<STG_STRIDE>(lds, lane, R.x, R.y, yaw, cf, sf, px, py);
     };
     // Doggo sensors (doggo.xml:83-126 via safe_adaptation_gym.py:225-237): accelerometer, velocimeter,
     // gyro, magnetometer, 8 touch, 12 joint rates, 12 x (sin, cos)
@@ -2031,6 +2061,9 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int ph
   }
 }
 
+#ifndef SAG_BUSY_PRIO
+#define SAG_BUSY_PRIO 0
+#endif
 #ifndef SAG_BUSY_ENVS
 #define SAG_BUSY_ENVS 64  // envs per busy wavefront
 #endif
@@ -2038,6 +2071,11 @@ template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
   __shared__ float lds[LDS_FLOATS];
   __shared__ int rows[WAVE];
+#if SAG_BUSY_PRIO
+  // the few long wavefronts of this kernel set the length of a step: they issue ahead of the quiet
+  // kernel's wavefronts that share their SIMDs
+  __builtin_amdgcn_s_setprio(SAG_BUSY_PRIO);
+#endif
   const int lane = threadIdx.x, c0 = blockIdx.x * SAG_BUSY_ENVS;
   const int count = *p.count;
   if (c0 >= count) return;

@@ -646,10 +646,9 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         const uint32_t env_id = (uint32_t)p.I[iaddr(DI_ENVID, N, i)], step = (uint32_t)p.I[iaddr(DI_STEP, N, i)];
         uint32_t cc[4] = {env_id, step, (uint32_t)(u >> 1), 1u};
         philox4x32_10(cc, p.key0, p.key1);
-        const float u1 = ((float)(cc[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float u2 = ((float)(cc[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        const float r = sqrtf(-2.0f * logf(u1)), a = 6.28318530717958647692f * u2;
-        z = (u & 1) ? r * sinf(a) : r * cosf(a);
+        float z0, z1;
+        box_muller(cc[0], cc[1], z0, z1);
+        z = (u & 1) ? z1 : z0;
       }
       const float an = S[saddr(SAG_F_ACTION_NOISE, N, i)], lim = S[saddr(SAG_F_CTRL_SCALE + u, N, i)];
       c = clampf(p.actions[i * 12 + u] + an * z, -lim, lim);

@@ -72,12 +72,20 @@ class BatchedSafeAdaptationGym:
     self._episode = 0
     self._base_seed = int(np.random.randint(2**31))
     self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
-    self.rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
+    self._rs = None
     self.action_space = Box(-1, 1, (self.robot.nu,), np.float32)
     self._observation_space = None
     self._reward_dim = 1
 
   # -- reference surface ----------------------------------------------------------
+  @property
+  def rs(self):
+    """Per-env host generators (safe_adaptation_gym.py:33,113-118).  Only parity mode draws from
+    them, so they are built on first use (a RandomState costs ~0.1 ms: 100 s per million envs)."""
+    if self._rs is None:
+      self._rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
+    return self._rs
+
   @property
   def observation_space(self):
     if self._observation_space is None and self._rgb_observation:
@@ -95,7 +103,7 @@ class BatchedSafeAdaptationGym:
     safe_adaptation_gym.py:113-118)."""
     self._base_seed = int(np.random.randint(2**31)) if seed is None else int(seed)
     self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
-    self.rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
+    self._rs = None
 
   def set_task(self, task):
     """A Task instance / class (every env gets its own instance of that class) or a
@@ -116,7 +124,7 @@ class BatchedSafeAdaptationGym:
       # the reference's single env moves to seed + 1 (safe_adaptation_gym.py:97-101);
       # a batch moves every env past the whole batch so episodes never share a seed.
       self._seeds = self._seeds + self.n_envs
-    self.rs = [np.random.RandomState(int(s) % 2**32) for s in self._seeds]
+    self._rs = None
     if options is not None and 'task' in options:
       self.set_task(options['task'])
       return self._observe()
@@ -191,9 +199,10 @@ class BatchedSafeAdaptationGym:
   def _build_world(self, first_episode):
     """World.sample_layout + World.reset for every env (safe_adaptation_gym.py:170-172) on the
     native sampler: env i draws from RandomState(seed_i) in the reference's order."""
-    rf, ri, status, states = nat.sample_layouts(self.robot.name, self._seeds, self._task_ids,
-                                                config=self.base_config, first_episode=first_episode,
-                                                want_rng=True)
+    out = nat.sample_layouts(self.robot.name, self._seeds, self._task_ids, config=self.base_config,
+                             first_episode=first_episode, want_rng=self.parity_rng)
+    rf, ri, status = out[:3]
+    states = out[3] if self.parity_rng else None
     if status.any():
       bad = np.flatnonzero(status)
       raise ResamplingError(f'Failed to generate layout for envs {bad[:8].tolist()} (seeds '

@@ -1,0 +1,49 @@
+"""CPU: coefficients of angle_bins() in csrc/sag_device.hpp - odd minimax polynomial for
+atan(q) * 8/pi on [0, 1] (Lawson iteration) and its error when evaluated in fp32 as the kernel does."""
+import numpy as np
+
+
+def fit(nterms):
+  q = np.sort(np.cos(np.linspace(0, np.pi / 2, 40001)))
+  q = q[q > 0]
+  z = q * q
+  A = np.stack([z**k for k in range(nterms)], 1)
+  y = np.arctan(q) / q * (8 / np.pi)
+  w = np.ones_like(q)
+  for _ in range(400):
+    c = np.linalg.lstsq(A * w[:, None], y * w, rcond=None)[0]
+    e = np.abs(A @ c - y) * q
+    w = w * (e / e.max() + 1e-3)
+    w /= w.max()
+  return c, e.max()
+
+
+def angle_bins_f32(ex, ey, c):
+  f = np.float32
+  c = c.astype(f)
+  ax, ay = np.abs(ex), np.abs(ey)
+  mx, mn = np.maximum(ax, ay), np.minimum(ax, ay)
+  q = (mn * (f(1) / mx).astype(f)).astype(f)
+  z = (q * q).astype(f)
+  t = np.full(len(ex), c[-1], f)
+  for k in range(len(c) - 2, -1, -1):
+    t = ((t * z).astype(f) + c[k]).astype(f)
+  t = (t * q).astype(f)
+  t = np.where(ay > ax, (f(4) - t).astype(f), t)
+  t = np.where(ex < 0, (f(8) - t).astype(f), t)
+  return np.where(ey < 0, (f(16) - t).astype(f), t)
+
+
+if __name__ == '__main__':
+  c, e = fit(8)
+  print('polynomial error (bins):', e)
+  print(', '.join('%.9ef' % x for x in c))
+  rng = np.random.RandomState(1)
+  n = 4_000_000
+  ex = rng.uniform(-4, 4, n).astype(np.float32)
+  ey = rng.uniform(-4, 4, n).astype(np.float32)
+  ex[:100000] *= np.float32(1e-4)
+  ey[100000:200000] *= np.float32(1e-4)
+  a = np.arctan2(ey.astype(np.float64), ex.astype(np.float64))
+  a = np.where(a < 0, a + 2 * np.pi, a)
+  print('fp32 evaluation, max error (bins):', np.abs(angle_bins_f32(ex, ey, c) - a * 16 / (2 * np.pi)).max())
