@@ -46,6 +46,13 @@ struct sag_ctx {
   // the quiet kernel (many short memory-bound ones); fork/join events order them against the main stream
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // Side by side with the busy kernel the quiet kernel requests this much unused LDS on top of its own
+  // 10 KB: a quiet wavefront then frees at least what a busy one needs (13 KB), so a waiting busy
+  // workgroup (higher stream priority) fits into any hole a quiet one leaves.  With 10-KB holes the busy
+  // kernel, which sets the length of a step, is starved of LDS by the far more numerous quiet
+  // workgroups once the batch exceeds what is resident at once (measured at 4 M envs: +8 % throughput,
+  // tools/abab_env.sh; SAG_QUIET_LDS_EXTRA overrides, bytes; < 0 = busy kernel's footprint minus the quiet one's).
+  int quiet_lds_extra = -1;
   bool overlap = true;  // SAG_OVERLAP=0: both kernels on the main stream, one after the other
   float* S = nullptr;
   int32_t* I = nullptr;
@@ -304,11 +311,19 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
       quiet_stream = c->stream2;
     }
   }
+  // LDS the quiet kernel asks for beyond what it uses (see sag_ctx::quiet_lds_extra)
+  size_t quiet_lds_extra = 0;
+  if (split && c->overlap) {
+    const int quiet_own = (LS_YAW + (c->cfg.robot == SAG_ROBOT_CAR ? 25 : 17)) * WAVE * (int)sizeof(float);
+    const int busy_own = LDS_FLOATS * (int)sizeof(float) + WAVE * (int)sizeof(int);
+    const int want = c->quiet_lds_extra >= 0 ? c->quiet_lds_extra : (busy_own > quiet_own ? (busy_own - quiet_own + 511) / 512 * 512 : 0);
+    quiet_lds_extra = (size_t)want;
+  }
 #define SAG_LAUNCH3(ROB, B_, X_)                                                                         \
   do {                                                                                                  \
     if (split) {                                                                                        \
       hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3((c->N + SAG_BUSY_ENVS - 1) / SAG_BUSY_ENVS), dim3(WAVE), 0, c->stream, a); \
-      hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), 0, quiet_stream, a);    \
+      hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), quiet_lds_extra, quiet_stream, a); \
     } else {                                                                                            \
       hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave), dim3(WAVE), 0, c->stream, a); \
     }                                                                                                   \
@@ -405,6 +420,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("SAG_OVERLAP")) c->overlap = atoi(e) != 0;
+  if (const char* e = getenv("SAG_QUIET_LDS_EXTRA")) c->quiet_lds_extra = atoi(e) > 65536 ? 65536 : atoi(e);
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
   if (const char* e = getenv("SAG_HOT")) c->use_hot = atoi(e) != 0;
   c->doggo_coop = cfg->robot == SAG_ROBOT_DOGGO && cfg->n_envs <= 12288;

@@ -1023,6 +1023,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   const int task = meta & 15, nH = meta >> 4 & 15, nV = meta >> 8 & 15, nP = meta >> 12 & 3,
             nB = HAS_BTN ? (meta >> 14 & 7) : 0, box_kind = HAS_TBOX ? (meta >> 17 & 3) : 0;
   const bool has_box = HAS_TBOX && box_kind != SAG_BOX_NONE;
+  // body index k is the task object: never, at compile time, in an instance without one, so the shape
+  // switches, geom loops and mass selects of the contact code fold to the vase case there
+  auto is_box = [](int k) { return HAS_TBOX && k == BOX_ID; };
   int flags = 0;
 
   Rng rng;
@@ -1113,7 +1116,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     dy.get(k, V.vx, V.vy, V.w, V.ax, V.ay, V.aw);
     sincosf(LP(LS_YAW, k), &s, &c);
     V.dyn = 1; V.m1 = 0; V.m2 = 0; V.m4 = 0;
-    if (k != BOX_ID) { V.m0 = V.m3 = 1.0f / vk.m; V.m5 = 1.0f / vk.I; }
+    if (!is_box(k)) { V.m0 = V.m3 = 1.0f / vk.m; V.m5 = 1.0f / vk.I; }
     else {
       V.m5 = 1.0f / bk.I;
       if (bk.sh == SH_ROD) {  // rolls along local x (1.5 m), slides along its axis (m)
@@ -1307,7 +1310,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     if (ABL(ABL_NO_RV)) hits = 0;
     for (uint32_t m = hits; m; m &= m - 1) {
       const int k = __ffs(m) - 1;
-      const bool isb = k == BOX_ID;
+      const bool isb = is_box(k);
       dy.ensure(k, false);
       BV V; float cv, sv; load_body(dy, k, V, cv, sv);
       const float ax0 = V.ax, ay0 = V.ay, aw0 = V.aw;
@@ -1344,7 +1347,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       // free bodies vs static circles (pillars then buttons), per active body
       for (uint32_t m = active; m; m &= m - 1) {
         const int k = __ffs(m) - 1;
-        const bool isb = k == BOX_ID;
+        const bool isb = is_box(k);
         const float bx_ = LP(LS_X, k), by_ = LP(LS_Y, k), br = isb ? box_r : vase_r;
         uint32_t shit = 0;
 #pragma unroll 1
@@ -1381,9 +1384,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (!ABL(ABL_NO_VV)) {
         for (uint32_t m = active; m; m &= m - 1) {
           const int k = __ffs(m) - 1;
-          const float kx = LP(LS_X, k), ky = LP(LS_Y, k), kr = k == BOX_ID ? box_r : vase_r;
+          const float kx = LP(LS_X, k), ky = LP(LS_Y, k), kr = is_box(k) ? box_r : vase_r;
 #pragma unroll
-          for (int j = 0; j < NBODY; j++) {
+          for (int j = 0; j < (HAS_TBOX ? NBODY : SAG_MAX_VASES); j++) {
             const float dx = LP(LS_X, j) - kx, dyy = LP(LS_Y, j) - ky, rs = kr + (j == BOX_ID ? box_r : vase_r);
             if ((fmask >> j & 1u) && j != k && dx * dx + dyy * dyy <= rs * rs) {
               const int lo = min(j, k), hi = max(j, k);
@@ -1397,7 +1400,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         int idx = __ffsll((unsigned long long)m) - 1, a = 0;
         while (idx >= NBODY - 1 - a) { idx -= NBODY - 1 - a; a++; }
         const int b = a + 1 + idx;
-        const bool isb = b == BOX_ID;
+        const bool isb = is_box(b);
         dy.ensure(a, false); dy.ensure(b, false);
         BV A, B; float ca, sa, cb, sb;
         load_body(dy, a, A, ca, sa);
@@ -1416,8 +1419,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         float vx_, vy_, w_, ax_, ay_, aw_;
         dy.get(k, vx_, vy_, w_, ax_, ay_, aw_);
         const float bc = sol0.bcoef;
-        if (k != BOX_ID || bk.sh == SH_BOX) {
-          const float mm = k != BOX_ID ? vk.m : bk.m, II = k != BOX_ID ? vk.I : bk.I, rr = k != BOX_ID ? vk.reff : bk.reff;
+        if (!is_box(k) || bk.sh == SH_BOX) {
+          const float mm = !is_box(k) ? vk.m : bk.m, II = !is_box(k) ? vk.I : bk.I, rr = !is_box(k) ? vk.reff : bk.reff;
           const float fmax_ = MU * GRAV * mm;
           float fx = -SOL_D0 * mm * (bc * vx_ + ax_), fy = -SOL_D0 * mm * (bc * vy_ + ay_);
           const float f2 = fx * fx + fy * fy;
@@ -2011,7 +2014,10 @@ __global__ __launch_bounds__(WAVE, SAG_QUIET_MIN_WAVES) void k_step_quiet(StepAr
   // 10 KB (Point) -> 16 wavefronts per CU
   constexpr int QSLOTS = LS_YAW + (ROBOT == SAG_ROBOT_CAR ? 25 : 17);
   static_assert(QSLOTS >= LS_YAW + NBODY, "the yaw rows written at load time must stay in bounds");
-  __shared__ float lds[QSLOTS * WAVE];
+#ifndef SAG_QUIET_LDS_PAD
+#define SAG_QUIET_LDS_PAD 0
+#endif
+  __shared__ float lds[QSLOTS * WAVE + SAG_QUIET_LDS_PAD];  // PAD: occupancy probe
   const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
   const bool in = gi < p.N;
   const bool busy = in && ((uint32_t)p.I[iaddr(DI_TSTATE, (size_t)p.N, (size_t)gi)] & (TS_BUSY_BIT << p.phase));
@@ -2069,7 +2075,10 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int ph
 #endif
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
-  __shared__ float lds[LDS_FLOATS];
+#ifndef SAG_BUSY_LDS_PAD
+#define SAG_BUSY_LDS_PAD 0
+#endif
+  __shared__ float lds[LDS_FLOATS + SAG_BUSY_LDS_PAD];  // PAD: occupancy probe
   __shared__ int rows[WAVE];
 #if SAG_BUSY_PRIO
   // the few long wavefronts of this kernel set the length of a step: they issue ahead of the quiet

@@ -3,7 +3,7 @@
 for v in "" "$@"; do
   lib=safe_adaptation_gym_amd/libsag${v:+_$v}.so
   echo "== ${v:-default}"
-  SAG_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-c2 2>&1 | python -c "
+  SAG_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-c2 ${BENCH_ARGS} 2>&1 | python -c "
 import sys,json
 for l in sys.stdin:
   try: r=json.loads(l)

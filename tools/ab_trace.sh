@@ -9,7 +9,7 @@ import csv,glob,sys
 f=glob.glob('/tmp/abt/**/*kernel_trace.csv',recursive=True)
 rows=list(csv.DictReader(open(f[0])))
 out=[]
-for key in ('quiet','busy','compact','k_step<'):
+for key in ('quiet','busy','phys','post','compact','k_step<'):
     q=[int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in rows if key in r['Kernel_Name']]
     if q: out.append('%s %.1f us' % (key, sum(q[-20:])/20/1e3))
 print('%-10s' % (sys.argv[1] or 'default'), ' | '.join(out))

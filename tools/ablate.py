@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import bench
 from safe_adaptation_gym_amd import _native as nat
-N = 1 << 19
+N = 1 << 20
 snap = '/tmp/sag_snap.npz'  # large: keep it out of gpurun_out (64 MiB merge limit)
 if sys.argv[1] == 'snapshot':
   run = bench.DeviceRun('go_to_goal', N, 0, 0)
