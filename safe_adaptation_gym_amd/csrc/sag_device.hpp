@@ -1523,10 +1523,31 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     const float reach = sqrtf(R.vx * R.vx + R.vy * R.vy) * T + amax * T * T + 0.005f;
     bool busy = awake != 0 || (HAS_TBOX && task == SAG_TASK_HAUL_BOX);
     const float rr = my_bound + reach;
+    // Point: bounding circles first, then the footprint itself.  The robot is inside circle A (its sphere,
+    // r .1) and circle B (around the arrow box at +.1 along the heading, r .05 sqrt 2); within the step
+    // the origin travels <= reach and the heading turns <= dth (the yaw servo saturates at 3 rad/s).  A vase
+    // (sleeping here, else the env is busy anyway) can only be touched if its box comes within those radii:
+    // cb_contact needs the sphere centre closer than .1 to the box, bb_contact a vertex of one box inside the
+    // other, i.e. the box within .05 sqrt 2 of B's centre.  A third fewer envs pass than with circles alone.
+    constexpr bool FINE = !CAR && !DOGGO;
+    const float dth = (fmaxf(fabsf(R.w), 3.0f) + 1.0f) * T;
+    const float fa = 0.1f + reach, fb = 0.0707107f + reach + 0.1f * dth;
+    const float Bx = R.x + 0.1f * cy, By = R.y + 0.1f * sy;   // cy, sy: heading at the final state
 #pragma unroll 1
     for (int k = 0; k < nV; k++) {
-      const float dx = LP(LS_X, k) - R.x, dyy = LP(LS_Y, k) - R.y, rs = rr + vase_r;
-      busy |= dx * dx + dyy * dyy <= rs * rs;
+      const float vx_ = LP(LS_X, k), vy_ = LP(LS_Y, k);
+      const float dx = vx_ - R.x, dyy = vy_ - R.y, rs = rr + vase_r;
+      if (dx * dx + dyy * dyy <= rs * rs) {
+        if constexpr (FINE) {
+          float sv, cv; sincosf(LP(LS_YAW, k), &sv, &cv);
+          auto box_d2 = [&](float px, float py) {   // squared distance of a point to the vase's box
+            const float wx = px - vx_, wy = py - vy_;
+            const float ex = fmaxf(fabsf(cv * wx + sv * wy) - vsz, 0.f), ey = fmaxf(fabsf(cv * wy - sv * wx) - vsz, 0.f);
+            return ex * ex + ey * ey;
+          };
+          busy |= box_d2(R.x, R.y) <= fa * fa || box_d2(Bx, By) <= fb * fb;
+        } else busy = true;
+      }
     }
     if (has_box) {
       const float dx = LP(LS_X, BOX_ID) - R.x, dyy = LP(LS_Y, BOX_ID) - R.y, rs = rr + box_r;
@@ -1537,8 +1558,12 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (k == capP) k = SAG_MAX_PILLARS;
       const bool is_p = k < SAG_MAX_PILLARS;
       const bool on = is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB);
-      const float dx = stx[k] - R.x, dyy = sty[k] - R.y, rs = rr + (is_p ? psz : BUTTON_R);
-      busy |= on && dx * dx + dyy * dyy <= rs * rs;
+      const float sr = is_p ? psz : BUTTON_R;
+      const float dx = stx[k] - R.x, dyy = sty[k] - R.y, rs = rr + sr;
+      if constexpr (FINE) {
+        const float ex = stx[k] - Bx, ey = sty[k] - By;
+        busy |= on && (dx * dx + dyy * dyy <= (fa + sr) * (fa + sr) || ex * ex + ey * ey <= (fb + sr) * (fb + sr));
+      } else busy |= on && dx * dx + dyy * dyy <= rs * rs;
     }
     const uint32_t nbit = TS_BUSY_BIT << (p.phase ^ 1);
     tstate = busy ? (tstate | nbit) : (tstate & ~nbit);
