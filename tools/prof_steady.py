@@ -1,0 +1,61 @@
+"""Steady-state figures from a tools/prof.sh output directory: only the LAST `n` steps of the run
+(bench.py ages the population for 200 steps first; young steps are cheaper and would bias a mean
+over all dispatches).
+  python tools/prof_steady.py gpurun_out/prof_<tag> [n=30] [envs] -> text + profiles/traffic.json body"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+out = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+envs = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 22
+KEYS = ('k_compact', 'k_step_quiet', 'k_step_busy')
+
+
+def key_of(name):
+  for k in KEYS:
+    if k in name:
+      return k
+  return None
+
+
+# kernel trace: per step = the three launches; span = first start .. last end (the two step kernels overlap)
+tr = glob.glob(os.path.join(out, 'trace/**/*kernel_trace.csv'), recursive=True)
+if tr:
+  rows = defaultdict(list)
+  for r in csv.DictReader(open(tr[0])):
+    k = key_of(r['Kernel_Name'])
+    if k:
+      rows[k].append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+  steps = min(len(v) for v in rows.values())
+  span, dur = [], defaultdict(list)
+  for s in range(steps - n, steps):
+    t0 = min(rows[k][s][0] for k in KEYS)
+    t1 = max(rows[k][s][1] for k in KEYS)
+    span.append(t1 - t0)
+    for k in KEYS:
+      dur[k].append(rows[k][s][1] - rows[k][s][0])
+  print(f'kernel trace, last {n} of {steps} steps: step span (compact start .. last kernel end) '
+        f'{sum(span) / n / 1e3:.1f} us; ' + '; '.join(f'{k} {sum(dur[k]) / n / 1e3:.1f} us' for k in KEYS))
+  print(f'  algorithmic 892 B x {envs} envs / span = {892 * envs / (sum(span) / n) :.0f} GB/s = '
+        f'{892 * envs / (sum(span) / n) / 8000:.4f} of 8 TB/s')
+
+res = {}
+for d, cname in (('pmc3', 'FETCH_SIZE'), ('pmc4', 'WRITE_SIZE')):
+  f = glob.glob(os.path.join(out, f'{d}/**/*counter_collection.csv'), recursive=True)
+  if not f:
+    continue
+  vals = defaultdict(list)
+  for r in csv.DictReader(open(f[0])):
+    k = key_of(r['Kernel_Name'])
+    if k and r['Counter_Name'] == cname:
+      vals[k].append(float(r['Counter_Value']))
+  res[cname] = {k: sum(v[-n:]) / n for k, v in vals.items()}
+  print(f'{cname} (KB per launch, last {n} launches):', {k: round(v, 1) for k, v in res[cname].items()})
+if len(res) == 2:
+  fetch = 2 * sum(res['FETCH_SIZE'].values()) * 1024   # gfx950: 128-B requests counted as 64 B
+  write = sum(res['WRITE_SIZE'].values()) * 1024
+  print(f'HBM traffic per step: fetch {fetch / 1e6:.1f} MB (x2 corrected) + write {write / 1e6:.1f} MB = '
+        f'{(fetch + write) / envs:.1f} B per env-step (algorithmic 892)')
+  print(json.dumps({'envs': envs, 'last_launches': n,
+                    'FETCH_SIZE_KB_per_step': res['FETCH_SIZE'], 'WRITE_SIZE_KB_per_step': res['WRITE_SIZE'],
+                    'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact',
+                    'bytes_per_env_step': (fetch + write) / envs}, indent=1))
