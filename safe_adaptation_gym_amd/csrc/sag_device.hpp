@@ -371,22 +371,22 @@ __device__ inline double dist2d(double ax, double ay, double bx, double by) {
 // circle.  Values follow point.xml:18-19, primitive_objects.py, push_box.py:28-72,
 // roll_rod.py:19-43, dribble_ball.py:18-41.
 enum { SH_ROBOT = 0, SH_VASE = 1, SH_BOX = 2, SH_ROD = 3, SH_BALL = 4, SH_STATIC = 5, SH_CAR = 6 };
-struct Geom { int box; float ox, oy, a, b; };  // box ? half extents (a, b) : radius a
+struct Geom { int box; float ox, oy, a, b, r; };  // box ? half extents (a, b) : radius a; r: bounding radius, rounded up
 
 __device__ inline int shape_ngeom(int sh) { return sh == SH_ROBOT ? 2 : (sh == SH_BOX ? 5 : (sh == SH_CAR ? 8 : 1)); }
 
 __device__ inline Geom shape_geom(int sh, int g, float vsz, float rstatic) {
-  Geom q; q.ox = 0; q.oy = 0; q.b = 0;
+  Geom q; q.ox = 0; q.oy = 0; q.b = 0; q.r = 0;
   switch (sh) {
-    case SH_ROBOT: q.box = g; q.ox = g ? 0.1f : 0.f; q.a = g ? 0.05f : 0.1f; q.b = 0.05f; break;
-    case SH_VASE: q.box = 1; q.a = vsz; q.b = vsz; break;
+    case SH_ROBOT: q.box = g; q.ox = g ? 0.1f : 0.f; q.a = g ? 0.05f : 0.1f; q.b = 0.05f; q.r = g ? 0.0707108f : 0.1f; break;
+    case SH_VASE: q.box = 1; q.a = vsz; q.b = vsz; q.r = vsz * 1.4142137f; break;
     case SH_BOX:
-      q.box = 1; q.a = q.b = g ? 0.1f : 0.2f;
+      q.box = 1; q.a = q.b = g ? 0.1f : 0.2f; q.r = g ? 0.1414215f : 0.2828429f;
       q.ox = g == 0 ? 0.f : ((g & 1) ? 0.2f : -0.2f);      // g: 1 (+,+) 2 (-,+) 3 (+,-) 4 (-,-)
       q.oy = g == 0 ? 0.f : (g <= 2 ? 0.2f : -0.2f);
       break;
-    case SH_ROD: q.box = 1; q.a = 0.08f; q.b = 0.3f; break;
-    case SH_BALL: q.box = 0; q.a = 0.14f; break;
+    case SH_ROD: q.box = 1; q.a = 0.08f; q.b = 0.3f; q.r = 0.3104836f; break;
+    case SH_BALL: q.box = 0; q.a = 0.14f; q.r = 0.14f; break;
     case SH_CAR:  // car.xml:16-32 footprints: base, back bumper/connector, front bumper/connector,
                   // left/right wheel (cylinders along x), rear ball
       q.box = g < 7;
@@ -394,8 +394,10 @@ __device__ inline Geom shape_geom(int sh, int g, float vsz, float rstatic) {
       q.oy = g == 1 ? 0.15f : (g == 2 ? 0.125f : (g == 3 ? -0.165f : (g == 4 ? -0.13f : (g == 7 ? -0.1f : (g >= 5 ? 0.1f : 0.f)))));
       q.a = g == 0 || g == 1 ? 0.1f : (g == 2 ? 0.01f : (g == 5 || g == 6 ? 0.025f : 0.05f));
       q.b = g == 0 ? 0.1f : (g == 1 || g == 3 ? 0.01f : (g == 2 ? 0.025f : (g == 4 ? 0.03f : 0.05f)));
+      // sqrt(a^2 + b^2) of the seven boxes (rounded up), the ball's radius
+      q.r = g == 0 ? 0.1414215f : (g == 1 ? 0.1004989f : (g == 2 ? 0.0269260f : (g == 3 ? 0.0509903f : (g == 4 ? 0.0583097f : (g < 7 ? 0.0559018f : 0.05f)))));
       break;
-    default: q.box = 0; q.a = rstatic; break;
+    default: q.box = 0; q.a = rstatic; q.r = rstatic; break;
   }
   return q;
 }
@@ -412,7 +414,11 @@ __device__ inline float shape_bound(int sh, float vsz, float rstatic) {
   }
 }
 
-// every geom pair of two bodies, geoms of A outer, of B inner (the specification's order)
+// every geom pair of two bodies, geoms of A outer, of B inner (the specification's order).
+// CONST_R: cull with the constant bounding radii of shape_geom; the Doggo instances keep the run-time
+// sqrt form they were validated with (their lane-per-env kernel is at the edge of what the register
+// allocator handles: see DESIGN.md 3.4)
+template <bool CONST_R = false>
 __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, int shB, float cb,
                                      float sb, float vsz, float rstatic, const Sol& sol) {
   int n = 0;
@@ -425,10 +431,12 @@ __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, 
     for (int gb = 0; gb < nb; gb++) {
       Geom b = shape_geom(shB, gb, vsz, rstatic);
       // the ball's centre is .04 above the robot sphere's: it presents sqrt(.24^2-.04^2)-.1
-      if (shA == SH_ROBOT && ga == 0 && shB == SH_BALL) b.a = 0.13664319132398464f;
+      if (shA == SH_ROBOT && ga == 0 && shB == SH_BALL) b.a = b.r = 0.13664319132398464f;
       const float bx = B.x + cb * b.ox - sb * b.oy, by = B.y + sb * b.ox + cb * b.oy;
-      // per-geom bounding circles first
-      const float ra = a.box ? sqrtf(a.a * a.a + a.b * a.b) : a.a, rb = b.box ? sqrtf(b.a * b.a + b.b * b.b) : b.a;
+      // per-geom bounding circles first (a cull the specification does not have: the radii only need
+      // to contain the geoms, so they are constants rounded up, not a run-time sqrt per pair)
+      float ra = a.r, rb = b.r;
+      if constexpr (!CONST_R) { ra = a.box ? sqrtf(a.a * a.a + a.b * a.b) : a.a; rb = b.box ? sqrtf(b.a * b.a + b.b * b.b) : b.a; }
       const float dx = bx - ax, dy = by - ay, rs = ra + rb;
       if (dx * dx + dy * dy > rs * rs) continue;
       if (!a.box && !b.box) n += cc_contact(A, B, ax, ay, a.a, bx, by, b.a, sol);
@@ -1288,7 +1296,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (on && dx * dx + dyy * dyy <= rs * rs) {
         BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
         St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-        const int n = collide_shapes(R, SH_ME, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
+        const int n = collide_shapes<!DOGGO>(R, SH_ME, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
         if (is_p) cost_contacts += n;
         else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
       }
@@ -1314,7 +1322,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       dy.ensure(k, false);
       BV V; float cv, sv; load_body(dy, k, V, cv, sv);
       const float ax0 = V.ax, ay0 = V.ay, aw0 = V.aw;
-      const int n = collide_shapes(R, SH_ME, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
+      const int n = collide_shapes<!DOGGO>(R, SH_ME, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
       if (!isb) cost_contacts += n;   // the task object is not an obstacle (consts.OBSTACLES)
       if (n) { dy.set_acc(k, V.ax, V.ay, V.aw); active |= 1u << k; }
       (void)ax0; (void)ay0; (void)aw0;
@@ -1367,7 +1375,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
           BV V; float cv, sv; load_body(dy, k, V, cv, sv);
           BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
           St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-          collide_shapes(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
+          collide_shapes<!DOGGO>(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
           dy.set_acc(k, V.ax, V.ay, V.aw);
         }
       }
@@ -1405,7 +1413,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         BV A, B; float ca, sa, cb, sb;
         load_body(dy, a, A, ca, sa);
         load_body(dy, b, B, cb, sb);
-        const int n = collide_shapes(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0);
+        const int n = collide_shapes<!DOGGO>(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0);
         if (n) {
           dy.set_acc(a, A.ax, A.ay, A.aw); dy.set_acc(b, B.ax, B.ay, B.aw);
           active |= 1u << a | 1u << b;
