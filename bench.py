@@ -179,7 +179,7 @@ def main(argv=None, run_factory=None, emit=print):
   ap.add_argument('--steps', type=int, default=200)
   ap.add_argument('--warmup', type=int, default=20)
   # 4 M envs per GPU (4 GB of device state): above ~2 M the busy and the quiet kernel both keep the chip
-  # full and throughput is ~12 % above the 1 M-env figure (profiles/r01_v14_batch_size_sweep.txt)
+  # full and throughput is ~12 % above the 1 M-env figure (profiles/r01_v16_batch_size_sweep.txt)
   ap.add_argument('--envs', type=int, default=1 << 22, help='environments per GPU (weak scaling)')
   ap.add_argument('--task', default='go_to_goal')
   ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (stationary contact load)')

@@ -18,6 +18,7 @@
 #include "sag_device.hpp"
 
 #ifndef SAG_SPLIT_MIN_ENVS
+#define SAG_EARLY_FORK_MIN_ENVS 2097152  // tools/abab_env.sh sweep: crossover between 1.5 M and 2 M envs
 #define SAG_SPLIT_MIN_ENVS 262144  // measured crossover (tools/split_sweep.py, overlapped launches): Point ~260k, Car ~390k
 #define SAG_SPLIT_MIN_ENVS_CAR 393216
 #endif
@@ -53,6 +54,7 @@ struct sag_ctx {
   // workgroups once the batch exceeds what is resident at once (measured at 4 M envs: +8 % throughput,
   // tools/abab_env.sh; SAG_QUIET_LDS_EXTRA overrides, bytes; < 0 = busy kernel's footprint minus the quiet one's).
   int quiet_lds_extra = -1;
+  int early_fork = -1;  // quiet stream forks before the compaction: 1 / 0, -1 = by batch size (SAG_EARLY_FORK)
   bool overlap = true;  // SAG_OVERLAP=0: both kernels on the main stream, one after the other
   float* S = nullptr;
   int32_t* I = nullptr;
@@ -68,7 +70,7 @@ struct sag_ctx {
   bool hot_valid = false, use_hot = true;   // SAG_HOT=0 disables
   // SAG_INKERNEL_LIST=1: the step kernels append the next busy list themselves and k_compact only runs
   // after installs.  Measured no faster (0.37 vs 0.35 ms at 1M envs): the 15 us saved are lost to the
-  // worse row locality of chunks in arrival order (k_compact emits rows sorted per 1024-env block).
+  // worse row locality of chunks in arrival order (k_compact emits rows sorted per 4096-env block).
   bool inkernel_list = false;
   // last installed layout (sag_reset)
   float* L_f = nullptr;   // [N][SAG_REC_FLOATS] AoS, device
@@ -292,20 +294,33 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     }
     if (!c->inkernel_list) { a.rows_next = nullptr; a.count_next = nullptr; c->list_valid = false; }
     else HIPCHK(c, hipMemsetAsync(a.count_next, 0, sizeof(int32_t), c->stream));
+    // The quiet kernel needs no list (it reads the busy bits), so its stream forks off BEFORE the
+    // compaction: k_compact only looks at this step's copy of the bit, which the quiet kernel never
+    // changes (it rewrites tstate words of quiet envs with that bit still clear), so the two may overlap.
+    // Only when the batch is large enough to keep the chip full (>= SAG_EARLY_FORK_MIN_ENVS): below that a
+    // step is as long as its busy wavefronts, which must then be resident first (1 M envs: 15 % slower
+    // with the early fork, 4 M envs: 10 % faster; profiles/r01_v16_early_fork_ab.txt).
+    const bool early_fork = c->overlap && !c->inkernel_list &&
+                            (c->early_fork < 0 ? c->N >= SAG_EARLY_FORK_MIN_ENVS : c->early_fork != 0);
+    if (early_fork) {
+      HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      quiet_stream = c->stream2;
+    }
     if (!c->inkernel_list) {
       // two counters used alternately: this step's compaction zeroes the one the next step will use
       a.count = c->d_count + 2 + c->count_flip;
-      hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
+      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->N, a.phase,
                          a.rows, a.count, c->d_count + 2 + (c->count_flip ^ 1));
       c->count_flip ^= 1;
     } else if (!c->list_valid) {
       HIPCHK(c, hipMemsetAsync(a.count, 0, sizeof(int32_t), c->stream));
-      hipLaunchKernelGGL(k_compact, dim3((c->N + 1023) / 1024), dim3(256), 0, c->stream, c->I, c->N, a.phase,
+      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->N, a.phase,
                          a.rows, a.count, (int32_t*)nullptr);
     }
     c->last_count = a.count;
     c->list_valid = true;
-    if (c->overlap) {
+    if (c->overlap && !early_fork) {
       HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
       HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
       quiet_stream = c->stream2;
@@ -420,6 +435,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   if (const char* e = getenv("SAG_OVERLAP")) c->overlap = atoi(e) != 0;
+  if (const char* e = getenv("SAG_EARLY_FORK")) c->early_fork = atoi(e);
   if (const char* e = getenv("SAG_QUIET_LDS_EXTRA")) c->quiet_lds_extra = atoi(e) > 65536 ? 65536 : atoi(e);
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
   if (const char* e = getenv("SAG_HOT")) c->use_hot = atoi(e) != 0;

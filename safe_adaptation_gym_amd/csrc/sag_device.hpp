@@ -2061,31 +2061,35 @@ __global__ __launch_bounds__(WAVE, SAG_QUIET_MIN_WAVES) void k_step_quiet(StepAr
                                                    min(WAVE, p.N - base), skip, nullptr);
 }
 
-// busy envs -> dense list.  Each 256-thread block covers 1024 envs, orders its own busy ones by
-// index (ballot + prefix) and claims a contiguous segment with one atomic; segments of different
-// blocks land in arbitrary order, which only affects which wavefront processes an env.
+// busy envs -> dense list.  Each 256-thread block covers COMPACT_ENVS envs, orders its own busy ones by
+// index (ballot + prefix) and claims a contiguous segment with ONE atomic; segments of different blocks
+// land in arbitrary order, which only affects which wavefront processes an env.  (The atomics all hit
+// one counter and serialise at ~10 ns each: with 1024 envs per block the launch took 51 us at 4 M envs,
+// 4096 atomics; 4096 envs per block quarters that.)
+constexpr int COMPACT_PER_LANE = 16, COMPACT_ENVS = 256 * COMPACT_PER_LANE;
 __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int phase, int32_t* rows, int32_t* count,
                                                   int32_t* zero_for_next) {
   // the counter the NEXT step's compaction will add to (saves a memset launch per step)
   if (zero_for_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_for_next = 0;
-  __shared__ int wave_tot[4][4];
+  __shared__ int wave_tot[4][COMPACT_PER_LANE];
   __shared__ int seg_base;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int e0 = blockIdx.x * 1024 + wv * 256;
-  int pre[4];
-  bool b[4];
+  const int e0 = blockIdx.x * COMPACT_ENVS + wv * (WAVE * COMPACT_PER_LANE);
+  uint32_t bmask = 0;        // bit j: env e0 + j * 64 + lane is busy
+  int pre[COMPACT_PER_LANE];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
+  for (int j = 0; j < COMPACT_PER_LANE; j++) {
     const int e = e0 + j * WAVE + lane;
-    b[j] = e < N && ((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] & (TS_BUSY_BIT << phase));
-    const uint64_t m = __ballot(b[j]);
+    const bool b = e < N && ((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] & (TS_BUSY_BIT << phase));
+    const uint64_t m = __ballot(b);
+    bmask |= (uint32_t)b << j;
     pre[j] = __popcll(m & ((1ull << lane) - 1));
     if (lane == 0) wave_tot[wv][j] = __popcll(m);
   }
   __syncthreads();
   int before = 0, total = 0;
   for (int w = 0; w < 4; w++)
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < COMPACT_PER_LANE; j++) {
       const int t = wave_tot[w][j];
       if (w < wv) before += t;
       total += t;
@@ -2094,8 +2098,8 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int ph
   __syncthreads();
   int off = seg_base + before;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (b[j]) rows[off + pre[j]] = e0 + j * WAVE + lane;
+  for (int j = 0; j < COMPACT_PER_LANE; j++) {
+    if (bmask >> j & 1u) rows[off + pre[j]] = e0 + j * WAVE + lane;
     off += wave_tot[wv][j];
   }
 }
