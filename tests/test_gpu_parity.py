@@ -353,6 +353,36 @@ def test_env_api_shapes_and_reference_surface(nat):
   env.close()
 
 
+def test_early_fork_equals_single_launch(nat, monkeypatch):
+  """Large batches start the quiet kernel before the compaction that feeds the busy kernel (sag_api.hip,
+  `early_fork`: k_compact and k_step_quiet then run side by side on the tstate words).  Forced on here at a
+  batch of a few hundred wavefronts: results must still equal the single launch bit for bit."""
+  n, T = 20011, 70
+  rf, ri = bu.sample_records_native('point', 'go_to_goal', n, seed=4100)
+  ctxs = []
+  for split, fork in (('0', '0'), ('1', '1')):
+    monkeypatch.setenv('SAG_SPLIT', split)
+    monkeypatch.setenv('SAG_EARLY_FORK', fork)
+    c = nat.Context('point', n, seed=78)
+    c.set_layout(rf, ri)
+    ctxs.append(c)
+  rng = np.random.RandomState(4)
+  cost_events = 0
+  for t in range(T):
+    s_rf, s_ri = ctxs[0].get_state()
+    act = bu.pursuit_actions(s_rf, s_ri, rng, robot='point')
+    outs = [c.step(act) for c in ctxs]
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+      np.testing.assert_array_equal(a, b, err_msg=f'step {t}')
+    cost_events += int(outs[0][2].sum())
+  sa, sb = ctxs[0].get_state(), ctxs[1].get_state()
+  np.testing.assert_array_equal(sa[0], sb[0])
+  np.testing.assert_array_equal(sa[1], sb[1])
+  assert cost_events > 0
+  for c in ctxs:
+    c.close()
+
+
 @pytest.mark.parametrize('robot,task', [('point', 'go_to_goal'), ('point', MIXED), ('car', 'push_box'),
                                         ('point', 'haul_box')])
 def test_split_launch_equals_single_launch(nat, monkeypatch, robot, task):
