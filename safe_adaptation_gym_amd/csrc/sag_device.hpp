@@ -427,6 +427,12 @@ __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, 
   for (int ga = 0; ga < na; ga++) {
     const Geom a = shape_geom(shA, ga, vsz, rstatic);
     const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;
+    if constexpr (CONST_R) {
+      // a geom of A that cannot reach B's bounding circle skips B's geoms altogether (the car's rear
+      // geoms against the 5-geom box it pushes with its front)
+      const float ex = B.x - ax, ey = B.y - ay, rb_all = a.r + shape_bound(shB, vsz, rstatic) * 1.000001f;
+      if (nb > 1 && ex * ex + ey * ey > rb_all * rb_all) continue;
+    }
 #pragma unroll 1
     for (int gb = 0; gb < nb; gb++) {
       Geom b = shape_geom(shB, gb, vsz, rstatic);
