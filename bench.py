@@ -291,6 +291,21 @@ def main(argv=None, run_factory=None, emit=print):
           'kernel_ms': ms,
           'note': 'BASELINE config-2 batch size (4096 envs on one GPU): latency bound, 16 envs per wavefront x 256 wavefronts'
       }
+      # the lidar + hazard-cost kernel alone on explicit poses (BASELINE config 2 "lidar + cost only";
+      # sag_lidar_cost takes host buffers: the figure includes the PCIe copies both ways)
+      rs = np.random.RandomState(0)
+      nK = 21
+      rob = np.concatenate([rs.uniform(-2, 2, (4096, 2)), rs.uniform(-np.pi, np.pi, (4096, 1))], 1).astype(np.float32)
+      pts = rs.uniform(-2.5, 2.5, (4096, nK, 2)).astype(np.float32)
+      grp = np.tile(np.array([1 + 128] * 8 + [1] * 12 + [2], np.uint8), (4096, 1))   # 8 hazards (+128: cost-tested), 12 vases / pillars, the goal
+      c2.ctx.lidar_cost(rob, pts, grp, want_bins=False)
+      t0 = time.perf_counter()
+      for _ in range(100):
+        c2.ctx.lidar_cost(rob, pts, grp, want_bins=False)
+      t_lc = (time.perf_counter() - t0) / 100
+      res['c2_lidar_cost_only_4096'] = {'ms_per_call': t_lc * 1e3, 'value': 4096 / t_lc, 'unit': 'env-evaluations/s',
+                                        'note': 'sag_lidar_cost (k_lidar_cost, fp64, bit-exact bins and cost flags vs the reference fixtures) on '
+                                                '4096 poses x 21 points through the host-buffer C ABI: H2D + kernel + D2H, synchronous'}
       c2.close()
     if not args.no_c2:
       # BASELINE config 3 (Car / push_box), 4096 envs and a loaded batch; 804 algorithmic B/env-step
