@@ -1,5 +1,7 @@
 """HIP path (libsag.so through the C ABI) vs the CPU oracle and the golden fixtures.
 Run on an MI355X: python -m pytest tests -m gpu."""
+import os
+
 import numpy as np
 import pytest
 
@@ -135,7 +137,7 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, robot, task):
   env-steps.  Discrete outputs (goal_met, done, RNG words consumed, task ints) are exact;
   cost flags are exact except where the oracle reports the decision within 1e-5 of its
   threshold."""
-  n, T = 192, 160
+  n, T = 192 * int(os.environ.get('SAG_LOCKSTEP_SCALE', '1')), 160   # SAG_LOCKSTEP_SCALE=8: occasional soak run
   rid = {'point': 0, 'car': 1}[robot]
   od = 60 if robot == 'point' else 72
   if task == MIXED:
