@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAG_ABI_VERSION 2
+#define SAG_ABI_VERSION 3
 
 /* ---- capacities (maxima over the reference's task set: Task.obstacles) ---- */
 #define SAG_MAX_HAZARDS 9  /* tasks/go_to_goal.py:83-84  [9,10,0,1]          */
@@ -128,7 +128,14 @@ enum sag_rec_int {
   SAG_I_ACTIVE_MASK = 10, /* collect.py:15-16: bit b = buttons{b} still active     */
   SAG_I_STEP = 11,        /* env steps since rebuild (time = step * nstep * dt)    */
   SAG_I_ENV_ID = 12,      /* global env index (counter-based RNG stream id)        */
-  SAG_I_FLAGS = 13,       /* bit0: resample failed (ResamplingError), bit1: tape exhausted */
+  SAG_I_FLAGS = 13,       /* bit0: resample failed (ResamplingError), bit1: tape exhausted,
+                           * bit2: a Doggo constraint did not fit the row budget and was dropped */
+  SAG_I_EPISODE = 14,     /* episode nonce of the counter-based generator (24 bits): with SAG_I_ENV_ID
+                           * and SAG_I_STEP it forms the counter, so that the device-side draws of
+                           * throughput mode (action noise, goal resampling, CatchGoal radii, button
+                           * choice) differ from episode to episode as the reference's reseeded
+                           * RandomState does (safe_adaptation_gym.py:97-101).  sag_set_layout takes it
+                           * from the record, sag_reset adds one */
   SAG_REC_INTS = 16
 };
 
@@ -143,7 +150,7 @@ typedef struct sag_config {
   int32_t max_buttons;
   int32_t has_box;      /* allocate box state                                  */
   int32_t reserved0;
-  uint64_t seed;        /* key of the counter-based generator (throughput mode) */
+  uint64_t seed;        /* key of the counter-based generator (throughput mode); sag_set_seed changes it */
 } sag_config;
 
 typedef struct sag_ctx sag_ctx;
@@ -167,8 +174,12 @@ int sag_set_layout(sag_ctx* ctx, const int32_t* env_ids, int32_t n,
                    const float* rec_f, const int32_t* rec_i);
 
 /* Re-install the records last given to sag_set_layout for these envs (start
- * of a fixed-layout episode). */
+ * of a fixed-layout episode); their episode nonce (SAG_I_EPISODE) advances by one. */
 int sag_reset(sag_ctx* ctx, const int32_t* env_ids, int32_t n);
+
+/* env.seed(s) (safe_adaptation_gym.py:113-118) for the device-side generator of throughput
+ * mode: the key of the counter-based stream from the next step on. */
+int sag_set_seed(sag_ctx* ctx, uint64_t seed);
 
 /* Checkpoint / parity access to the complete per-env state (same records). */
 int sag_get_state(sag_ctx* ctx, const int32_t* env_ids, int32_t n, float* rec_f,
@@ -219,6 +230,13 @@ int sag_observe(sag_ctx* ctx, float* obs);
 int sag_lidar_cost(sag_ctx* ctx, int32_t n, int32_t K, const float* robot,
                    const float* points, const uint8_t* group, float hazard_size,
                    float* lidar, int32_t* bins, uint8_t* cost);
+
+/* The same kernel on DEVICE buffers of the context's device, enqueued on the context stream
+ * without host copies or synchronisation (sag_wait joins); bracketed by the HIP events of
+ * sag_enable_timing / sag_kernel_time_ms like a step launch.  d_bins may be NULL. */
+int sag_lidar_cost_device(sag_ctx* ctx, int32_t n, int32_t K, const float* d_robot,
+                          const float* d_points, const uint8_t* d_group, float hazard_size,
+                          float* d_lidar, int32_t* d_bins, uint8_t* d_cost);
 
 /* Device allocation helpers so NumPy-only hosts can keep action/observation
  * buffers resident (bench harness, GPU learners without torch). */

@@ -153,6 +153,7 @@ typedef struct {
   int len, pos;
   int exhausted;
   uint32_t key0, key1, env_id, step;
+  uint32_t ep4; /* episode nonce (SAG_I_EPISODE) << 2: counter word 3 = nonce | stream */
 } Rng;
 
 /* stream 0: in-step draws (words indexed by pos); stream 1: action noise;
@@ -162,7 +163,7 @@ static uint32_t rng_word(Rng* g) {
     if (g->pos >= g->len) { g->exhausted = 1; g->pos++; return 0; }
     return g->tape[g->pos++];
   }
-  uint32_t c[4] = {g->env_id, g->step, (uint32_t)(g->pos >> 2), 0u};
+  uint32_t c[4] = {g->env_id, g->step, (uint32_t)(g->pos >> 2), g->ep4};
   philox4x32_10(c, g->key0, g->key1);
   return c[g->pos++ & 3];
 }
@@ -176,9 +177,9 @@ static double rng_uniform(Rng* g, double lo, double hi) { return lo + (hi - lo) 
 
 /* counter-based standard normals for action noise (throughput mode only; the
  * reference draws rs.normal(size=nu), safe_adaptation_gym.py:63-65). */
-void sago_noise(uint32_t key0, uint32_t key1, uint32_t env_id, uint32_t step, int nu, float* out) {
+void sago_noise_ep(uint32_t key0, uint32_t key1, uint32_t env_id, uint32_t step, uint32_t episode, int nu, float* out) {
   for (int j = 0; j < nu; j += 2) {
-    uint32_t c[4] = {env_id, step, (uint32_t)(j >> 1), 1u};
+    uint32_t c[4] = {env_id, step, (uint32_t)(j >> 1), episode << 2 | 1u};
     philox4x32_10(c, key0, key1);
     float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
     float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
@@ -187,6 +188,9 @@ void sago_noise(uint32_t key0, uint32_t key1, uint32_t env_id, uint32_t step, in
     out[j] = r * cosf(a);
     if (j + 1 < nu) out[j + 1] = r * sinf(a);
   }
+}
+void sago_noise(uint32_t key0, uint32_t key1, uint32_t env_id, uint32_t step, int nu, float* out) {
+  sago_noise_ep(key0, key1, env_id, step, 0u, nu, out);
 }
 /* synthetic policy: U(-1,1) (stream 2) */
 void sago_actions(uint32_t key0, uint32_t key1, uint32_t env_id, uint32_t step, int nu, float* out) {
@@ -1426,9 +1430,10 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   int nu = NU[robot];
   double h = DT[robot];
   if (nstep < 0) nstep = NSTEP[robot];
-  Rng g = {tape, tape_len, 0, 0, key0, key1, (uint32_t)e->i[SAG_I_ENV_ID], (uint32_t)e->i[SAG_I_STEP]};
+  Rng g = {tape, tape_len, 0, 0, key0, key1, (uint32_t)e->i[SAG_I_ENV_ID], (uint32_t)e->i[SAG_I_STEP],
+           (uint32_t)e->i[SAG_I_EPISODE] << 2};
   float nz[SAG_MAX_NU];
-  if (!noise) { sago_noise(key0, key1, g.env_id, g.step, nu, nz); noise = nz; }
+  if (!noise) { sago_noise_ep(key0, key1, g.env_id, g.step, (uint32_t)e->i[SAG_I_EPISODE], nu, nz); noise = nz; }
   real ctrl[SAG_MAX_NU];
   for (int j = 0; j < nu; j++) {
     /* action + action_noise * normal, clipped to ctrlrange * scale (:63-67, mujoco_bridge.py:164-166) */

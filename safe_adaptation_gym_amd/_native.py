@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SAG_LIB overrides the library file (A/B builds of the same ABI during kernel tuning)
 LIB_PATH = os.environ.get('SAG_LIB') or os.path.join(_HERE, 'libsag.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_HAZARDS, MAX_VASES, MAX_PILLARS, MAX_BUTTONS, MAX_NU = 9, 10, 2, 6, 12
 REC_FLOATS, REC_INTS = 184, 16
 
@@ -23,14 +23,14 @@ F_HAZARDS, F_PILLARS, F_BUTTONS, F_VASES = 47, 65, 69, 81
 F_ROBOT_EXT = 144
 F_BOUND = 141
 (I_TASK, I_NH, I_NV, I_NP, I_NB, I_BOX_KIND, I_GOAL_BUTTON, I_BTN_STATE, I_BTN_TIMER,
- I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS) = range(14)
+ I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS, I_EPISODE) = range(15)
 
 ROBOT_IDS = {'point': 0, 'car': 1, 'doggo': 2}
 
 EXPORTS = [
     'sag_robot_info', 'sag_create', 'sag_destroy', 'sag_last_error', 'sag_set_layout',
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
-    'sag_observe', 'sag_lidar_cost', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
+    'sag_observe', 'sag_lidar_cost', 'sag_lidar_cost_device', 'sag_set_seed', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
     'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device', 'sag_debug_doggo_coop',
     'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts'
 ]
@@ -84,6 +84,8 @@ def load():
   lib.sag_wait.argtypes = [vp]
   lib.sag_observe.argtypes = [vp, fp]
   lib.sag_lidar_cost.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, bp, C.c_float, fp, ip, bp]
+  lib.sag_lidar_cost_device.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_float, vp, vp, vp]
+  lib.sag_set_seed.argtypes = [vp, C.c_uint64]
   lib.sag_dev_alloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
   lib.sag_dev_free.argtypes = [vp, vp]
   lib.sag_dev_upload.argtypes = [vp, vp, vp, C.c_uint64]
@@ -274,6 +276,15 @@ class Context:
                                 _ptr(group, C.c_uint8), hazard_size, _ptr(lidar, C.c_float),
                                 _ptr(bins, C.c_int32), _ptr(cost, C.c_uint8)), 'sag_lidar_cost')
     return lidar, bins, cost
+
+  def lidar_cost_device(self, n, K, d_robot, d_points, d_group, d_lidar, d_bins, d_cost, hazard_size=0.2):
+    """The same kernel on device buffers, asynchronous on the context stream (bench: kernel-only time)."""
+    self._check(self.lib.sag_lidar_cost_device(self.h, n, K, d_robot, d_points, d_group, hazard_size, d_lidar, d_bins,
+                                               d_cost), 'sag_lidar_cost_device')
+
+  def set_seed(self, seed):
+    """Key of the device-side generator of throughput mode (env.seed())."""
+    self._check(self.lib.sag_set_seed(self.h, int(seed) & (2**64 - 1)), 'sag_set_seed')
 
   # -- device-resident stepping (bench harness / GPU learners) -----------------
   def dev_alloc(self, nbytes):

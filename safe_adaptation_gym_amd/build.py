@@ -1,4 +1,5 @@
 """Builds libsag.so (HIP, gfx950) in-tree.  `python -m safe_adaptation_gym_amd.build`."""
+import glob
 import os
 import shutil
 import subprocess
@@ -8,7 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsag.so')
 SOURCES = ['sag_api.hip', 'sag_sampler.cpp']
-HEADERS = ['sag_device.hpp', os.path.join('..', '..', 'include', 'sag.h')]
+# every header under csrc/ (sag_device.hpp includes the Doggo, cooperative-Doggo and render headers) + the ABI
+HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, '*.hpp'))) + [
+    os.path.join('..', '..', 'include', 'sag.h')]
 
 
 def hipcc():

@@ -3,8 +3,10 @@
 // One context = one GPU = one HIP stream.  Device memory: the SoA world
 // (S: [DEV_GROUPS][N] float4, I: tstate [N] + int4 [N]; sag_device.hpp didx / iaddr), AoS staging for records,
 // pinned host + device staging for the host-pointer step.  No allocation, no
-// synchronisation and no host<->device copy happens inside sag_step_device(),
-// so callers may capture it into a hipGraph.
+// synchronisation and no host<->device copy happens inside sag_step_device()
+// (every buffer it needs exists after sag_create; timing events, off by default,
+// are the exception), so callers may capture it into a hipGraph.  Every entry point
+// selects the context's device first: contexts on different GPUs may share a host thread.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -18,7 +20,7 @@
 #include "sag_device.hpp"
 
 #ifndef SAG_SPLIT_MIN_ENVS
-#define SAG_EARLY_FORK_MIN_ENVS 2097152  // tools/abab_env.sh sweep: crossover between 1.5 M and 2 M envs
+#define SAG_EARLY_FORK_MIN_ENVS 2097152  // tools/ab.sh run sweep: crossover between 1.5 M and 2 M envs
 #define SAG_SPLIT_MIN_ENVS 262144  // measured crossover (tools/split_sweep.py, overlapped launches): Point ~260k, Car ~390k
 #define SAG_SPLIT_MIN_ENVS_CAR 393216
 #endif
@@ -52,7 +54,7 @@ struct sag_ctx {
   // workgroup (higher stream priority) fits into any hole a quiet one leaves.  With 10-KB holes the busy
   // kernel, which sets the length of a step, is starved of LDS by the far more numerous quiet
   // workgroups once the batch exceeds what is resident at once (measured at 4 M envs: +8 % throughput,
-  // tools/abab_env.sh; SAG_QUIET_LDS_EXTRA overrides, bytes; < 0 = busy kernel's footprint minus the quiet one's).
+  // tools/ab.sh run; SAG_QUIET_LDS_EXTRA overrides, bytes; < 0 = busy kernel's footprint minus the quiet one's).
   int quiet_lds_extra = -1;
   int early_fork = -1;  // quiet stream forks before the compaction: 1 / 0, -1 = by batch size (SAG_EARLY_FORK)
   bool overlap = true;  // SAG_OVERLAP=0: both kernels on the main stream, one after the other
@@ -99,6 +101,7 @@ struct sag_ctx {
   // to ~12k envs (measured 8.4 vs 16.8 ms at 4096), the lane-per-env kernel above that (36 vs 48 ms at
   // 32768: it keeps 64 envs per wavefront busy).  SAG_DOGGO_COOP=0/1 forces one.
   bool doggo_coop = false;
+  int epw_override = 0;  // SAG_EPW (read once at create): envs per wavefront of the single-launch form
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
@@ -231,16 +234,37 @@ void drain_events(sag_ctx* c) {
   c->ev_used = 0;
 }
 
+// a pair of timing events for one launch (nullptr, nullptr when timing is off); bounded pool
+int timing_events(sag_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
+  if (!c->timing) return 0;
+  if (c->ev_used == c->ev_pool.size()) {
+    if (c->ev_pool.size() >= 4096) {  // fold what has finished
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      drain_events(c);
+    } else {
+      hipEvent_t a0, a1;
+      HIPCHK(c, hipEventCreate(&a0));
+      HIPCHK(c, hipEventCreate(&a1));
+      c->ev_pool.emplace_back(a0, a1);
+    }
+  }
+  *e0 = c->ev_pool[c->ev_used].first; *e1 = c->ev_pool[c->ev_used].second;
+  c->ev_used++;
+  return 0;
+}
+
 int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint32_t* d_tape,
                 int tape_len, int nstep, float* d_obs, float* d_rew, uint8_t* d_cost,
                 uint8_t* d_done, uint8_t* d_met, int32_t* d_used, int observe_only) {
+  HIPCHK(c, hipSetDevice(c->cfg.device));
   StepArgs a;
   a.S = c->S; a.I = c->I; a.N = c->N;
   a.actions = d_act; a.noise = d_noise; a.tape = d_tape; a.tape_len = tape_len;
   a.nstep = nstep < 0 ? c->rb.nstep : nstep;
   a.nstep_table = c->rb.nstep;
   a.h = (float)c->rb.dt;
-  a.key0 = (uint32_t)(c->cfg.seed & 0xffffffffu); a.key1 = (uint32_t)(c->cfg.seed >> 32);
+  a.key0 = (uint32_t)(c->cfg.seed & 0xffffffffu); a.key1 = (uint32_t)(c->cfg.seed >> 32);  // sag_set_seed
   a.obs = d_obs; a.reward = d_rew; a.cost = d_cost; a.done = d_done; a.goal_met = d_met;
   a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
@@ -254,28 +278,17 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     const bool dg = c->cfg.robot == SAG_ROBOT_DOGGO;
     int epw = 64;
     while (epw > (dg ? 8 : 16) && (c->N + epw - 1) / epw < (dg ? 1 : 4) * c->n_cu) epw >>= 1;
-    if (const char* e = getenv("SAG_EPW")) epw = atoi(e);
+    if (c->epw_override > 0) epw = c->epw_override;
     a.envs_per_wave = epw < 1 ? 1 : (epw > 64 ? 64 : epw);
   }
   c->phase_used = c->phase;
   if (!observe_only) c->phase ^= 1;
   const int blocks = (c->N + WAVE - 1) / WAVE;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (c->timing && !observe_only) {
-    if (c->ev_used == c->ev_pool.size()) {
-      if (c->ev_pool.size() >= 4096) {  // bounded pool: fold what has finished
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        drain_events(c);
-      } else {
-        hipEvent_t a0, a1;
-        HIPCHK(c, hipEventCreate(&a0));
-        HIPCHK(c, hipEventCreate(&a1));
-        c->ev_pool.emplace_back(a0, a1);
-      }
-    }
-    e0 = c->ev_pool[c->ev_used].first; e1 = c->ev_pool[c->ev_used].second;
-    c->ev_used++;
-    HIPCHK(c, hipEventRecord(e0, c->stream));
+  if (!observe_only) {
+    int rc = timing_events(c, &e0, &e1);
+    if (rc) return rc;
+    if (e0) HIPCHK(c, hipEventRecord(e0, c->stream));
   }
   const bool btn = c->cfg.max_buttons > 0, tbox = c->cfg.has_box != 0;
   // split form: QUIET kernel over every env whose busy bit is clear, then BUSY kernel over the
@@ -284,8 +297,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   hipStream_t quiet_stream = c->stream;
   if (split) {
     a.rows_next = c->d_rows + (size_t)(c->phase_used ^ 1) * c->N; a.count_next = c->d_count + (c->phase_used ^ 1);
-    if (c->use_hot) {
-      if (!c->d_hot) HIPCHK(c, hipMalloc(&c->d_hot, (size_t)c->N * (HOT_FLOATS + 20) * sizeof(float)));
+    if (c->use_hot && c->d_hot) {
       a.hot = c->d_hot; a.hot_haz = c->d_hot + (size_t)c->N * HOT_FLOATS;
       if (!c->hot_valid) {
         hipLaunchKernelGGL(k_hot_refresh, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N, c->d_hot, c->d_hot + (size_t)c->N * HOT_FLOATS);
@@ -354,7 +366,6 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   else if (c->cfg.robot == SAG_ROBOT_CAR) SAG_LAUNCH(SAG_ROBOT_CAR);
   else if (c->doggo_coop) {
     // Doggo, wave-cooperative physics (32 lanes per env) + the generic step without physics
-    if (!c->d_dr) HIPCHK(c, hipMalloc(&c->d_dr, (size_t)c->N * DR_STRIDE * sizeof(double)));
     a.DR = c->d_dr;
     hipLaunchKernelGGL(k_doggo_physics, dim3((c->N + DC_EPW - 1) / DC_EPW), dim3(32 * DC_EPW), 0, c->stream, a, c->d_dr);
     hipLaunchKernelGGL((k_step_doggo_post<true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
@@ -439,6 +450,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   if (const char* e = getenv("SAG_QUIET_LDS_EXTRA")) c->quiet_lds_extra = atoi(e) > 65536 ? 65536 : atoi(e);
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
   if (const char* e = getenv("SAG_HOT")) c->use_hot = atoi(e) != 0;
+  if (const char* e = getenv("SAG_EPW")) c->epw_override = atoi(e);
   c->doggo_coop = cfg->robot == SAG_ROBOT_DOGGO && cfg->n_envs <= 12288;
   if (const char* e = getenv("SAG_DOGGO_COOP")) c->doggo_coop = atoi(e) != 0;
   {
@@ -464,6 +476,9 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->d_done, N));
   CREATE_CHK(hipMalloc(&c->d_met, N));
   CREATE_CHK(hipMalloc(&c->d_used, N * sizeof(int32_t)));
+  if (c->split && c->use_hot && cfg->robot != SAG_ROBOT_DOGGO)
+    CREATE_CHK(hipMalloc(&c->d_hot, N * (HOT_FLOATS + 20) * sizeof(float)));
+  if (c->doggo_coop) CREATE_CHK(hipMalloc(&c->d_dr, N * DR_STRIDE * sizeof(double)));
   if (cfg->robot == SAG_ROBOT_DOGGO) {
     DgModel model;
     dg_build_model(model);
@@ -530,18 +545,15 @@ int sag_set_layout(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* r
   hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i);
   HIPCHK(c, hipGetLastError());
-  // scatter the staged records into L_f/L_i rows by env id (host loop of async copies would be
-  // slow; records are contiguous when env_ids == NULL, the common case)
+  // the layout store keeps the records as installed, by env id (one scatter launch, not 2 n copies)
   if (!env_ids) {
     HIPCHK(c, hipMemcpyAsync(c->L_f, c->st_f, (size_t)n * SAG_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->L_i, c->st_i, (size_t)n * SAG_REC_INTS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
   } else {
-    for (int k = 0; k < n; k++) {
-      HIPCHK(c, hipMemcpyAsync(c->L_f + (size_t)env_ids[k] * SAG_REC_FLOATS, c->st_f + (size_t)k * SAG_REC_FLOATS,
-                               SAG_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->L_i + (size_t)env_ids[k] * SAG_REC_INTS, c->st_i + (size_t)k * SAG_REC_INTS,
-                               SAG_REC_INTS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-    }
+    const size_t pieces = (size_t)n * (SAG_REC_FLOATS / 4 + SAG_REC_INTS / 4);
+    hipLaunchKernelGGL(k_move_rows, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, c->stream, c->L_f, c->L_i, c->st_f,
+                       c->st_i, c->st_ids, n, 0, 0);
+    HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_layout = true;
@@ -584,25 +596,23 @@ int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
   if (!c->have_layout) return fail(c, SAG_ERR_STATE, "sag_reset before sag_set_layout");
   if (n <= 0 || n > c->N) return fail(c, SAG_ERR_ARG, "bad n=%d", n);
   HIPCHK(c, hipSetDevice(c->cfg.device));
+  // a new episode of the same layout: the episode nonce of the counter-based generator advances
   if (!env_ids) {
+    hipLaunchKernelGGL(k_bump_episode, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->L_i, n);
     hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                        (const int32_t*)nullptr, n, c->L_f, c->L_i, 0);
-  c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   } else {
     for (int k = 0; k < n; k++)
       if (env_ids[k] < 0 || env_ids[k] >= c->N) return fail(c, SAG_ERR_ARG, "env id %d out of range", env_ids[k]);
-    // gather the chosen layout rows into staging, then install
-    for (int k = 0; k < n; k++) {
-      HIPCHK(c, hipMemcpyAsync(c->st_f + (size_t)k * SAG_REC_FLOATS, c->L_f + (size_t)env_ids[k] * SAG_REC_FLOATS,
-                               SAG_REC_FLOATS * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->st_i + (size_t)k * SAG_REC_INTS, c->L_i + (size_t)env_ids[k] * SAG_REC_INTS,
-                               SAG_REC_INTS * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-    }
+    // gather the chosen layout rows into staging (one launch), then install
     HIPCHK(c, hipMemcpyAsync(c->st_ids, env_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    const size_t pieces = (size_t)n * (SAG_REC_FLOATS / 4 + SAG_REC_INTS / 4);
+    hipLaunchKernelGGL(k_move_rows, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, c->stream, c->st_f, c->st_i, c->L_f,
+                       c->L_i, c->st_ids, n, 1, 1);
     hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                        c->st_ids, n, c->st_f, c->st_i, 0);
-  c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   }
+  c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SAG_OK;
@@ -619,7 +629,14 @@ int sag_step_device(sag_ctx* c, const float* d_actions, const float* d_noise, in
 
 int sag_wait(sag_ctx* c) {
   if (!c) return SAG_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_set_seed(sag_ctx* c, uint64_t seed) {
+  if (!c) return SAG_ERR_ARG;
+  c->cfg.seed = seed;   // read by the next launch (StepArgs::key0/1)
   return SAG_OK;
 }
 
@@ -699,6 +716,23 @@ int sag_lidar_cost(sag_ctx* c, int32_t n, int32_t K, const float* robot, const f
   if (bins && K > 0) HIPCHK(c, hipMemcpyAsync(bins, d_bins, b_bins, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(cost, d_cost, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_lidar_cost_device(sag_ctx* c, int32_t n, int32_t K, const float* d_robot, const float* d_points,
+                          const uint8_t* d_group, float hazard_size, float* d_lidar, int32_t* d_bins, uint8_t* d_cost) {
+  if (!c) return SAG_ERR_ARG;
+  if (n <= 0 || K < 0 || !d_robot || (K > 0 && (!d_points || !d_group)) || !d_lidar || !d_cost)
+    return fail(c, SAG_ERR_ARG, "bad sag_lidar_cost_device arguments");
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = timing_events(c, &e0, &e1);
+  if (rc) return rc;
+  if (e0) HIPCHK(c, hipEventRecord(e0, c->stream));
+  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, c->stream, n, K, d_robot, d_points,
+                     d_group, hazard_size, d_lidar, d_bins, d_cost);
+  if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipGetLastError());
   return SAG_OK;
 }
 

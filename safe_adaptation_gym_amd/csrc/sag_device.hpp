@@ -26,6 +26,8 @@ constexpr int WAVE = 64;
 // device int fields.  TSTATE is a plain [N] column (k_compact and the quiet kernel's busy test read
 // only it); the other four words of an env sit together as one int4 behind it.
 enum { DI_META = 0, DI_TSTATE = 1, DI_STEP = 2, DI_ENVID = 3, DI_FLAGS = 4, DI_COUNT = 5 };
+// the FLAGS word: record flags in the low byte, the episode nonce (SAG_I_EPISODE) above it
+constexpr int FLAG_EPISODE_SHIFT = 8;
 __host__ __device__ constexpr size_t iaddr(int w, size_t N, size_t i) {
   return w == DI_TSTATE ? i : N + i * 4 + (w == DI_META ? 0 : (w == DI_STEP ? 1 : (w == DI_ENVID ? 2 : 3)));
 }
@@ -184,12 +186,13 @@ struct Rng {
   const uint32_t* tape;  // this env's row or nullptr
   int len, pos, exhausted;
   uint32_t k0, k1, env, step;
+  uint32_t ep4;   // episode nonce << 2 (counter word 3 = nonce | stream: 0 in-step draws, 1 action noise, 2 bench policy)
   __device__ uint32_t word() {
     if (tape) {
       if (pos >= len) { exhausted = 1; pos++; return 0u; }
       return tape[pos++];
     }
-    uint32_t c[4] = {env, step, (uint32_t)(pos >> 2), 0u};
+    uint32_t c[4] = {env, step, (uint32_t)(pos >> 2), ep4};
     philox4x32_10(c, k0, k1);
     uint32_t w = c[pos & 3];
     pos++;
@@ -1046,6 +1049,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   rng.tape = p.tape ? p.tape + (size_t)i * p.tape_len : nullptr;
   rng.len = p.tape_len; rng.pos = 0; rng.exhausted = 0;
   rng.k0 = p.key0; rng.k1 = p.key1; rng.env = env_id; rng.step = (uint32_t)step;
+  rng.ep4 = ((uint32_t)iw.w >> FLAG_EPISODE_SHIFT) << 2;
 
   // ---- action noise + clip (safe_adaptation_gym.py:58-67) ---------------------
   float ctrl0 = 0, ctrl1 = 0;
@@ -1058,7 +1062,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         float z0, z1;
         if (p.noise) { z0 = p.noise[(size_t)i * 12 + j]; z1 = p.noise[(size_t)i * 12 + j + 1]; }
         else {
-          uint32_t c[4] = {rng.env, rng.step, (uint32_t)(j >> 1), 1u};
+          uint32_t c[4] = {rng.env, rng.step, (uint32_t)(j >> 1), rng.ep4 | 1u};
           philox4x32_10(c, p.key0, p.key1);
           box_muller(c[0], c[1], z0, z1);
         }
@@ -1070,7 +1074,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   }
   if (!p.observe_only) {
     if (!p.noise && !DOGGO) {
-      uint32_t c[4] = {rng.env, rng.step, 0u, 1u};
+      uint32_t c[4] = {rng.env, rng.step, 0u, rng.ep4 | 1u};
       philox4x32_10(c, p.key0, p.key1);
       box_muller(c[0], c[1], n0, n1);
     }
@@ -1726,7 +1730,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       const int s_box = __shfl((int)has_box, src);
       const double s_bx = __shfl(boxx, src), s_by = __shfl(boxy, src);
       const int s_pos0 = __shfl(rng.pos, src), s_len = __shfl(rng.len, src);
-      const uint32_t s_env = __shfl(rng.env, src), s_step = __shfl(rng.step, src);
+      const uint32_t s_env = __shfl(rng.env, src), s_step = __shfl(rng.step, src), s_ep4 = __shfl(rng.ep4, src);
       const uint32_t* s_tape = p.tape ? p.tape + (size_t)s_i * p.tape_len : nullptr;
       const double k_robot = S[saddr(SAG_F_KEEPOUT, (size_t)N, (size_t)s_i)], k_haz = S[saddr(SAG_F_KEEPOUT + 1, (size_t)N, (size_t)s_i)],
                    k_vase = S[saddr(SAG_F_KEEPOUT + 2, (size_t)N, (size_t)s_i)], k_pil = S[saddr(SAG_F_KEEPOUT + 3, (size_t)N, (size_t)s_i)],
@@ -1752,7 +1756,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         } else {
 #pragma unroll
           for (int t = 0; t < 4; t++) {
-            uint32_t c[4] = {s_env, s_step, (uint32_t)((w0 + t) >> 2), 0u};
+            uint32_t c[4] = {s_env, s_step, (uint32_t)((w0 + t) >> 2), s_ep4};
             philox4x32_10(c, p.key0, p.key1);
             wd[t] = c[(w0 + t) & 3];
           }
@@ -2204,7 +2208,7 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
   I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)] = (int32_t)(pack_tstate(ri) | awake << TS_AWAKE_SHIFT | TS_BUSY_BIT | TS_BUSY_BIT << 1);
   I[iaddr(DI_STEP, (size_t)N, (size_t)i)] = ri[SAG_I_STEP];
   I[iaddr(DI_ENVID, (size_t)N, (size_t)i)] = ri[SAG_I_ENV_ID];
-  I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)] = ri[SAG_I_FLAGS];
+  I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)] = (ri[SAG_I_FLAGS] & 0xff) | (int32_t)((uint32_t)ri[SAG_I_EPISODE] << FLAG_EPISODE_SHIFT);
   if (init_task) {
     // task.reset() as run by World.reset right after rebuild (world.py:167-170):
     // `last` distances from the installed positions (go_to_goal.py:54-55,
@@ -2238,7 +2242,36 @@ __global__ void k_extract(const float* S, const int32_t* I, int N, const int32_t
   unpack_tstate((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)], ri);
   ri[SAG_I_STEP] = I[iaddr(DI_STEP, (size_t)N, (size_t)i)];
   ri[SAG_I_ENV_ID] = I[iaddr(DI_ENVID, (size_t)N, (size_t)i)];
-  ri[SAG_I_FLAGS] = I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)];
+  const uint32_t fw = (uint32_t)I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)];
+  ri[SAG_I_FLAGS] = (int32_t)(fw & 0xffu);
+  ri[SAG_I_EPISODE] = (int32_t)(fw >> FLAG_EPISODE_SHIFT);
+}
+
+// rows of an AoS record store by env id: dst[ids[j]] <- src[j] (scatter) or dst[j] <- src[ids[j]] (gather);
+// one thread per (row, 16-byte piece).  bump != 0 (sag_reset): the gathered rows' episode nonce advances,
+// in the store too
+__global__ void k_move_rows(float* dst_f, int32_t* dst_i, float* src_f, int32_t* src_i, const int32_t* ids, int n,
+                            int gather, int bump) {
+  constexpr int QF = SAG_REC_FLOATS / 4, QI = SAG_REC_INTS / 4;
+  static_assert(SAG_REC_FLOATS % 4 == 0 && SAG_REC_INTS % 4 == 0, "records are whole 16-byte pieces");
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n * (QF + QI)) return;
+  const int j = (int)(t / (QF + QI)), q = (int)(t % (QF + QI));
+  const size_t d = gather ? (size_t)j : (size_t)ids[j], s_ = gather ? (size_t)ids[j] : (size_t)j;
+  if (q < QF) reinterpret_cast<float4*>(dst_f)[d * QF + q] = reinterpret_cast<const float4*>(src_f)[s_ * QF + q];
+  else {
+    int4 v = reinterpret_cast<const int4*>(src_i)[s_ * QI + (q - QF)];
+    if (bump && q - QF == SAG_I_EPISODE / 4) {
+      (&v.x)[SAG_I_EPISODE % 4] = ((&v.x)[SAG_I_EPISODE % 4] + 1) & 0xffffff;
+      reinterpret_cast<int4*>(src_i)[s_ * QI + (q - QF)] = v;
+    }
+    reinterpret_cast<int4*>(dst_i)[d * QI + (q - QF)] = v;
+  }
+}
+// all rows of the store: episode nonce + 1 (sag_reset of every env)
+__global__ void k_bump_episode(int32_t* rec_i, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) rec_i[(size_t)j * SAG_REC_INTS + SAG_I_EPISODE] = (rec_i[(size_t)j * SAG_REC_INTS + SAG_I_EPISODE] + 1) & 0xffffff;
 }
 
 // ---------------------------------------------------------------------------

@@ -644,7 +644,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       if (p.noise) z = p.noise[i * 12 + u];
       else {
         const uint32_t env_id = (uint32_t)p.I[iaddr(DI_ENVID, N, i)], step = (uint32_t)p.I[iaddr(DI_STEP, N, i)];
-        uint32_t cc[4] = {env_id, step, (uint32_t)(u >> 1), 1u};
+        const uint32_t ep4 = ((uint32_t)p.I[iaddr(DI_FLAGS, N, i)] >> FLAG_EPISODE_SHIFT) << 2;
+        uint32_t cc[4] = {env_id, step, (uint32_t)(u >> 1), ep4 | 1u};
         philox4x32_10(cc, p.key0, p.key1);
         float z0, z1;
         box_muller(cc[0], cc[1], z0, z1);

@@ -51,7 +51,7 @@ class BatchedSafeAdaptationGym:
   BASE_SENSORS = ['accelerometer', 'velocimeter', 'gyro', 'magnetometer']
 
   def __init__(self, robot_base, n_envs=1, rgb_observation=False, config=None, devices=None,
-               parity_rng=False, device_seed=0):
+               parity_rng=False, device_seed=None):
     # rgb_observation: the observation is the robot camera's 64 x 64 x 3 uint8 image
     # (safe_adaptation_gym.py:122-126,148-149), ray-cast on the device
     self._rgb_observation = bool(rgb_observation)
@@ -63,8 +63,12 @@ class BatchedSafeAdaptationGym:
     if self.n_envs < len(self.devices):
       self.devices = self.devices[:self.n_envs]
     self._ranges = shard_ranges(self.n_envs, len(self.devices))
+    # throughput mode: the device-side generator is keyed by the env seed (seed() / reset(seed=...)) unless
+    # device_seed pins it; counter = (global env id, step, draw, episode), so noise and in-step draws differ
+    # between envs, steps, episodes and seeds
+    self._device_seed = device_seed
     self._ctx = [
-        nat.Context(self.robot.name, e - s, device=d, seed=device_seed)
+        nat.Context(self.robot.name, e - s, device=d, seed=0 if device_seed is None else device_seed)
         for (s, e), d in zip(self._ranges, self.devices)
     ]
     self._pool = ThreadPoolExecutor(len(self._ctx)) if len(self._ctx) > 1 else None
@@ -73,6 +77,7 @@ class BatchedSafeAdaptationGym:
     self._base_seed = int(np.random.randint(2**31))
     self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
     self._rs = None
+    self._key_device()
     self.action_space = Box(-1, 1, (self.robot.nu,), np.float32)
     self._observation_space = None
     self._reward_dim = 1
@@ -104,6 +109,12 @@ class BatchedSafeAdaptationGym:
     self._base_seed = int(np.random.randint(2**31)) if seed is None else int(seed)
     self._seeds = self._base_seed + np.arange(self.n_envs, dtype=np.int64)
     self._rs = None
+    self._key_device()
+
+  def _key_device(self):
+    if self._device_seed is None:
+      for c in self._ctx:
+        c.set_seed(self._base_seed)
 
   def set_task(self, task):
     """A Task instance / class (every env gets its own instance of that class) or a
@@ -118,8 +129,11 @@ class BatchedSafeAdaptationGym:
   def reset(self, *, seed=None, return_info=False, options=None):
     assert self._tasks is not None or (options is not None and 'task' in options), (
         'A task should be first set before reset.')
+    self._episode += 1
     if seed is not None:
+      self._base_seed = int(seed)
       self._seeds = int(seed) + np.arange(self.n_envs, dtype=np.int64)
+      self._key_device()
     else:
       # the reference's single env moves to seed + 1 (safe_adaptation_gym.py:97-101);
       # a batch moves every env past the whole batch so episodes never share a seed.
@@ -221,6 +235,7 @@ class BatchedSafeAdaptationGym:
       rf[:, nat.F_CATCH + 2] = self._persist['catch_cur']
       rf[:, nat.F_CATCH + 3] = self._persist['catch_next']
     self._bounds = rf[:, nat.F_BOUND].copy()
+    ri[:, nat.I_EPISODE] = self._episode & 0xffffff   # episode nonce of the device-side generator
     self._map(lambda c, s, e: c.set_layout(rf[s:e], ri[s:e]))
 
   def _pull_task_state(self):

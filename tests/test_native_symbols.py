@@ -52,7 +52,8 @@ def test_record_offsets_match_header():
                   ('REC_FLOATS', 'SAG_REC_FLOATS'), ('REC_INTS', 'SAG_REC_INTS'),
                   ('I_TASK', 'SAG_I_TASK'), ('I_NB', 'SAG_I_NB'), ('I_BOX_KIND', 'SAG_I_BOX_KIND'),
                   ('I_GOAL_BUTTON', 'SAG_I_GOAL_BUTTON'), ('I_ACTIVE_MASK', 'SAG_I_ACTIVE_MASK'),
-                  ('I_STEP', 'SAG_I_STEP'), ('I_ENV_ID', 'SAG_I_ENV_ID'), ('I_FLAGS', 'SAG_I_FLAGS')]:
+                  ('I_STEP', 'SAG_I_STEP'), ('I_ENV_ID', 'SAG_I_ENV_ID'), ('I_FLAGS', 'SAG_I_FLAGS'),
+                  ('I_EPISODE', 'SAG_I_EPISODE')]:
       assert getattr(mod, py) == int(vals[c]), (mod.__name__, py)
 
 
