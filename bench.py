@@ -182,6 +182,7 @@ def main(argv=None, run_factory=None, emit=print):
   # full and throughput is ~12 % above the 1 M-env figure (profiles/r01_v16_batch_size_sweep.txt)
   ap.add_argument('--envs', type=int, default=1 << 22, help='environments per GPU (weak scaling)')
   ap.add_argument('--task', default='go_to_goal')
+  ap.add_argument('--robot', default='point', help='point (headline) | car | doggo: profile another config as the main line')
   ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (stationary contact load)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line')
@@ -225,7 +226,8 @@ def main(argv=None, run_factory=None, emit=print):
   else:
     device = local
 
-  run = run_factory(args.task, args.envs, device, rank)
+  run = run_factory(args.task, args.envs, device, rank) if args.robot == 'point' else run_factory(
+      args.task, args.envs, device, rank, robot=args.robot)
   run.burn_in(args.burn_in)
   # timed region with per-launch HIP events on the context stream (kernel time for the roofline)
   run.timing(True)

@@ -8,7 +8,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsag.so')
-SOURCES = ['sag_api.hip', 'sag_sampler.cpp']
+SOURCES = ['sag_api.hip', 'sag_doggo_lane.hip', 'sag_sampler.cpp']
+# per-source extra flags.  sag_doggo_lane.hip: SGPR spills go to scratch memory, not to VGPR lanes - its one big
+# device function was miscompiled on that path (see the file header and DESIGN.md 3.4)
+EXTRA = {'sag_doggo_lane.hip': ['-mllvm', '-amdgpu-spill-sgpr-to-vgpr=false']}
 # every header under csrc/ (sag_device.hpp includes the Doggo, cooperative-Doggo and render headers) + the ABI
 HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, '*.hpp'))) + [
     os.path.join('..', '..', 'include', 'sag.h')]
@@ -32,13 +35,24 @@ def up_to_date():
 def build(force=False, verbose=False, extra=()):
   if not force and up_to_date():
     return LIB
-  cmd = [
-      hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared',
-      '-fno-fast-math', '-ffp-contract=off', '-Wall', '-Wno-unused-function', '-pthread', *extra, '-o', LIB
-  ] + [os.path.join(CSRC, s) for s in SOURCES]
+  base = [hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-fast-math', '-ffp-contract=off', '-Wall',
+          '-Wno-unused-function', '-pthread', *extra]
+  objdir = os.path.join(HERE, 'build')
+  os.makedirs(objdir, exist_ok=True)
+  jobs = []
+  for src in SOURCES:   # the translation units compile side by side
+    obj = os.path.join(objdir, src + '.o')
+    cmd = base + EXTRA.get(src, []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+    if verbose:
+      print(' '.join(cmd))
+    jobs.append((cmd, obj, subprocess.Popen(cmd)))
+  for cmd, obj, proc in jobs:
+    if proc.wait() != 0:
+      raise subprocess.CalledProcessError(proc.returncode, cmd)
+  link = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB] + [j[1] for j in jobs]
   if verbose:
-    print(' '.join(cmd))
-  subprocess.check_call(cmd)
+    print(' '.join(link))
+  subprocess.check_call(link)
   return LIB
 
 

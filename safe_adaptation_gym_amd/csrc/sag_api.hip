@@ -27,6 +27,11 @@
 
 using namespace sag;
 
+namespace sag {  // sag_doggo_lane.hip: the lane-per-env Doggo kernel lives in its own translation unit
+hipError_t doggo_lane_upload_model(const DgModel* m);
+void doggo_lane_launch(const StepArgs& a, int blocks, hipStream_t stream);
+}
+
 namespace {
 
 struct RobotInfo { int nu, obs_dim, nstep, nq, nv; double dt; };
@@ -370,8 +375,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     hipLaunchKernelGGL(k_doggo_physics, dim3((c->N + DC_EPW - 1) / DC_EPW), dim3(32 * DC_EPW), 0, c->stream, a, c->d_dr);
     hipLaunchKernelGGL((k_step_doggo_post<true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
   } else {  // Doggo, lane-per-env form: one (buttons + task object) instance, single launch
-    hipLaunchKernelGGL((k_step<SAG_ROBOT_DOGGO, true, true>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave),
-                       dim3(WAVE), 0, c->stream, a);
+    doggo_lane_launch(a, (c->N + a.envs_per_wave - 1) / a.envs_per_wave, c->stream);
   }
 #undef SAG_LAUNCH
 #undef SAG_LAUNCH3
@@ -483,6 +487,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
     DgModel model;
     dg_build_model(model);
     CREATE_CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dg), &model, sizeof(model)));
+    CREATE_CHK(doggo_lane_upload_model(&model));
   }
   CREATE_CHK(hipMemsetAsync(c->S, 0, N * DEV_FLOATS * sizeof(float), c->stream));
   CREATE_CHK(hipMemsetAsync(c->I, 0, N * DI_COUNT * sizeof(int32_t), c->stream));

@@ -223,7 +223,7 @@ __device__ inline int lidar_accum(double ex, double ey, double* obs) {
   double ang = atan2(ey, ex);
   if (ang < 0) ang += two_pi;  // python float %: fmod leaves |ang| < 2pi untouched, then shifts
   const double bin_size = two_pi / SAG_LIDAR_BINS;
-  int bin = (int)(ang / bin_size);
+  int bin = ang >= 0 ? (int)(ang / bin_size) : 0;   // (NaN pose: bin 0, no conversion of a NaN)
   if (bin >= SAG_LIDAR_BINS) bin -= SAG_LIDAR_BINS;
   double bin_angle = bin_size * bin;
   double sensor = (5.0 - dist > 0 ? 5.0 - dist : 0.0) / 5.0;
@@ -572,7 +572,7 @@ __device__ __attribute__((noinline)) LidarHit lidar_exact(float rxf, float ryf, 
   double a = atan2(EY, EX);
   if (a < 0) a += two_pi;
   LidarHit h;
-  h.bin = (int)(a / bin_size);
+  h.bin = a >= 0 ? (int)(a / bin_size) : 0;   // (NaN state, PhysicsError branch: bin 0, no conversion of a NaN)
   if (h.bin >= SAG_LIDAR_BINS) h.bin -= SAG_LIDAR_BINS;
   h.alias = (float)((a - bin_size * h.bin) / bin_size);
   const double D = hypot(EX, EY);
@@ -610,11 +610,15 @@ __device__ inline void lidar_point(float* lds, int lane, float rxf, float ryf, f
   const float ex = w0 * cf + w1 * sf, ey = w1 * cf - w0 * sf;
   const float dist = __builtin_amdgcn_sqrtf(ex * ex + ey * ey);   // 1 ulp: feeds the closeness value only
   const float t = angle_bins(ex, ey);
-  int bin = (int)t;
+  // NaN (the point is the robot's own position: 0 * rcp(0)), or a non-finite state: no float -> int
+  // conversion of it (undefined in C++ and poison in LLVM, whatever v_cvt_i32_f32 does with it); bin 16
+  // sends the point to the fp64 evaluation below
+  const bool t_ok = t >= 0.0f && t <= 16.0f;
+  int bin = t_ok ? (int)t : 16;
   float alias = t - (float)bin;
   float sensor = fmaxf(5.0f - dist, 0.0f) * 0.2f;
   // the fp32 estimate is off by < 4e-6 bins + 1e-6 / dist (rounding of the relative position);
-  // inside that band of a bin boundary (or NaN: the point is the robot's own position) fp64 decides
+  // inside that band of a bin boundary fp64 decides
   const float edge = fminf(alias, 1.0f - alias);
   if (!(edge * dist >= 2e-5f * dist + 1.5e-6f) || bin > 15) {
     const LidarHit h = lidar_exact(rxf, ryf, yawf, px, py);
@@ -654,7 +658,7 @@ __device__ inline void lidar_point_tilted(float* lds, int lane, const double* po
   const double two_pi = PI_D * 2, bin_size = two_pi / SAG_LIDAR_BINS;
   double a = atan2(EY, EX);
   if (a < 0) a += two_pi;
-  int bin = (int)(a / bin_size);
+  int bin = a >= 0 ? (int)(a / bin_size) : 0;
   if (bin >= SAG_LIDAR_BINS) bin -= SAG_LIDAR_BINS;
   const float alias = (float)((a - bin_size * bin) / bin_size);
   const double Dd = hypot(EX, EY);
@@ -673,12 +677,16 @@ __device__ inline void lidar_point_tilted(float* lds, int lane, const double* po
 // order of the Point/Car kernels, without the sleeping-body shortcut (every body is processed; a
 // resting body is a fixed point of the update, so the result is the same).
 // ---------------------------------------------------------------------------
+#ifndef SAG_DG_CONST_R
+#define SAG_DG_CONST_R false   // cull of the planar pair tests inside doggo_physics
+#endif
 struct DgResult {
   double qacc_lin[3], touch[8], comvel[4];
   int cost_contacts;
   uint32_t btn_mask;
 };
 
+#ifdef SAG_DOGGO_LANE_TU
 __device__ inline void dg_body_view(const DgWorld& Wd, int k, BV& V, float& c, float& s) {
   const float* B = Wd.fb[k];
   V.x = B[0]; V.y = B[1]; V.vx = B[3]; V.vy = B[4]; V.w = B[5]; V.ax = B[6]; V.ay = B[7]; V.aw = B[8];
@@ -686,6 +694,8 @@ __device__ inline void dg_body_view(const DgWorld& Wd, int k, BV& V, float& c, f
   const float* m = Wd.minv[k];
   V.m0 = m[0]; V.m1 = m[1]; V.m2 = m[2]; V.m3 = m[3]; V.m4 = m[4]; V.m5 = m[5]; V.dyn = 1;
 }
+
+#endif  // SAG_DOGGO_LANE_TU
 
 // floor friction + semi-implicit Euler + rest capture of one planar free body (the block of
 // step_body, on the [x y yaw vx vy w ax ay aw] layout)
@@ -730,6 +740,7 @@ __device__ __attribute__((noinline)) void dg_free_body_finish(float* B, bool is_
   B[0] += h * vx_; B[1] += h * vy_; B[2] += h * w_;
 }
 
+#ifdef SAG_DOGGO_LANE_TU
 __device__ __attribute__((noinline)) void doggo_physics(
     DgState& D, DgWorld& Wd, DgResult& out, lds_f64* dgL, const float* ctrl12, int nsub, float hf, const float* stx,
     const float* sty, int nP, int nB, float psz, float vsz, const BodyK& vk, const BodyK& bk, const Sol& sol0,
@@ -882,7 +893,7 @@ __device__ __attribute__((noinline)) void doggo_physics(
         BV V; float cv, sv; dg_body_view(Wd, k, V, cv, sv);
         BV St; St.x = stx[q]; St.y = sty[q]; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
         St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-        collide_shapes(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
+        collide_shapes<SAG_DG_CONST_R>(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
         Wd.fb[k][6] = V.ax; Wd.fb[k][7] = V.ay; Wd.fb[k][8] = V.aw;
       }
     }
@@ -897,7 +908,7 @@ __device__ __attribute__((noinline)) void doggo_physics(
         BV A, B; float ca, sa, cb, sb;
         dg_body_view(Wd, a, A, ca, sa);
         dg_body_view(Wd, b, B, cb, sb);
-        if (collide_shapes(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0)) {
+        if (collide_shapes<SAG_DG_CONST_R>(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0)) {
           Wd.fb[a][6] = A.ax; Wd.fb[a][7] = A.ay; Wd.fb[a][8] = A.aw;
           Wd.fb[b][6] = B.ax; Wd.fb[b][7] = B.ay; Wd.fb[b][8] = B.aw;
         }
@@ -923,7 +934,11 @@ __device__ __attribute__((noinline)) void doggo_physics(
   dg_com_vel(D, K, out.comvel);
 }
 
-enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2 };
+#endif  // SAG_DOGGO_LANE_TU
+
+// MODE_POST: Doggo only - the generic step after the wave-cooperative physics kernel (results in StepArgs::DR):
+// no physics code in the instance at all
+enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2, MODE_POST = 3 };
 // two copies of the busy bit, used alternately (StepArgs::phase): a launch reads bit 28 + phase and
 // writes bit 28 + (phase ^ 1), so the QUIET launch cannot re-flag an env for the BUSY launch of
 // the same step
@@ -935,7 +950,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
                                           const uint64_t skip_mask, const int* rows, double* dgL = nullptr) {
   constexpr int NSTAT = SAG_MAX_PILLARS + (HAS_BTN ? SAG_MAX_BUTTONS : 0);
   constexpr bool CAR = ROBOT == SAG_ROBOT_CAR, DOGGO = ROBOT == SAG_ROBOT_DOGGO;
-  static_assert(!DOGGO || MODE == MODE_ALL, "Doggo runs the single-launch form");
+  static_assert(!DOGGO || MODE == MODE_ALL || MODE == MODE_POST, "Doggo runs the single-launch form");
+  static_assert(DOGGO || MODE != MODE_POST, "MODE_POST is the Doggo post kernel");
   constexpr bool QUIET = MODE == MODE_QUIET;
   constexpr int SH_ME = CAR ? SH_CAR : SH_ROBOT;
   constexpr int OBS_DIM = DOGGO ? 104 : (CAR ? 72 : 60);
@@ -956,7 +972,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   const float4* __restrict__ S4 = reinterpret_cast<const float4*>(S);
   auto G4 = [&](int g) { return S4[(size_t)g * N + i]; };
   const bool use_hot = MODE == MODE_BUSY && p.hot != nullptr;
-  const float4* __restrict__ H4 = reinterpret_cast<const float4*>(p.hot) + (size_t)i * HOT_GROUPS;
+  const float4* __restrict__ H4 = use_hot ? reinterpret_cast<const float4*>(p.hot) + (size_t)i * HOT_GROUPS : nullptr;
   // group g of this env: from the hot record (busy kernel; g < 14 covers 0-4 and the positions at
   // 5 + (g - DG_POS)) or from the group-major state
   auto GH = [&](int g, int hslot) { return use_hot ? H4[hslot] : G4(g); };
@@ -1186,16 +1202,22 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     for (int k = 0; k < 8; k++) dgr.touch[k] = 0;
     for (int k = 0; k < 4; k++) dgr.comvel[k] = 1;
     dgr.cost_contacts = 0; dgr.btn_mask = 0;
-    const bool post = p.DR != nullptr;   // cooperative form: k_doggo_physics has run, its results are in DR and S
-    if (post) {
+    constexpr bool post = MODE == MODE_POST;   // cooperative form: k_doggo_physics has run, its results are in DR and S
+    if constexpr (post) {
       const double* dr = p.DR + (size_t)i * DR_STRIDE;
       for (int k = 0; k < 3; k++) dgr.qacc_lin[k] = dr[k];
       for (int k = 0; k < 8; k++) dgr.touch[k] = dr[3 + k];
       for (int k = 0; k < 4; k++) dgr.comvel[k] = dr[11 + k];
       dgr.cost_contacts = (int)dr[15]; dgr.btn_mask = (uint32_t)dr[16];
-    } else if (live)  // padding lanes of a partly filled wavefront stay out of the divergence union
-      doggo_physics(dgs, Wd, dgr, (lds_f64*)dgL + lane, ctrl12, nsub, h, stx, sty, nP, nB, psz, vsz, vk, bk, sol0, solb, nV,
-                    has_box, HAS_TBOX && task == SAG_TASK_HAUL_BOX);
+    } else {
+#ifdef SAG_DOGGO_LANE_TU
+      if (live)  // padding lanes of a partly filled wavefront stay out of the divergence union
+        doggo_physics(dgs, Wd, dgr, (lds_f64*)dgL + lane, ctrl12, nsub, h, stx, sty, nP, nB, psz, vsz, vk, bk, sol0, solb, nV,
+                      has_box, HAS_TBOX && task == SAG_TASK_HAUL_BOX);
+#else
+      static_assert(MODE == MODE_POST, "the lane-per-env Doggo kernel is instantiated in sag_doggo_lane.hip only");
+#endif
+    }
     cost_contacts = dgr.cost_contacts; btn_mask = dgr.btn_mask;
     float wz;
     if (!p.observe_only && live && !post) dg_store(dgs, S, (size_t)N, (size_t)i, yaw, wz);
@@ -2044,10 +2066,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_step_doggo_post(StepArgs p) {
   __shared__ float lds[LDS_FLOATS];
   const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
   const bool live = gi < p.N;
-  step_body<SAG_ROBOT_DOGGO, HAS_BTN, HAS_TBOX, MODE_ALL>(p, lds, lane, live ? gi : p.N - 1, live, base, min(WAVE, p.N - base),
-                                                           0ull, nullptr, nullptr);
+  step_body<SAG_ROBOT_DOGGO, HAS_BTN, HAS_TBOX, MODE_POST>(p, lds, lane, live ? gi : p.N - 1, live, base, min(WAVE, p.N - base),
+                                                            0ull, nullptr, nullptr);
 }
 
+#ifndef SAG_DOGGO_LANE_TU   // the rest of the file: kernels of the main translation unit (sag_api.hip)
 #ifndef SAG_QUIET_MIN_WAVES
 #define SAG_QUIET_MIN_WAVES 4
 #endif
@@ -2326,3 +2349,6 @@ __global__ void k_fill_actions(float* actions, const int32_t* I, int N, int nu, 
 }  // namespace sag
 #include "sag_render.hpp"
 #include "sag_doggo_coop.hpp"
+#else
+}  // namespace sag
+#endif  // SAG_DOGGO_LANE_TU

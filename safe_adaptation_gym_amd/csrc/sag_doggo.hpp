@@ -32,7 +32,9 @@ struct DgModel {
   double sph_p[DG_NS][3], sph_r[DG_NS];
   unsigned anc[DG_NB];            // bit a set: body a is on the path root -> b (inclusive)
 };
-__constant__ DgModel g_dg;
+// one copy per translation unit (sag_api.hip: cooperative form + post kernel; sag_doggo_lane.hip: lane-per-env
+// form); sag_create uploads the model to both
+static __constant__ DgModel g_dg;
 
 // LDS pointers keep their address space through the (non-inlined) function boundaries: a generic
 // `double*` turns every access into a flat load that takes the slow path to the LDS aperture

@@ -25,7 +25,45 @@ BOX_KIND = {
     'push_box': 1, 'push_box_scarce': 1, 'haul_box': 1, 'roll_rod': 2, 'dribble_ball': 3
 }
 OBSTACLE_PREFIXES = ['hazards', 'vases', 'gremlins', 'pillars']
-ROBOT_GEOMS = {'point': {'robot', 'pointarrow'}}
+# geoms of the robot XMLs (robot.py:20-22: every geom except `floor`); a contact counts when one side is one of these
+ROBOT_GEOMS = {
+    'point': {'robot', 'pointarrow'},
+    'car': {'robot', 'back_bumper', 'back_connector', 'front_bumper', 'front_connector', 'left', 'right', 'rear'},
+    'doggo': {'robot', 'robot2'} | {f'{p}_{i}' for p in ('aux', 'hip', 'ankle') for i in range(1, 5)},
+}
+ROBOT_ID = {'point': 0, 'car': 1, 'doggo': 2}
+ROBOT_NU = {'point': 2, 'car': 2, 'doggo': 12}
+ROBOT_OBS = {'point': 60, 'car': 72, 'doggo': 104}
+# observation columns that the scripted reference episodes pin: everything except what MuJoCo's forward pass
+# produces (accelerometer; Doggo's 8 touch forces) - the scripts leave those sensors at arbitrary / zero values
+PINNED_SENSOR_COLS = {
+    'point': list(range(50, 60)),
+    'car': list(range(50, 72)),       # + ballangvel_rear (3), ballquat_rear as 3x3 (9)
+    'doggo': list(range(51, 60)) + list(range(68, 104)),   # + 12 joint rates, 12 x (sin, cos)
+}
+# at reset the scripted bridge holds zeros in the four base sensors (placeholders), so only the extra columns
+# (identity ballquat; zero joint rates; sin 0 / cos 0 pairs) say something about the layout there
+INIT_PINNED_COLS = {'point': [], 'car': list(range(60, 72)), 'doggo': list(range(68, 104))}
+EPISODE_KEYS = None
+
+
+def episode_keys():
+  """(robot, task) of every reference episode in tests/golden/episodes.json.gz (14 Point, 2 Car, 2 Doggo)."""
+  global EPISODE_KEYS
+  if EPISODE_KEYS is None:
+    EPISODE_KEYS = [(e['robot'], e['task']) for e in load_json_gz('episodes.json.gz')]
+  return EPISODE_KEYS
+
+
+def set_robot_planar(rf, robot, yaw, wz):
+  """The scripted episodes move the robots as planar rigid bodies at their XML height: for Doggo that is the base
+  pose z = .22, quaternion about z, joints at 0, angular velocity (0, 0, wz) in the base frame."""
+  if robot == 'doggo':
+    E = 144
+    rf[E] = 0.22
+    rf[E + 1:E + 5] = [np.cos(0.5 * yaw), 0.0, 0.0, np.sin(0.5 * yaw)]
+    rf[E + 5] = 0.0
+    rf[E + 6:E + 9] = [0.0, 0.0, wz]
 
 
 def load_json_gz(name):
@@ -122,8 +160,9 @@ def base_record(task, names, keepouts, env_id=0, robot='point'):
 
 def episode_init_record(ep):
   names = ep['names']
-  rf, ri = base_record(ep['task'], names, ep['keepouts'])
+  rf, ri = base_record(ep['task'], names, ep['keepouts'], robot=ep['robot'])
   set_poses(rf, names, ep['init']['body_pos'], yaw=ep['init_robot_rot'])
+  set_robot_planar(rf, ep['robot'], ep['init_robot_rot'], 0.0)
   rf[F_ROBOT0:F_ROBOT0 + 3] = rf[F_ROBOT:F_ROBOT + 3]
   if 'goal' in ep['init']['body_pos']:
     rf[F_GOAL:F_GOAL + 2] = ep['init']['body_pos']['goal'][:2]

@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage: tools/prof.sh <tag>   (run on the GPU box from the repo root)
+# usage: [BENCH_ARGS="--robot car --task push_box --envs 1048576"] tools/prof.sh <tag>   (on the GPU box, repo root)
 # kernel-trace stats + PMC passes (separate runs, as gpurun requires) for bench.py
 set -e
 TAG=${1:-r1}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="bench.py --steps 30 --warmup 5 --no-c2 --no-cpu-baseline"
+ARGS="bench.py --steps ${STEPS:-30} --warmup 5 --no-c2 --no-cpu-baseline ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || true
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -- python3 $ARGS > /dev/null 2> $OUT/pmc1.err || true
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc2 -- python3 $ARGS > /dev/null 2> $OUT/pmc2.err || true

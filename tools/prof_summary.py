@@ -19,7 +19,7 @@ for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
       vg[k] = (r.get('VGPR_Count'), r.get('SGPR_Count'), r.get('LDS_Block_Size'), r.get('Scratch_Size'), r.get('Grid_Size'), r.get('Workgroup_Size'))
     print('== pmc', d)
     for k in acc:
-      if 'step' not in k and 'lidar' not in k and 'compact' not in k:
+      if not any(t in k for t in ('step', 'lidar', 'compact', 'doggo', 'render')):
         continue
       print(k, 'vgpr/sgpr/lds/scratch/grid/wg', vg[k])
       for c, v in acc[k].items():
