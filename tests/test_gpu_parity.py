@@ -105,6 +105,60 @@ def test_lidar_cost_empty_and_ragged(nat, oracle):
   ctx.close()
 
 
+def _mat2quat(m):
+  """Rotation matrix -> unit quaternion (w, x, y, z), largest-component branch."""
+  t = np.trace(m)
+  if t > 0:
+    s = np.sqrt(t + 1.0) * 2
+    q = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
+  else:
+    i = int(np.argmax(np.diag(m)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = np.sqrt(1.0 + m[i, i] - m[j, j] - m[k, k]) * 2
+    q = [0.0] * 4
+    q[0] = (m[k, j] - m[j, k]) / s
+    q[1 + i] = 0.25 * s
+    q[1 + j] = (m[j, i] + m[i, j]) / s
+    q[1 + k] = (m[k, i] + m[i, k]) / s
+  return np.array(q) / np.linalg.norm(q)
+
+
+def test_tilted_lidar_reference_cases_on_device(nat):
+  """The 60 tilted-base cases of tests/golden/lidar.npz (reference _lidar with a pitched / rolled robot_mat:
+  e = (d @ R)[:2] picks up -z R[2,:2], safe_adaptation_gym.py:197-216) through the device's Doggo lidar: the
+  base pose goes in as position + quaternion (sag_set_state), the points as hazards + pillars, and
+  sag_observe's obstacle lidar is compared with the fixture directly.  Tolerance: the ABI stores fp32 (pose,
+  quaternion, points: relative 6e-8, i.e. <= 3e-6 bins and 1e-6 of closeness at these ranges); the lidar value is
+  continuous across bin boundaries, so no case needs excluding."""
+  z = np.load(gu.GOLDEN + '/lidar.npz')
+  idx = [i for i in range(len(z['count'])) if abs(z['robot_mat'][i][2, 2] - 1) > 1e-15 and 0 < z['count'][i] <= 11]
+  assert len(idx) == 60
+  n = len(idx)
+  rf = np.zeros((n, nat.REC_FLOATS), np.float32)
+  ri = np.zeros((n, nat.REC_INTS), np.int32)
+  E = nat.F_ROBOT_EXT
+  for j, i in enumerate(idx):
+    b_rf, b_ri = gu.base_record('go_to_goal', [], {'robot': 0.4}, env_id=j, robot='doggo')
+    m, k, pts = z['robot_mat'][i], int(z['count'][i]), z['points'][i]
+    b_rf[0:2] = z['robot_pos'][i][:2]
+    b_rf[2] = np.arctan2(m[1, 0], m[0, 0])
+    b_rf[E] = z['robot_pos'][i][2]
+    b_rf[E + 1:E + 5] = _mat2quat(m)
+    nh = min(k, 9)
+    b_rf[nat.F_HAZARDS:nat.F_HAZARDS + 2 * nh] = pts[:nh].ravel()
+    b_rf[nat.F_PILLARS:nat.F_PILLARS + 2 * (k - nh)] = pts[nh:k].ravel()
+    b_rf[nat.F_GOAL:nat.F_GOAL + 2] = [3.0, 3.0]
+    b_ri[nat.I_NH], b_ri[nat.I_NP] = nh, k - nh
+    rf[j], ri[j] = b_rf, b_ri
+  ctx = nat.Context('doggo', n)
+  ctx.set_state(rf, ri)
+  obs = ctx.observe()
+  want = np.stack([z['obs'][i] for i in idx])
+  np.testing.assert_allclose(obs[:, :16], want, rtol=0, atol=OBS_TOL)
+  assert (want > 0).sum() > 100 and not obs[:, 16:32].any()   # (objects group empty)
+  ctx.close()
+
+
 # ----------------------------------------------------------------------------------
 # full step: lockstep against the oracle
 # ----------------------------------------------------------------------------------
@@ -119,6 +173,33 @@ def _flags_agree(dev, orc, margin, tol=1e-5):
   return int(bad.sum()), int((dev != orc).sum())
 
 
+def _lidar_e2e_bound(nat, d_rf, o_rf):
+  """Per-env bound on |lidar(device state) - lidar(oracle state)| derived from the ACTUAL state difference of
+  the two (first order, x1.5): a body at distance D seen with closeness s = (5 - D) / 5 contributes
+  s * (16 / 2 pi) * (|d rel. position| / D + |d yaw|) through the bin fraction and |d rel. position| / 5 through
+  the closeness; the lidar is a max over bodies, so the env's bound is the max over its bodies.  Replaces a
+  constant (1e-3), which is wrong in both directions: far too loose for a body 3 m away, too tight for the box a
+  car is tethered to at 0.6 m (the error scales like 1 / D)."""
+  n = len(d_rf)
+  cols = ([(nat.F_HAZARDS + 2 * k, nat.F_HAZARDS + 2 * k + 1) for k in range(nat.MAX_HAZARDS)] +
+          [(nat.F_VASES + 6 * k, nat.F_VASES + 6 * k + 1) for k in range(nat.MAX_VASES)] +
+          [(nat.F_PILLARS + 2 * k, nat.F_PILLARS + 2 * k + 1) for k in range(nat.MAX_PILLARS)] +
+          [(nat.F_BUTTONS + 2 * k, nat.F_BUTTONS + 2 * k + 1) for k in range(nat.MAX_BUTTONS)] +
+          [(nat.F_BOX, nat.F_BOX + 1), (nat.F_GOAL, nat.F_GOAL + 1)])
+  d_rob = np.hypot(d_rf[:, 0] - o_rf[:, 0], d_rf[:, 1] - o_rf[:, 1]).astype(np.float64)
+  d_yaw = np.abs(d_rf[:, 2] - o_rf[:, 2]).astype(np.float64)
+  bound = np.zeros(n)
+  for cx, cy in cols:
+    D = np.hypot(o_rf[:, cx] - o_rf[:, 0], o_rf[:, cy] - o_rf[:, 1]).astype(np.float64)
+    d_rel = d_rob + np.hypot(d_rf[:, cx] - o_rf[:, cx], d_rf[:, cy] - o_rf[:, cy])
+    s = np.clip(5.0 - D, 0, None) / 5.0
+    with np.errstate(divide='ignore', invalid='ignore'):
+      b = s * (16 / (2 * np.pi)) * (np.where(d_rel > 0, d_rel / D, 0.0) + d_yaw) + d_rel / 5.0
+    bound = np.maximum(bound, np.nan_to_num(b, nan=np.inf))
+  # + the f(state) tolerance on either side (the oracle's record is its fp64 state rounded to fp32)
+  return 1.5 * bound + 2 * OBS_TOL
+
+
 CAR_TASKS = ['go_to_goal', 'push_box', 'press_buttons', 'unsupervised', 'catch_goal', 'haul_box']
 MIXED = 'multitask'  # per-env task ids drawn by the benchmark's TaskSampler (BASELINE config 4 shape)
 
@@ -126,6 +207,18 @@ MIXED = 'multitask'  # per-env task ids drawn by the benchmark's TaskSampler (BA
 @pytest.mark.parametrize('robot,task', [('point', t) for t in LOCKSTEP_TASKS] + [('car', t) for t in CAR_TASKS] +
                          [('point', MIXED), ('car', MIXED)])
 def test_step_lockstep_vs_oracle(nat, oracle, oracle32, robot, task):
+  _lockstep(nat, oracle, oracle32, robot, task, int(os.environ.get('SAG_LOCKSTEP_SCALE', '1')))
+
+
+# The soak at its real size (8 x the envs: 1536 envs x 160 steps per case): the two cases that were marginal
+# against the old constant end-to-end lidar bound (car tethered to / pushing the box at < 1 m) and the two
+# multitask mixes
+@pytest.mark.parametrize('robot,task', [('car', 'haul_box'), ('car', MIXED), ('point', MIXED), ('car', 'push_box')])
+def test_step_lockstep_soak(nat, oracle, oracle32, robot, task):
+  _lockstep(nat, oracle, oracle32, robot, task, 8)
+
+
+def _lockstep(nat, oracle, oracle32, robot, task, scale):
   """Every step: take the device state, advance the device AND both oracle builds (fp64 =
   the specification, fp32 = same source in the device's precision) from it with identical
   action / noise / random tape, compare outputs and next state, continue from the device.
@@ -136,8 +229,9 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, robot, task):
   boundary switches a stiff contact on one substep earlier), allowed on <= 0.05 % of
   env-steps.  Discrete outputs (goal_met, done, RNG words consumed, task ints) are exact;
   cost flags are exact except where the oracle reports the decision within 1e-5 of its
-  threshold."""
-  n, T = 192 * int(os.environ.get('SAG_LOCKSTEP_SCALE', '1')), 160   # SAG_LOCKSTEP_SCALE=8: occasional soak run
+  threshold.  Observations are checked as a function of the device's own post-step state (tight) and end to
+  end against the oracle's within the bound that the actual state difference implies (_lidar_e2e_bound)."""
+  n, T = 192 * scale, 160
   rid = {'point': 0, 'car': 1}[robot]
   od = 60 if robot == 'point' else 72
   if task == MIXED:
@@ -208,7 +302,9 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, robot, task):
     f_obs = oracle.observe_batch(oracle.make_batch(d_rf, d_ri), rid, od)
     np.testing.assert_allclose(d_obs[:, :48], f_obs[:, :48], rtol=0, atol=OBS_TOL, err_msg=f'lidar step {t}')
     np.testing.assert_allclose(d_obs[:, 50:], f_obs[:, 50:], rtol=0, atol=1e-5, err_msg=f'sensors step {t}')
-    np.testing.assert_allclose(d_obs[ok, :48], o_obs[ok, :48], rtol=0, atol=1e-3, err_msg=f'lidar e2e step {t}')
+    e2e = _lidar_e2e_bound(nat, d_rf, o_rf)
+    worst = np.abs(d_obs[ok, :48] - o_obs[ok, :48]).max(1) - e2e[ok]
+    assert (worst <= 0).all(), f'lidar e2e step {t}: {worst.max():.3g} above the bound implied by the state difference'
     np.testing.assert_allclose(d_obs[ok, 50:], o_obs[ok, 50:], rtol=2e-4, atol=2e-4, err_msg=f'sensors e2e step {t}')
     # accelerometer = forward dynamics at the post-step state incl. stiff contact forces
     # (k = 2770 /s^2 per metre of penetration, b = 105 /s per m/s): checked as a function of
@@ -229,6 +325,79 @@ def test_step_lockstep_vs_oracle(nat, oracle, oracle32, robot, task):
   assert viol32 <= budget, f'{viol32} env-steps outside the fp32 tolerance'
   assert acc_bad <= 0.0005 * n * T, f'{acc_bad} accelerometer readings off on identical state'
   assert acc_e2e <= 0.005 * n * T, f'{acc_e2e} accelerometer readings off end to end'
+  ctx.close()
+
+
+# ----------------------------------------------------------------------------------
+# free-running comparison: no resynchronisation, the drift is observed and bounded
+# ----------------------------------------------------------------------------------
+DRIFT_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r02_free_running_drift.txt')
+
+
+@pytest.mark.parametrize('robot,task', [('point', 'go_to_goal'), ('car', 'push_box'), ('doggo', 'go_to_goal')])
+def test_free_running_drift(nat, oracle, robot, task):
+  """Device and fp64 oracle start from the same state and run 200 steps on the same actions, noise and random
+  tapes WITHOUT ever being resynchronised (the lockstep tests bound the one-step error only).  Contact dynamics
+  amplify rounding - a vase touched one substep earlier ends somewhere else, and a legged robot under random
+  torques is outright chaotic - so the yardstick is the oracle itself: the fp64 oracle run twice, once with its
+  state rounded to fp32 after every step (what the ABI's fp32 records do to any implementation).  Asserted:
+  (a) the device's median drift is within 3x that reference level (+ 1 mm); (b) Point / Car, whose dynamics are
+  not chaotic between contacts, keep the median env within 1 mm over 200 steps; (c) the streams of discrete outputs
+  stay statistically identical (cost-flag and goal-met agreement).  Figures go to gpurun_out/ and DESIGN.md."""
+  rid = {'point': 0, 'car': 1, 'doggo': 2}[robot]
+  nu, od = gu.ROBOT_NU[robot], gu.ROBOT_OBS[robot]
+  n, T = (64 if robot == 'doggo' else 192), 200
+  rf, ri = bu.sample_records_native(robot, task, n, seed=4242)
+  ctx = nat.Context(robot, n, seed=99)
+  ctx.set_layout(rf, ri)
+  rf, ri = ctx.get_state()
+  arr = oracle.make_batch(rf, ri)
+  arr_r = oracle.make_batch(rf, ri)   # the oracle itself with its state rounded to fp32 after every step (as the ABI stores it)
+  rng, mt = np.random.RandomState(3), np.random.RandomState(4)
+  dev_cost, orc_cost, dev_met, orc_met, dpos, rpos = [], [], [], [], [], []
+  for t in range(T):
+    if robot == 'doggo':
+      act = mt.uniform(-1, 1, size=(n, nu)).astype(np.float32)
+    else:
+      act = bu.pursuit_actions(ctx.get_state()[0], ri, rng, robot=robot)
+    noise = mt.normal(size=(n, nu)).astype(np.float32)
+    tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
+    d = ctx.step(act, noise, tape)
+    o = oracle.step_batch_full(arr, rid, act, noise, tape, obs_dim=od)
+    oracle.step_batch_full(arr_r, rid, act, noise, tape, obs_dim=od)
+    r_rf, r_ri = oracle.batch_records(arr_r)
+    arr_r = oracle.make_batch(r_rf, r_ri)
+    d_rf = ctx.get_state()[0]
+    o_rf = oracle.batch_records(arr)[0]
+    dpos.append(np.hypot(d_rf[:, 0] - o_rf[:, 0], d_rf[:, 1] - o_rf[:, 1]))
+    rpos.append(np.hypot(r_rf[:, 0] - o_rf[:, 0], r_rf[:, 1] - o_rf[:, 1]))
+    dev_cost.append(d[2]); orc_cost.append(o[2]); dev_met.append(d[4]); orc_met.append(o[4])
+  dpos, rpos = np.array(dpos), np.array(rpos)
+  dev_cost, orc_cost, dev_met, orc_met = (np.array(x) for x in (dev_cost, orc_cost, dev_met, orc_met))
+  q = lambda t: np.quantile(dpos[t], [0.5, 0.9, 0.99])
+  cost_agree = (dev_cost == orc_cost).mean()
+  met_agree = (dev_met == orc_met).mean()
+  close = (dpos[-1] < 1e-3).mean()
+  line = (f'{robot}/{task}: {n} envs x {T} steps free-running vs fp64 oracle | robot position drift [m] median/p90/p99 at '
+          f'step 50: {q(49)[0]:.2e}/{q(49)[1]:.2e}/{q(49)[2]:.2e}, step 100: {q(99)[0]:.2e}/{q(99)[1]:.2e}/{q(99)[2]:.2e}, '
+          f'step 200: {q(199)[0]:.2e}/{q(199)[1]:.2e}/{q(199)[2]:.2e} | envs within 1 mm at step 200: {close:.3f} | '
+          f'cost-flag agreement per env-step {cost_agree:.5f} (device rate {dev_cost.mean():.4f}, oracle {orc_cost.mean():.4f}) | '
+          f'goal-met agreement {met_agree:.5f} (device {int(dev_met.sum())}, oracle {int(orc_met.sum())} events) | reference level - the '
+          f'fp64 oracle against ITSELF with its state rounded to fp32 after every step: median/p90 at step 200 '
+          f'{np.median(rpos[-1]):.2e}/{np.quantile(rpos[-1], 0.9):.2e}')
+  print(line)
+  try:
+    os.makedirs(os.path.dirname(DRIFT_LOG), exist_ok=True)
+    with open(DRIFT_LOG, 'a') as f:
+      f.write(line + '\n')
+  except OSError:
+    pass
+  assert np.isfinite(dpos).all()
+  assert q(199)[0] <= 3 * np.median(rpos[-1]) + 1e-3, 'drift beyond what fp32 state storage alone causes in the oracle'
+  if robot != 'doggo':
+    assert q(199)[0] < 1e-3, 'the median env should not separate from its oracle twin'
+  assert cost_agree > (0.93 if robot == 'doggo' else 0.99) and abs(dev_cost.mean() - orc_cost.mean()) < 0.01
+  assert met_agree > 0.995
   ctx.close()
 
 
@@ -632,7 +801,8 @@ def test_parity_rng_mode_matches_reference_draw_order(nat, oracle):
 # ----------------------------------------------------------------------------------
 @pytest.mark.parametrize('robot,task', [('point', 'go_to_goal'), ('point', 'press_buttons'), ('point', 'push_box'),
                                         ('car', 'dribble_ball'), ('car', 'collect'), ('doggo', 'go_to_goal'),
-                                        ('doggo', 'roll_rod'), ('point', 'unsupervised')])
+                                        ('doggo', 'roll_rod'), ('point', 'unsupervised'),
+                                        ('doggo', 'haul_box')])   # (the last one: BASELINE config 5's own pair)
 def test_rgb_observation_matches_oracle(nat, oracle, robot, task):
   """Every pixel is a hard decision (surface hit, checker square, 8-bit rounding) evaluated in fp64
   on both sides: images agree exactly except where libm differences flip a decision - bounded to
