@@ -30,8 +30,25 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 # action 8 + robot qpos,qvel r/w 48 + 10 vases x 6 floats r/w 480 + 9 hazards, pillar,
 # goal xy 88 + task scalars r/w 16 + obs 240 + reward 4 + cost 4 + done 4
 ALG_BYTES_PER_ENV_STEP = 892
+# SURVEY 8(d) for the other configs: Car/PushBox full step; the lidar + cost kernel alone (robot 12 + 20 obstacle
+# xy 160 + goal xy 8 + 48 lidar 192 + cost 4); rgb_observation = state read + one 64x64x3 uint8 image
+ALG_BYTES = {'point': 892, 'car': 804, 'lidar_cost': 376, 'render': 64 * 64 * 3 + 736}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
+# fp64 flops of one Doggo env-step in the wave-cooperative kernel, counted by rocprofv3
+# (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes, FMA = 2), profiles/r02_doggo_flops.txt; None until measured
+DOGGO_FP64_FLOPS_PER_ENV_STEP = None
 N_ACTION_BUFS = 8
+
+
+def source_sha16():
+  """Hash of the device sources: keys profiles/traffic.json to the code it was measured on."""
+  import glob
+  import hashlib
+  h = hashlib.sha256()
+  for f in sorted(glob.glob(os.path.join(ROOT, 'safe_adaptation_gym_amd', 'csrc', '*')) + [os.path.join(ROOT, 'include', 'sag.h')]):
+    h.update(open(f, 'rb').read())
+  return h.hexdigest()[:16]
 
 
 def build_records(task, envs_per_gpu, rank, seed=666, robot='point'):
@@ -127,15 +144,25 @@ def timed(run, steps, warmup, barrier):
   return time.perf_counter() - t0
 
 
-def traffic_per_launch(envs):
+def traffic_per_launch(envs, key='point'):
   """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json:
   FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs of this same command), scaled to
-  this launch's env count.  None if no profile has been committed."""
+  this launch's env count.  None if no profile has been committed FOR THESE SOURCES: the file carries the
+  hash of the device sources it was measured on (tools/prof_steady.py) and a stale one is not quoted."""
   try:
     t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-    return t['bytes_per_env_step'] * envs
-  except (OSError, KeyError, ValueError):
+    if t.get('src_sha16') != source_sha16():
+      return None
+    return t['configs'][key]['bytes_per_env_step'] * envs
+  except (OSError, KeyError, ValueError, TypeError):
     return None
+
+
+def roofline_block(alg_bytes, envs, kernel_ms, kernel, key=None, launches=None):
+  achieved = alg_bytes * envs / (kernel_ms * 1e-3) / 1e9
+  return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+          'traffic': traffic_per_launch(envs, key) if key else None, 'kernel': kernel, 'kernel_ms': kernel_ms,
+          'launches_timed': launches, 'alg_bytes_per_unit': alg_bytes, 'units_per_launch': envs}
 
 
 def cpu_baseline(task, seconds=12.0):
@@ -216,6 +243,15 @@ def main(argv=None, run_factory=None, emit=print):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
+  def gather_ranks(x):
+    if dist is None:
+      return [x]
+    import torch
+    t = torch.zeros(world, dtype=torch.float64)
+    t[rank] = x
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t]
+
   if run_factory is None:
     from safe_adaptation_gym_amd import _native as nat
     ndev = nat.device_count()
@@ -232,15 +268,18 @@ def main(argv=None, run_factory=None, emit=print):
   # timed region with per-launch HIP events on the context stream (kernel time for the roofline)
   run.timing(True)
   elapsed = max_over_ranks(timed(run, args.steps, args.warmup, barrier))
-  k_ms, k_n = run.kernel_time_ms()
+  k_ms_rank, k_n = run.kernel_time_ms()
   # kernel_time covers warmup + timed launches; both are the same kernel on the same data
   run.timing(False)
+  k_ms = max_over_ranks(k_ms_rank)            # the roofline is quoted on the slowest rank's kernel time
+  k_ms_per_rank = gather_ranks(k_ms_rank)
   cost_rate, n_done, finite = run.stats()
   total_env_steps = world * args.envs * args.steps
   value = total_env_steps / elapsed
-  achieved = ALG_BYTES_PER_ENV_STEP * args.envs / (k_ms * 1e-3) / 1e9
+  alg = ALG_BYTES.get(args.robot, ALG_BYTES_PER_ENV_STEP)
+  achieved = alg * args.envs / (k_ms * 1e-3) / 1e9
   res = {
-      'metric': 'env-steps/sec (batched) Point/GoToGoal',
+      'metric': 'env-steps/sec (batched) Point/GoToGoal' if args.robot == 'point' else f'env-steps/sec (batched) {args.robot}/{args.task}',
       'value': value,
       'unit': 'env-steps/s',
       'n_gpus': world,
@@ -253,12 +292,12 @@ def main(argv=None, run_factory=None, emit=print):
       'dtype': 'f32',
       'data': 'synthetic',
       'config': {
-          'workload': f'point/{args.task} full step() (5 substeps + contact + reward + cost + lidar + obs), '
+          'workload': f'{args.robot}/{args.task} full step() (5 substeps + contact + reward + cost + lidar + obs), '
                       f'one layout per env from the reference sampler semantics (env i <- RandomState(666 + i)), '
                       f'{args.envs} envs per GPU, counter-based actions U(-1,1) and noise 0.01 on device',
           'envs_per_gpu': args.envs,
           'global_envs': world * args.envs,
-          'env_id_range_rank0': [0, args.envs],
+          'env_id_ranges_per_rank': [[r * args.envs, (r + 1) * args.envs] for r in range(world)],
           'parallelism': f'env-sharded x{world}, no collective',
       },
       'roofline': {
@@ -267,11 +306,13 @@ def main(argv=None, run_factory=None, emit=print):
           'peak': HBM_PEAK_GBS,
           'unit': 'GB/s',
           'frac': achieved / HBM_PEAK_GBS,
-          'traffic': traffic_per_launch(args.envs),
+          'traffic': traffic_per_launch(args.envs, args.robot),
           'kernel': 'sag::k_compact + k_step_quiet + k_step_busy (one step() = the three launches)',
           'kernel_ms': k_ms,
+          'kernel_ms_per_rank': k_ms_per_rank,
           'launches_timed': k_n,
-          'alg_bytes_per_env_step': ALG_BYTES_PER_ENV_STEP,
+          'alg_bytes_per_env_step': alg,
+          'src_sha16': source_sha16(),
       },
       'checks': {'cost_rate_last_step': cost_rate, 'done_envs': n_done, 'obs_finite': finite,
                  'goal_met_rate_last_step': getattr(run, 'met_rate', None),
@@ -293,33 +334,52 @@ def main(argv=None, run_factory=None, emit=print):
           'kernel_ms': ms,
           'note': 'BASELINE config-2 batch size (4096 envs on one GPU): latency bound, 16 envs per wavefront x 256 wavefronts'
       }
-      # the lidar + hazard-cost kernel alone on explicit poses (BASELINE config 2 "lidar + cost only";
-      # sag_lidar_cost takes host buffers: the figure includes the PCIe copies both ways)
-      rs = np.random.RandomState(0)
+      # the lidar + hazard-cost kernel alone on explicit poses (BASELINE config 2 "lidar + cost only"), device
+      # buffers, kernel-only HIP-event time: at the config's 4096 poses (launch-bound) and at 4 M (roofline)
+      lc = {}
       nK = 21
-      rob = np.concatenate([rs.uniform(-2, 2, (4096, 2)), rs.uniform(-np.pi, np.pi, (4096, 1))], 1).astype(np.float32)
-      pts = rs.uniform(-2.5, 2.5, (4096, nK, 2)).astype(np.float32)
-      grp = np.tile(np.array([1 + 128] * 8 + [1] * 12 + [2], np.uint8), (4096, 1))   # 8 hazards (+128: cost-tested), 12 vases / pillars, the goal
-      c2.ctx.lidar_cost(rob, pts, grp, want_bins=False)
-      t0 = time.perf_counter()
-      for _ in range(100):
-        c2.ctx.lidar_cost(rob, pts, grp, want_bins=False)
-      t_lc = (time.perf_counter() - t0) / 100
-      res['c2_lidar_cost_only_4096'] = {'ms_per_call': t_lc * 1e3, 'value': 4096 / t_lc, 'unit': 'env-evaluations/s',
-                                        'note': 'sag_lidar_cost (k_lidar_cost, fp64, bit-exact bins and cost flags vs the reference fixtures) on '
-                                                '4096 poses x 21 points through the host-buffer C ABI: H2D + kernel + D2H, synchronous'}
+      for n_lc in (4096, 1 << 22):
+        rs = np.random.RandomState(0)
+        rob = np.concatenate([rs.uniform(-2, 2, (n_lc, 2)), rs.uniform(-np.pi, np.pi, (n_lc, 1))], 1).astype(np.float32)
+        pts = rs.uniform(-2.5, 2.5, (n_lc, nK, 2)).astype(np.float32)
+        grp = np.tile(np.array([1 + 128] * 8 + [1] * 12 + [2], np.uint8), (n_lc, 1))   # 8 hazards (+128: cost-tested), 12 vases / pillars, the goal
+        cx = nat.Context('point', 64, device=device)
+        d = [cx.dev_alloc(x.nbytes) for x in (rob, pts, grp)]
+        for dp, x in zip(d, (rob, pts, grp)):
+          cx.dev_upload(dp, x)
+        d_lid, d_cost = cx.dev_alloc(n_lc * 48 * 4), cx.dev_alloc(n_lc)
+        for _ in range(5):
+          cx.lidar_cost_device(n_lc, nK, d[0], d[1], d[2], d_lid, None, d_cost)
+        cx.wait()
+        cx.enable_timing(True)
+        cx.kernel_time_ms(reset=True)
+        reps = 200 if n_lc == 4096 else 30
+        t0 = time.perf_counter()
+        for _ in range(reps):
+          cx.lidar_cost_device(n_lc, nK, d[0], d[1], d[2], d_lid, None, d_cost)
+        cx.wait()
+        t_lc = (time.perf_counter() - t0) / reps
+        ms, cnt = cx.kernel_time_ms(reset=True)
+        lc[str(n_lc)] = {'value': n_lc / t_lc, 'unit': 'env-evaluations/s', 'ms_per_call': t_lc * 1e3,
+                         'roofline': roofline_block(ALG_BYTES['lidar_cost'], n_lc, ms, 'sag::k_lidar_cost', 'lidar_cost', cnt)}
+        cx.close()
+      lc['note'] = ('sag_lidar_cost_device (k_lidar_cost: inputs staged through LDS, [bin][lane] ds_max tile, bit-exact bins and '
+                    'cost flags vs the reference fixtures) on n poses x 21 points resident in HBM, kernel-only time')
+      res['c2_lidar_cost_only'] = lc
       c2.close()
     if not args.no_c2:
       # BASELINE config 3 (Car / push_box), 4096 envs and a loaded batch; 804 algorithmic B/env-step
       c3 = {}
-      for n_c3 in (4096, 1 << 18):
+      for n_c3 in (4096, 1 << 22):   # the config's own batch (latency-bound) and a chip-filling one (split form)
         r3 = DeviceRun('push_box', n_c3, device, 0, robot='car')
         r3.burn_in(60)
         r3.timing(True)
-        t = timed(r3, 100, 10, lambda: None)
-        ms, _ = r3.kernel_time_ms()
-        c3[str(n_c3)] = {'value': n_c3 * 100 / t, 'kernel_ms': ms,
-                         'roofline_frac': 804 * n_c3 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        k3 = 100 if n_c3 == 4096 else 30
+        t = timed(r3, k3, 10, lambda: None)
+        ms, cnt = r3.kernel_time_ms()
+        c3[str(n_c3)] = {'value': n_c3 * k3 / t, 'unit': 'env-steps/s', 'ms_per_step': t / k3 * 1e3,
+                         'roofline': roofline_block(ALG_BYTES['car'], n_c3, ms, 'sag::k_compact + k_step_quiet<1> + k_step_busy<1>'
+                                                    if n_c3 > 393216 else 'sag::k_step<1>', 'car' if n_c3 > 393216 else None, cnt)}
         r3.close()
       res['c3_car_push_box'] = c3
       # BASELINE config 4 shape on one GPU: Doggo, multitask sampler, 4096 envs (x 8 GPUs = 32768)
@@ -328,8 +388,16 @@ def main(argv=None, run_factory=None, emit=print):
       r4.timing(True)
       t = timed(r4, 30, 5, lambda: None)
       ms, _ = r4.kernel_time_ms()
-      res['c4_doggo_multitask_4096'] = {'value': 4096 * 30 / t, 'unit': 'env-steps/s', 'kernel_ms': ms,
-                                        'note': 'per GPU; wave-cooperative fp64 articulated solve (32 lanes per env), 12 substeps'}
+      c4 = {'value': 4096 * 30 / t, 'unit': 'env-steps/s', 'kernel_ms': ms,
+            'note': 'per GPU; wave-cooperative fp64 articulated solve (32 lanes per env), 12 substeps'}
+      if DOGGO_FP64_FLOPS_PER_ENV_STEP:
+        tf = DOGGO_FP64_FLOPS_PER_ENV_STEP * 4096 / (ms * 1e-3) / 1e12
+        c4['roofline'] = {'bound': 'fp64-vector', 'achieved': tf, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': tf / FP64_VECTOR_PEAK_TFLOPS, 'traffic': None, 'kernel': 'sag::k_doggo_physics + k_step_doggo_post',
+                          'kernel_ms': ms, 'flops_per_env_step': DOGGO_FP64_FLOPS_PER_ENV_STEP,
+                          'note': 'a chain of dependent fp64 operations and LDS round trips on 2 envs per wavefront: latency-bound, '
+                                  'far from either roofline'}
+      res['c4_doggo_multitask_4096'] = c4
       r4.close()
       # BASELINE config 5 (stretch): Doggo / haul_box with rgb_observation: step + 64x64x3 render per env
       r5 = DeviceRun('haul_box', 4096, device, 0, robot='doggo')
@@ -345,7 +413,9 @@ def main(argv=None, run_factory=None, emit=print):
       t = timed(r5, 20, 2, lambda: None)
       res['c5_doggo_haul_box_rgb_4096'] = {'render_ms': t_render * 1e3, 'step_ms': t / 20 * 1e3,
                                            'value': 4096 / (t / 20 + t_render), 'unit': 'env-steps/s',
-                                           'note': 'per GPU: one step + one 64x64x3 uint8 first-person image per env'}
+                                           'roofline_render': roofline_block(ALG_BYTES['render'], 4096, t_render * 1e3, 'sag::k_render_rgb'),
+                                           'note': 'per GPU: one step + one 64x64x3 uint8 first-person image per env; the ray caster '
+                                                   'is fp64 compute per pixel (a hard decision like a lidar bin), not memory-bound'}
       r5.close()
     if not args.no_cpu_baseline:
       res['cpu_baseline'] = cpu_baseline(args.task)

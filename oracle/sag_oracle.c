@@ -435,6 +435,37 @@ static real impedance(real depth) {
 }
 
 /* u = Minv * J^T for J = [dx, dy, r x d]; returns J u */
+/* ---- N-sweep mode (diagnosis; DESIGN.md "how far is one sweep from the converged solution") -------------
+ * The specification solves every scalar constraint ONCE per forward evaluation, in a fixed order (one
+ * Gauss-Seidel sweep).  sago_set_sweeps(n > 1) repeats the sweep n times over the same constraint set as a
+ * proper projected Gauss-Seidel: every constraint keeps its accumulated force f, an update is
+ *   f <- clamp(f + (aref - a - R f) / (A + R)),  R = A (1 - d) / d   (the soft-constraint regulariser),
+ * and only the increment is applied.  With f = 0 this is the specification's one-shot formula
+ * d (aref - a) / A, so sweep 0 of the N-sweep mode IS the specification; n = 1 runs the original code. */
+static int g_sweeps = 1;
+static int g_car_sweeps = 1;   /* (study knob: plain Gauss-Seidel sweeps over the car's six floor-friction elements) */
+void sago_set_car_sweeps(int n) { g_car_sweeps = n < 1 ? 1 : n; }
+void sago_set_sweeps(int n) { g_sweeps = n < 1 ? 1 : n; }
+int sago_get_sweeps(void) { return g_sweeps; }
+#define ACC_SLOTS 8192
+static _Thread_local real g_acc[ACC_SLOTS];
+static _Thread_local int g_ai, g_sweep;
+static real* acc_slot(void) {
+  real* f = &g_acc[g_ai < ACC_SLOTS ? g_ai : ACC_SLOTS - 1];
+  g_ai++;
+  if (g_sweep == 0) *f = 0;
+  return f;
+}
+/* PGS update of one accumulated force; returns the increment */
+static real pgs_step(real* f, real aref, real a, real A, real d, real lo, real hi) {
+  real R = A * (1 - d) / d;
+  real fn = *f + (aref - a - R * *f) / (A + R);
+  fn = fn < lo ? lo : (fn > hi ? hi : fn);
+  real df = fn - *f;
+  *f = fn;
+  return df;
+}
+
 static real minv_apply(const Body* b, real dx, real dy, real rxd, real u[3]) {
   const real* m = b->minv;
   u[0] = m[0] * dx + m[1] * dy + m[2] * rxd;
@@ -475,6 +506,20 @@ static void solve_contact(Body* A, Body* B, const Contact* c, const Sol* sol) {
   real d = impedance(c->depth);
   /* separating acceleration wanted: aref = -b*vn + k*depth (vn<0 approaching) */
   real aref = -sol->bcoef * vn + sol->kcoef * c->depth;
+  if (g_sweeps > 1) {
+    real* fN = acc_slot(); real* fT = acc_slot();
+    real dfn = pgs_step(fN, aref, an, An, d, 0, (real)1e30);
+    apply_dir(A, B, nx, ny, rax, ray, rbx, rby, dfn, ua, ub);
+    real tx = -ny, ty = nx;
+    rel_at(A, B, rax, ray, rbx, rby, &vx, &vy, &ax, &ay);
+    real vt = vx * tx + vy * ty, at = ax * tx + ay * ty, At = 0;
+    if (A->dynamic) At += minv_apply(A, tx, ty, rax * ty - ray * tx, ua);
+    if (B->dynamic) At += minv_apply(B, tx, ty, rbx * ty - rby * tx, ub);
+    if (At <= 0) return;
+    real dft = pgs_step(fT, -sol->bcoef * vt, at, At, d, -sol->mu * *fN, sol->mu * *fN);
+    apply_dir(A, B, tx, ty, rax, ray, rbx, rby, dft, ua, ub);
+    return;
+  }
   real fn = d * (aref - an) / An;
   if (fn <= 0) return;
   apply_dir(A, B, nx, ny, rax, ray, rbx, rby, fn, ua, ub);
@@ -523,6 +568,19 @@ static int collide_pair(Body* A, Body* B, real ra, real rb, const Sol* base, int
  *   f = clamp_norm(-d0 m (b v + a), mu m g),  tau = clamp(-d0 I (b w + alpha), mu m g r_eff) */
 static void floor_friction(Body* b, real mass, real inertia, real reff, const Sol* sol) {
   real d0 = (real)SOL_D0;
+  if (g_sweeps > 1) {   /* accumulated (fx, fy) with the norm bound, accumulated torsion */
+    real* ax_ = acc_slot(); real* ay_ = acc_slot(); real* at_ = acc_slot();
+    real fmax_ = (real)(FRICTION_MU * GRAVITY) * mass, A = 1 / mass, R = A * (1 - d0) / d0;
+    real nx_ = *ax_ + (-sol->bcoef * b->vx - b->ax - R * *ax_) / (A + R);
+    real ny_ = *ay_ + (-sol->bcoef * b->vy - b->ay - R * *ay_) / (A + R);
+    real n2 = nx_ * nx_ + ny_ * ny_;
+    if (n2 > fmax_ * fmax_) { real sc = fmax_ / R_SQRT(n2); nx_ *= sc; ny_ *= sc; }
+    b->ax += (nx_ - *ax_) / mass; b->ay += (ny_ - *ay_) / mass;
+    *ax_ = nx_; *ay_ = ny_;
+    real dt_ = pgs_step(at_, -sol->bcoef * b->w, b->aw, 1 / inertia, d0, -fmax_ * reff, fmax_ * reff);
+    b->aw += dt_ / inertia;
+    return;
+  }
   real fx = -d0 * mass * (sol->bcoef * b->vx + b->ax);
   real fy = -d0 * mass * (sol->bcoef * b->vy + b->ay);
   real fmax = (real)(FRICTION_MU * GRAVITY) * mass;
@@ -621,6 +679,26 @@ static void box_floor_friction(World* w, const Sol* sol) {
   real vx = c * b->vx + s * b->vy, vy = -s * b->vx + c * b->vy;
   real ax = c * b->ax + s * b->ay, ay = -s * b->ax + c * b->ay;
   real fx, fy, tlim;
+  if (g_sweeps > 1) {
+    real* fx_ = acc_slot(); real* fy_ = acc_slot(); real* ft_ = acc_slot();
+    if (w->box_kind == SAG_BOX_ROD) {
+      real mx = (real)1.5 * m, lx = (real)0.05 * m * g / (real)0.08, ly = (real)1.2 * m * g;
+      ax += pgs_step(fx_, -sol->bcoef * vx, ax, 1 / mx, d0, -lx, lx) / mx;
+      ay += pgs_step(fy_, -sol->bcoef * vy, ay, 1 / m, d0, -ly, ly) / m;
+      tlim = (real)1.2 * m * g * (real)0.15;
+    } else {
+      real me = (real)1.4 * m, lim = (real)0.05 * m * g / (real)0.14, A = 1 / me, R = A * (1 - d0) / d0;
+      real nx_ = *fx_ + (-sol->bcoef * vx - ax - R * *fx_) / (A + R), ny_ = *fy_ + (-sol->bcoef * vy - ay - R * *fy_) / (A + R);
+      real n2 = nx_ * nx_ + ny_ * ny_;
+      if (n2 > lim * lim) { real sc = lim / R_SQRT(n2); nx_ *= sc; ny_ *= sc; }
+      ax += (nx_ - *fx_) / me; ay += (ny_ - *fy_) / me;
+      *fx_ = nx_; *fy_ = ny_;
+      tlim = (real)0.003 * m * g;
+    }
+    b->ax = c * ax - s * ay; b->ay = s * ax + c * ay;
+    b->aw += pgs_step(ft_, -sol->bcoef * b->w, b->aw, 1 / w->box_I, d0, -tlim, tlim) / w->box_I;
+    return;
+  }
   if (w->box_kind == SAG_BOX_ROD) {
     real mx = (real)1.5 * m;
     fx = clampr(-d0 * mx * (sol->bcoef * vx + ax), -(real)0.05 * m * g / (real)0.08, (real)0.05 * m * g / (real)0.08);
@@ -658,6 +736,12 @@ static void haul_tendon(World* w, const Sol* sol) {
   real Ainv = minv_apply(A, jx, jy, 0, ua) + minv_apply(B, jx, jy, 0, ub);
   real dimp = impedance(viol);
   /* want Lacc -> aref = -b*Ldot - k*viol */
+  if (g_sweeps > 1) {
+    real f = pgs_step(acc_slot(), -sol->bcoef * Ldot - sol->kcoef * viol, Lacc, Ainv, dimp, -(real)1e30, 0);
+    A->ax -= ua[0] * f; A->ay -= ua[1] * f; A->aw -= ua[2] * f;
+    B->ax += ub[0] * f; B->ay += ub[1] * f; B->aw += ub[2] * f;
+    return;
+  }
   real f = dimp * ((-sol->bcoef * Ldot - sol->kcoef * viol) - Lacc) / Ainv;
   if (f >= 0) return; /* a tendon only pulls */
   A->ax -= ua[0] * f; A->ay -= ua[1] * f; A->aw -= ua[2] * f;
@@ -854,23 +938,30 @@ void sago_car_constants(double out[9]) {
 /* one regularised friction direction at a contact point of the base, optionally coupled to a
  * spinning part (wheel / ball) through lever `rw` and inertia `Ispin` */
 static real car_friction(Body* r, real dx, real dy, real rx, real ry, real spin_rate, real* spin_acc,
-                         real rw, real Ispin, real limit, real bcoef) {
+                         real rw, real Ispin, real limit, real bcoef, real* facc) {
   real u[3];
   real A = minv_apply(r, dx, dy, rx * dy - ry * dx, u);
   real slip = (r->vx - r->w * ry) * dx + (r->vy + r->w * rx) * dy + rw * spin_rate;
   real sacc = (r->ax - r->aw * ry) * dx + (r->ay + r->aw * rx) * dy + rw * (spin_acc ? *spin_acc : 0);
   if (spin_acc) A += rw * rw / Ispin;
-  real f = clampr((real)SOL_D0 * (-bcoef * slip - sacc) / A, -limit, limit);
+  real f;
+  if (g_sweeps > 1 || g_car_sweeps > 1)   /* study modes: accumulated force, PGS increment */
+    f = pgs_step(g_sweeps > 1 ? acc_slot() : facc, -bcoef * slip, sacc, A, (real)SOL_D0, -limit, limit);
+  else f = clampr((real)SOL_D0 * (-bcoef * slip - sacc) / A, -limit, limit);
   r->ax += u[0] * f; r->ay += u[1] * f; r->aw += u[2] * f;
   if (spin_acc) *spin_acc += rw * f / Ispin;
   return f;
 }
 
-static void car_smooth(World* w, const real ctrl[2], const Sol* sol) {
+/* part 1: inverse inertia, centrifugal term, motor / damping of the spinning parts; part 2: floor friction sweep */
+static void car_smooth(World* w, const real ctrl[2], const Sol* sol, int part) {
   Body* r = &w->robot;
   const CarK k = car_constants();
   real h = sol->h;
   real c = R_COS(r->yaw), s = R_SIN(r->yaw);
+  real Iw = k.Iw + h * (real)CAR_JDAMP, Ib = k.Ib + h * (real)CAR_JDAMP;
+  real* acc = w->ext_acc;
+  if (part & 1) {
   /* COM offset in world axes, M = [[m,0,-m oy],[0,m,m ox],[.,.,Io]], bias = -m w^2 o */
   real ox = c * k.ox - s * k.oy, oy = s * k.ox + c * k.oy;
   real a = -k.m * oy, b = k.m * ox, m = k.m, I = k.Io;
@@ -881,27 +972,29 @@ static void car_smooth(World* w, const real ctrl[2], const Sol* sol) {
   r->ax = r->minv[0] * Fx + r->minv[1] * Fy; r->ay = r->minv[1] * Fx + r->minv[3] * Fy;
   r->aw = r->minv[2] * Fx + r->minv[4] * Fy;
   /* wheels: motor torque clip(ctrl, +-.02) (gear 1), joint damping implicit */
-  real Iw = k.Iw + h * (real)CAR_JDAMP, Ib = k.Ib + h * (real)CAR_JDAMP;
-  real* acc = w->ext_acc;
   for (int i = 0; i < 2; i++)
     acc[i] = (clampr(ctrl[i], -(real)CAR_FLIM, (real)CAR_FLIM) - (real)CAR_JDAMP * w->ext[i]) / Iw;
   for (int i = 0; i < 3; i++) acc[2 + i] = -(real)CAR_JDAMP * w->ext[2 + i] / Ib;
+  }
+  if (!(part & 2)) return;
   /* floor friction: left, right (longitudinal = body y, coupled to the wheel; lateral = body x),
    * then the caster (x coupled to -ball_y spin, y to +ball_x spin) */
   static const real PX[3] = {-0.13, 0.13, 0}, PY[3] = {0.1, 0.1, -0.1};
   real xbx = c, xby = s, ybx = -s, yby = c;
+  real facc[6] = {0, 0, 0, 0, 0, 0};
+  for (int sw = 0; sw < (g_sweeps > 1 ? 1 : g_car_sweeps); sw++)
   for (int i = 0; i < 3; i++) {
     real rx = c * PX[i] - s * PY[i], ry = s * PX[i] + c * PY[i];
     real lim = (real)FRICTION_MU * k.N[i];
     if (i < 2) {
-      car_friction(r, ybx, yby, rx, ry, w->ext[i], &acc[i], (real)CAR_RW, Iw, lim, sol->bcoef);
-      car_friction(r, xbx, xby, rx, ry, 0, NULL, 0, 1, lim, sol->bcoef);
+      car_friction(r, ybx, yby, rx, ry, w->ext[i], &acc[i], (real)CAR_RW, Iw, lim, sol->bcoef, &facc[2 * i]);
+      car_friction(r, xbx, xby, rx, ry, 0, NULL, 0, 1, lim, sol->bcoef, &facc[2 * i + 1]);
     } else {
       /* x slip = v.x - r * ball_y  -> spin variable -ball_y;  y slip = v.y + r * ball_x */
       real sy_rate = -w->ext[3], sy_acc = -acc[3];
-      car_friction(r, xbx, xby, rx, ry, sy_rate, &sy_acc, (real)CAR_RW, Ib, lim, sol->bcoef);
+      car_friction(r, xbx, xby, rx, ry, sy_rate, &sy_acc, (real)CAR_RW, Ib, lim, sol->bcoef, &facc[4]);
       acc[3] = -sy_acc;
-      car_friction(r, ybx, yby, rx, ry, w->ext[2], &acc[2], (real)CAR_RW, Ib, lim, sol->bcoef);
+      car_friction(r, ybx, yby, rx, ry, w->ext[2], &acc[2], (real)CAR_RW, Ib, lim, sol->bcoef, &facc[5]);
     }
   }
 }
@@ -933,7 +1026,7 @@ static void car_integrate_ext(World* w, real h) {
  * with prefixes consts.OBSTACLES; the box is not an obstacle) and the button contact mask. */
 static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* sol,
                          uint32_t* btn_mask) {
-  if (w->robot_id == SAG_ROBOT_CAR) car_smooth(w, ctrl, sol);
+  if (w->robot_id == SAG_ROBOT_CAR) car_smooth(w, ctrl, sol, 1);
   else if (w->robot_id == SAG_ROBOT_POINT) point_smooth(&w->robot, ctrl, e->f[SAG_F_GEAR], e->f[SAG_F_DAMP], sol->h);
   for (int k = 0; k < w->nV; k++) { w->vase[k].ax = w->vase[k].ay = w->vase[k].aw = 0; }
   w->box.ax = w->box.ay = w->box.aw = 0;
@@ -945,17 +1038,21 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
   const int has_box = w->box_kind != SAG_BOX_NONE;
   int cost_contacts = 0;
   uint32_t mask = 0;
-  if (w->robot_id == SAG_ROBOT_DOGGO) {
-    /* every robot row (limits, floor, pillars, buttons, vases, box, tether) in one PGS */
-    cost_contacts = dg_forward(w, (Doggo*)w->dg, ctrl, sol, &mask);
-    goto free_bodies;
-  }
+  /* every robot row of the Doggo (limits, floor, pillars, buttons, vases, box, tether) in one PGS of its own */
+  if (w->robot_id == SAG_ROBOT_DOGGO) cost_contacts = dg_forward(w, (Doggo*)w->dg, ctrl, sol, &mask);
+  /* the planar constraints: one sweep (the specification) or, in the study mode, g_sweeps over accumulated forces */
+  for (g_sweep = 0; g_sweep < g_sweeps; g_sweep++) {
+  g_ai = 0;
+  int cc = 0;
+  uint32_t mk = 0;
+  if (w->robot_id == SAG_ROBOT_DOGGO) goto free_bodies;
+  if (w->robot_id == SAG_ROBOT_CAR) car_smooth(w, ctrl, sol, 2);
   for (int p = 0; p < w->nP; p++)
-    cost_contacts += collide_pair(&w->robot, &w->pillar[p], w->r_robot, w->r_pillar, sol, 1);
+    cc += collide_pair(&w->robot, &w->pillar[p], w->r_robot, w->r_pillar, sol, 1);
   for (int b = 0; b < w->nB; b++)
-    if (collide_pair(&w->robot, &w->button[b], w->r_robot, w->r_button, sol, 1)) mask |= 1u << b;
+    if (collide_pair(&w->robot, &w->button[b], w->r_robot, w->r_button, sol, 1)) mk |= 1u << b;
   for (int k = 0; k < w->nV; k++)
-    cost_contacts += collide_pair(&w->robot, &w->vase[k], w->r_robot, w->r_vase, sol, 1);
+    cc += collide_pair(&w->robot, &w->vase[k], w->r_robot, w->r_vase, sol, 1);
   if (has_box) {
     if (w->box_kind == SAG_BOX_BALL) {
       /* the ball's centre is .04 above the robot sphere's: they touch at horizontal distance
@@ -975,6 +1072,7 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
     }
     if (w->haul) haul_tendon(w, sol);
   }
+  if (g_sweep == 0) { cost_contacts = cc; mask = mk; }
 free_bodies:
   for (int k = 0; k < w->nV; k++) {
     for (int p = 0; p < w->nP; p++)
@@ -994,6 +1092,8 @@ free_bodies:
   }
   for (int k = 0; k < w->nV; k++) floor_friction(&w->vase[k], w->vase_m, w->vase_I, w->vase_reff, sol);
   if (has_box) box_floor_friction(w, sol);
+  }
+  g_sweep = 0;
   if (btn_mask) *btn_mask = mask;
   return cost_contacts;
 }

@@ -698,8 +698,9 @@ int sag_lidar_cost(sag_ctx* c, int32_t n, int32_t K, const float* robot, const f
   if (n <= 0 || K < 0 || !robot || (K > 0 && (!points || !group)) || !lidar || !cost)
     return fail(c, SAG_ERR_ARG, "bad sag_lidar_cost arguments");
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  const size_t b_robot = (size_t)n * 3 * 4, b_pts = (size_t)n * K * 2 * 4, b_grp = ((size_t)n * K + 15) & ~(size_t)15,
-               b_lid = (size_t)n * 48 * 4, b_bins = (size_t)n * K * 4, b_cost = ((size_t)n + 15) & ~(size_t)15;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };   // every buffer 256-byte aligned (vector loads)
+  const size_t b_robot = up((size_t)n * 3 * 4), b_pts = up((size_t)n * K * 2 * 4), b_grp = up((size_t)n * K),
+               b_lid = up((size_t)n * 48 * 4), b_bins = up((size_t)n * K * 4), b_cost = up((size_t)n);
   int rc = ensure_scratch(c, b_robot + b_pts + b_grp + b_lid + b_bins + b_cost + 256);
   if (rc) return rc;
   char* base = (char*)c->scratch;
@@ -709,16 +710,17 @@ int sag_lidar_cost(sag_ctx* c, int32_t n, int32_t K, const float* robot, const f
   int32_t* d_bins = (int32_t*)base; base += b_bins;
   uint8_t* d_grp = (uint8_t*)base; base += b_grp;
   uint8_t* d_cost = (uint8_t*)base;
-  HIPCHK(c, hipMemcpyAsync(d_robot, robot, b_robot, hipMemcpyHostToDevice, c->stream));
+  if (lidar_cost_lds_bytes(K) > 64 * 1024) return fail(c, SAG_ERR_ARG, "K = %d points per env exceed the kernel's LDS staging (K <= 100)", K);
+  HIPCHK(c, hipMemcpyAsync(d_robot, robot, (size_t)n * 3 * 4, hipMemcpyHostToDevice, c->stream));
   if (K > 0) {
-    HIPCHK(c, hipMemcpyAsync(d_pts, points, b_pts, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_pts, points, (size_t)n * K * 2 * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_grp, group, (size_t)n * K, hipMemcpyHostToDevice, c->stream));
   }
-  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts,
+  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lidar_cost_lds_bytes(K), c->stream, n, K, d_robot, d_pts,
                      d_grp, hazard_size, d_lid, bins ? d_bins : nullptr, d_cost);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(lidar, d_lid, b_lid, hipMemcpyDeviceToHost, c->stream));
-  if (bins && K > 0) HIPCHK(c, hipMemcpyAsync(bins, d_bins, b_bins, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(lidar, d_lid, (size_t)n * 48 * 4, hipMemcpyDeviceToHost, c->stream));
+  if (bins && K > 0) HIPCHK(c, hipMemcpyAsync(bins, d_bins, (size_t)n * K * 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(cost, d_cost, (size_t)n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SAG_OK;
@@ -733,8 +735,9 @@ int sag_lidar_cost_device(sag_ctx* c, int32_t n, int32_t K, const float* d_robot
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = timing_events(c, &e0, &e1);
   if (rc) return rc;
+  if (lidar_cost_lds_bytes(K) > 64 * 1024) return fail(c, SAG_ERR_ARG, "K = %d points per env exceed the kernel's LDS staging (K <= 100)", K);
   if (e0) HIPCHK(c, hipEventRecord(e0, c->stream));
-  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, c->stream, n, K, d_robot, d_points,
+  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lidar_cost_lds_bytes(K), c->stream, n, K, d_robot, d_points,
                      d_group, hazard_size, d_lidar, d_bins, d_cost);
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipGetLastError());

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/sag.h"
 
 namespace sag {
@@ -134,7 +136,7 @@ struct StepArgs {
 // written by whichever kernel classifies an env busy for the next step (~10 % of the envs) and by
 // k_hot_refresh after an install.
 constexpr int HOT_GROUPS = 16, HOT_FLOATS = 4 * HOT_GROUPS;
-constexpr int DR_STRIDE = 20;  // qacc_lin 3, touch 8, comvel 4, cost_contacts, btn_mask, pad
+constexpr int DR_STRIDE = 20;  // qacc_lin 3, touch 8, comvel 4, cost_contacts, btn_mask, row overflow, pad
 
 // ---- constants of the Point robot (assets/xmls/point.xml) -------------------
 constexpr float PT_M_SPHERE = 4.0f / 3.0f * 3.14159265358979323846f * 0.001f;
@@ -169,6 +171,7 @@ constexpr float CAR_IO =
     2 * CAR_MW * ((3 * 0.0025f + 0.0025f) / 12 + 0.13f * 0.13f + 0.01f) + CAR_MBALL * (0.4f * 0.0025f + 0.01f);
 constexpr float CAR_IW = 0.5f * CAR_MW * 0.0025f + 0.00025f;  // axle inertia + armature (car.xml:22,26)
 constexpr float CAR_IB = 0.4f * CAR_MBALL * 0.0025f;
+constexpr int CAR_FRICTION_SWEEPS = 1;   // Gauss-Seidel sweeps over the six floor-friction elements (the specification: one; see DESIGN.md 4 for what more would buy)
 
 // ---- counter-based generator ------------------------------------------------
 __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -457,6 +460,74 @@ __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, 
   return n;
 }
 
+// The same pair tests for a compile-time shape A (the robot's footprint, a vase), organised for the wavefront:
+// one branch-free pass culls every geom pair with the bounding circles (A's geoms are constants after unrolling)
+// into a per-lane bit mask, then each lane walks ITS OWN hits in ascending (geom of A, geom of B) order - the
+// specification's order.  collide_shapes runs its 8 x 5 loop for the union of what 64 lanes need (the car pushing
+// a box: ~40 culls + ~10 narrowphases per substep); here a wavefront pays 40 straight-line culls + the maximum
+// number of hits of one lane (2 - 3).  Arithmetic per pair is collide_shapes<true>'s, so results are bit-identical.
+template <int SHA, int NB>
+__device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB, float cb, float sb, float vsz,
+                                      float rstatic, const Sol& sol) {
+  constexpr int NA = SHA == SH_ROBOT ? 2 : (SHA == SH_CAR ? 8 : 1);
+  static_assert(SHA == SH_ROBOT || SHA == SH_CAR || SHA == SH_VASE, "shapes with a compile-time geom list");
+  float bx[NB], by[NB], brr[NB];
+#pragma unroll
+  for (int gb = 0; gb < NB; gb++) {
+    const Geom b = shape_geom(shB, gb, vsz, rstatic);
+    bx[gb] = B.x + cb * b.ox - sb * b.oy; by[gb] = B.y + sb * b.ox + cb * b.oy; brr[gb] = b.r;
+  }
+  const float bound_b = shape_bound(shB, vsz, rstatic) * 1.000001f;
+  typedef typename std::conditional<(NA > 4), uint64_t, uint32_t>::type mask_t;
+  mask_t mask = 0;   // bit 8 ga + gb
+#pragma unroll
+  for (int ga = 0; ga < NA; ga++) {
+    const Geom a = shape_geom(SHA, ga, vsz, rstatic);
+    const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;
+    bool outer = true;
+    if constexpr (NB > 1) {
+      const float ex = B.x - ax, ey = B.y - ay, rb_all = a.r + bound_b;
+      outer = !(ex * ex + ey * ey > rb_all * rb_all);
+    }
+#pragma unroll
+    for (int gb = 0; gb < NB; gb++) {
+      // the ball's centre is .04 above the robot sphere's: it presents sqrt(.24^2-.04^2)-.1
+      const float rb = (SHA == SH_ROBOT && ga == 0 && shB == SH_BALL) ? 0.13664319132398464f : brr[gb];
+      const float dx = bx[gb] - ax, dy = by[gb] - ay, rs = a.r + rb;
+      const bool hit = outer && !(dx * dx + dy * dy > rs * rs);
+      mask |= (mask_t)hit << (8 * ga + gb);
+    }
+  }
+  int n = 0;
+  while (mask) {
+    const int pbit = (NA > 4 ? __ffsll((unsigned long long)mask) : __ffs((unsigned int)mask)) - 1;
+    mask &= mask - 1;
+    const int ga = NA > 1 ? pbit >> 3 : 0, gb = NB > 1 ? pbit & 7 : 0;
+    const Geom a = shape_geom(SHA, ga, vsz, rstatic);
+    Geom b = shape_geom(shB, gb, vsz, rstatic);
+    if (SHA == SH_ROBOT && ga == 0 && shB == SH_BALL) b.a = b.r = 0.13664319132398464f;
+    const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;
+    const float qx = B.x + cb * b.ox - sb * b.oy, qy = B.y + sb * b.ox + cb * b.oy;
+    if (!a.box && !b.box) n += cc_contact(A, B, ax, ay, a.a, qx, qy, b.a, sol);
+    else if (!a.box) n += cb_contact(A, B, ax, ay, a.a, qx, qy, cb, sb, b.a, b.b, true, sol);
+    else if (!b.box) n += cb_contact(B, A, qx, qy, b.a, ax, ay, ca, sa, a.a, a.b, false, sol);
+    else n += bb_contact(A, B, ax, ay, ca, sa, a.a, a.b, qx, qy, cb, sb, b.a, b.b, sol);
+  }
+  return n;
+}
+// MULTI: the other body may be the 5-geom PushBox box (instances that hold a task object); else it has one geom
+template <int SHA, bool MULTI>
+__device__ inline int collide_list(BV& A, float ca, float sa, BV& B, int shB, float cb, float sb, float vsz,
+                                   float rstatic, const Sol& sol) {
+#ifdef SAG_COLLIDE_REF   // (diagnosis: the plain loop form; results must be bit-identical - tests/diag_traj.py)
+  return collide_shapes<true>(A, SHA, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
+#endif
+  if constexpr (MULTI) {
+    if (shape_ngeom(shB) > 1) return collide_list_nb<SHA, 5>(A, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
+  }
+  return collide_list_nb<SHA, 1>(A, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
+}
+
 // ---------------------------------------------------------------------------
 // the fused step kernel (Point robot)
 // ---------------------------------------------------------------------------
@@ -684,6 +755,7 @@ struct DgResult {
   double qacc_lin[3], touch[8], comvel[4];
   int cost_contacts;
   uint32_t btn_mask;
+  int overflow;   // a constraint row did not fit into DG_MAXROWS during this step
 };
 
 #ifdef SAG_DOGGO_LANE_TU
@@ -759,7 +831,8 @@ __device__ __attribute__((noinline)) void doggo_physics(
   const float vase_r = vk.reff, box_r = shape_bound(bk.sh, vsz, 0);
   const double top_vase = 2.0 * (double)vsz;
   const double top_box = bk.sh == SH_ROD ? 0.16 : (bk.sh == SH_BALL ? 0.28 : 0.4);
-  out.cost_contacts = 0; out.btn_mask = 0;
+  out.cost_contacts = 0; out.btn_mask = 0; out.overflow = 0;
+  R.overflow = 0;
 #pragma unroll 1
   for (int sub = 0; sub <= nsub; sub++) {
     for (int k = 0; k < NBODY; k++) { Wd.fb[k][6] = 0; Wd.fb[k][7] = 0; Wd.fb[k][8] = 0; }
@@ -929,6 +1002,7 @@ __device__ __attribute__((noinline)) void doggo_physics(
   }
 #endif
 #undef DCY
+  out.overflow = R.overflow;
   for (int k = 0; k < 3; k++) out.qacc_lin[k] = K.qacc[k];
   for (int k = 0; k < 8; k++) out.touch[k] = K.touch[k];
   dg_com_vel(D, K, out.comvel);
@@ -1175,7 +1249,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   uint32_t dirty = 0;  // bodies whose state changed during this step
   int cost_contacts = 0;
   uint32_t btn_mask = 0;
-  float cy = 1, sy = 0;
+  float cy = 1, sy = 0, yaw_turn = 0;
 
   CYC(CY_LOAD);
   // Doggo: its own substep loop (doggo_physics); state in private memory
@@ -1201,14 +1275,14 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     for (int k = 0; k < 3; k++) dgr.qacc_lin[k] = 0;
     for (int k = 0; k < 8; k++) dgr.touch[k] = 0;
     for (int k = 0; k < 4; k++) dgr.comvel[k] = 1;
-    dgr.cost_contacts = 0; dgr.btn_mask = 0;
+    dgr.cost_contacts = 0; dgr.btn_mask = 0; dgr.overflow = 0;
     constexpr bool post = MODE == MODE_POST;   // cooperative form: k_doggo_physics has run, its results are in DR and S
     if constexpr (post) {
       const double* dr = p.DR + (size_t)i * DR_STRIDE;
       for (int k = 0; k < 3; k++) dgr.qacc_lin[k] = dr[k];
       for (int k = 0; k < 8; k++) dgr.touch[k] = dr[3 + k];
       for (int k = 0; k < 4; k++) dgr.comvel[k] = dr[11 + k];
-      dgr.cost_contacts = (int)dr[15]; dgr.btn_mask = (uint32_t)dr[16];
+      dgr.cost_contacts = (int)dr[15]; dgr.btn_mask = (uint32_t)dr[16]; dgr.overflow = (int)dr[17];
     } else {
 #ifdef SAG_DOGGO_LANE_TU
       if (live)  // padding lanes of a partly filled wavefront stay out of the divergence union
@@ -1219,6 +1293,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 #endif
     }
     cost_contacts = dgr.cost_contacts; btn_mask = dgr.btn_mask;
+    if (dgr.overflow) flags |= 4;   // SAG_I_FLAGS bit 2: a Doggo constraint did not fit the row budget
     float wz;
     if (!p.observe_only && live && !post) dg_store(dgs, S, (size_t)N, (size_t)i, yaw, wz);
     else { double Rm[9], ww[3]; dg_quat2mat(dgs.quat, Rm); dg_matvec(Rm, dgs.wloc, ww); yaw = (float)atan2(Rm[3], Rm[0]); wz = (float)ww[2]; }
@@ -1240,9 +1315,37 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       }
     }
   } else {
+  // Car: 1 / inertia of the spinning parts (joint damping implicit: I + h d) and 1 / (J M^-1 J^T) of the friction
+  // elements (body frame: constants up to the h-dependent spin term), once per step
+  float car_iIw = 0, car_iIb = 0, car_iA_wl = 0, car_iA_wt = 0, car_iA_bx = 0, car_iA_by = 0;
+  float car_R_wl = 0, car_R_wt = 0, car_R_bx = 0, car_R_by = 0;
+  if constexpr (CAR) {
+    constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CRW = 0.05f, AB = -CM * COY;
+    constexpr float IDC = 1.0f / (CM * (CM * CIO - AB * AB));
+    constexpr float M0 = (CM * CIO) * IDC, M2 = (-AB * CM) * IDC, M3 = (CM * CIO - AB * AB) * IDC, M5 = (CM * CM) * IDC;
+    car_iIw = 1.0f / (CAR_IW + h * 0.001f); car_iIb = 1.0f / (CAR_IB + h * 0.001f);
+    // d = body y at lever (rx, .1): rxd = rx -> A = M3 + M5 rx^2;  d = body x at (rx, ry): rxd = -ry -> A = M0 - 2 M2 ry + M5 ry^2
+    // A of an element, then R = A (1 - d0) / d0 and 1 / (A + R) (named iA below)
+    const float A_wl = M3 + M5 * 0.13f * 0.13f + CRW * CRW * car_iIw, A_wt = M0 - 2 * M2 * 0.1f + M5 * 0.1f * 0.1f;
+    const float A_bx = M0 + 2 * M2 * 0.1f + M5 * 0.1f * 0.1f + CRW * CRW * car_iIb, A_by = M3 + CRW * CRW * car_iIb;
+    constexpr float RF = (1.0f - SOL_D0) / SOL_D0;
+    car_R_wl = A_wl * RF; car_R_wt = A_wt * RF; car_R_bx = A_bx * RF; car_R_by = A_by * RF;
+    car_iA_wl = 1.0f / (A_wl + car_R_wl); car_iA_wt = 1.0f / (A_wt + car_R_wt);
+    car_iA_bx = 1.0f / (A_bx + car_R_bx); car_iA_by = 1.0f / (A_by + car_R_by);
+  }
 #pragma unroll 1
   for (int sub = 0; sub <= nsub; sub++) {
-    sincosf(yaw, &sy, &cy);
+    // heading: exact at the first substep and at the final forward evaluation (its cos / sin also serve the
+    // lidar); in between the pair is rotated by the substep's own turn h w (|h w| < .2: series to h^7; an
+    // implausible turn - non-finite state - falls back to the exact call)
+    if (sub == 0 || sub == nsub || !(fabsf(yaw_turn) < 0.25f)) sincosf(yaw, &sy, &cy);
+    else {
+      const float d2 = yaw_turn * yaw_turn;
+      const float sd = yaw_turn * (1.0f - d2 * (1.0f / 6.0f) * (1.0f - d2 * (1.0f / 20.0f) * (1.0f - d2 * (1.0f / 42.0f))));
+      const float cd = 1.0f - d2 * 0.5f * (1.0f - d2 * (1.0f / 12.0f) * (1.0f - d2 * (1.0f / 30.0f)));
+      const float c1 = cy * cd - sy * sd, s1 = sy * cd + cy * sd;
+      cy = c1; sy = s1;
+    }
     if constexpr (!CAR) {
     // robot smooth dynamics (point.xml)
     {
@@ -1267,46 +1370,60 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     } else {
       // Car (car.xml; DESIGN.md "Car"): planar base with COM offset, two driven wheels and a
-      // rear ball; floor contact = regularised Coulomb friction at the three contact points
-      constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CIW = CAR_IW, CIB = CAR_IB, CJD = 0.001f, CRW = 0.05f;
+      // rear ball; floor contact = regularised Coulomb friction at the three contact points.
+      // Evaluated in the BODY frame: there the generalised inverse inertia, the six friction directions (body x
+      // and y at the two wheels and the ball) and their levers are constants, so M^-1 J^T and J M^-1 J^T of every
+      // friction element fold at compile time (the world-frame form of the specification spends ~45 instructions
+      // per element on them; this one ~14).  Same sequential sweep: left, right, caster.
+      constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CJD = 0.001f, CRW = 0.05f;
       constexpr float CNL = CM * GRAV * (0.1f + COY) / 0.4f, CNC = CM * GRAV - 2 * CNL;
-      const float ox = -sy * COY, oy = cy * COY;
-      {
+      constexpr float AB = -CM * COY;                                  // body frame: a = -m oy, b = m ox = 0
+      constexpr float IDC = 1.0f / (CM * (CM * CIO - AB * AB));
+      constexpr float M0 = (CM * CIO) * IDC, M2 = (-AB * CM) * IDC, M3 = (CM * CIO - AB * AB) * IDC, M5 = (CM * CM) * IDC;
+      if constexpr (!QUIET) {
+        // contacts of the footprint use the world-frame inverse inertia
+        const float ox = -sy * COY, oy = cy * COY;
         const float a = -CM * oy, b = CM * ox;
         const float id = 1.0f / (CM * (CM * CIO - a * a - b * b));
         R.m0 = (CM * CIO - b * b) * id; R.m1 = (a * b) * id; R.m2 = (-a * CM) * id;
         R.m3 = (CM * CIO - a * a) * id; R.m4 = (-b * CM) * id; R.m5 = (CM * CM) * id;
-        const float Fx = CM * R.w * R.w * ox, Fy = CM * R.w * R.w * oy;
-        R.ax = R.m0 * Fx + R.m1 * Fy; R.ay = R.m1 * Fx + R.m3 * Fy; R.aw = R.m2 * Fx + R.m4 * Fy;
       }
-      const float Iw = CIW + h * CJD, Ib = CIB + h * CJD;
-      eacc[0] = (clampf(ctrl0, -0.02f, 0.02f) - CJD * ext[0]) / Iw;
-      eacc[1] = (clampf(ctrl1, -0.02f, 0.02f) - CJD * ext[1]) / Iw;
-      eacc[2] = -CJD * ext[2] / Ib; eacc[3] = -CJD * ext[3] / Ib; eacc[4] = -CJD * ext[4] / Ib;
-      // one friction direction d at lever (rx, ry), optionally coupled to a spinning part
-      auto fric = [&](float dx, float dy, float rx, float ry, float rate, float* sacc, float Isp, float lim) {
-        float u[3];
-        float A = minv_apply(R, dx, dy, rx * dy - ry * dx, u);
-        const float slip = (R.vx - R.w * ry) * dx + (R.vy + R.w * rx) * dy + (sacc ? CRW * rate : 0.f);
-        const float sa = (R.ax - R.aw * ry) * dx + (R.ay + R.aw * rx) * dy + (sacc ? CRW * *sacc : 0.f);
-        if (sacc) A += CRW * CRW / Isp;
-        const float f = clampf(SOL_D0 * (-sol0.bcoef * slip - sa) / A, -lim, lim);
-        R.ax += u[0] * f; R.ay += u[1] * f; R.aw += u[2] * f;
-        if (sacc) *sacc += CRW * f / Isp;
+      const float vbx = cy * R.vx + sy * R.vy, vby = cy * R.vy - sy * R.vx;
+      float abx = 0.f, aby = R.w * R.w * COY, aw = 0.f;             // M^-1 (centrifugal force of the offset COM)
+      eacc[0] = (clampf(ctrl0, -0.02f, 0.02f) - CJD * ext[0]) * car_iIw;
+      eacc[1] = (clampf(ctrl1, -0.02f, 0.02f) - CJD * ext[1]) * car_iIw;
+      eacc[2] = -CJD * ext[2] * car_iIb; eacc[3] = -CJD * ext[3] * car_iIb; eacc[4] = -CJD * ext[4] * car_iIb;
+      // one friction direction (dx, dy) in {body x, body y} at the constant lever (rx, ry), optionally coupled to a
+      // spinning part: projected Gauss-Seidel update of its accumulated force,
+      //   f <- clamp(f + (-b slip - a - R f) / (A + R)),  A = J M^-1 J^T [+ r_w^2 / I_spin],  R = A (1 - d0) / d0,
+      // with iAR = 1 / (A + R) = d0 / A and Rr = R from before the substep loop.  The six elements couple through
+      // the rigid base; CAR_FRICTION_SWEEPS sweeps (one leaves 10 % of a step's motion unresolved against the
+      // converged solution, two 2 %: profiles/r02_sweep_convergence.txt; oracle car_smooth)
+      auto fricb = [&](const float dx, const float dy, const float rx, const float ry, float rate, float* sacc,
+                       float iIsp, float iAR, float Rr, float lim, float& facc) {
+        const float rxd = rx * dy - ry * dx;
+        const float u0 = M0 * dx + M2 * rxd, u1 = M3 * dy, u2 = M2 * dx + M5 * rxd;
+        const float slip = (vbx - R.w * ry) * dx + (vby + R.w * rx) * dy + (sacc ? CRW * rate : 0.f);
+        const float sa = (abx - aw * ry) * dx + (aby + aw * rx) * dy + (sacc ? CRW * *sacc : 0.f);
+        const float fn = clampf(facc + (-sol0.bcoef * slip - sa - Rr * facc) * iAR, -lim, lim);
+        const float f = fn - facc;
+        facc = fn;
+        abx += u0 * f; aby += u1 * f; aw += u2 * f;
+        if (sacc) *sacc += CRW * f * iIsp;
       };
-      {
-        float rx = cy * -0.13f - sy * 0.1f, ry = sy * -0.13f + cy * 0.1f;   // left wheel
-        fric(-sy, cy, rx, ry, ext[0], &eacc[0], Iw, MU * CNL);
-        fric(cy, sy, rx, ry, 0.f, nullptr, 1.f, MU * CNL);
-        rx = cy * 0.13f - sy * 0.1f; ry = sy * 0.13f + cy * 0.1f;           // right wheel
-        fric(-sy, cy, rx, ry, ext[1], &eacc[1], Iw, MU * CNL);
-        fric(cy, sy, rx, ry, 0.f, nullptr, 1.f, MU * CNL);
-        rx = sy * 0.1f; ry = -cy * 0.1f;                                    // rear ball (0, -.1)
-        float syacc = -eacc[3];
-        fric(cy, sy, rx, ry, -ext[3], &syacc, Ib, MU * CNC);                // x slip <-> -ball_y
+      float fa0 = 0, fa1 = 0, fa2 = 0, fa3 = 0, fa4 = 0, fa5 = 0;
+#pragma unroll
+      for (int sw = 0; sw < CAR_FRICTION_SWEEPS; sw++) {
+        fricb(0.f, 1.f, -0.13f, 0.1f, ext[0], &eacc[0], car_iIw, car_iA_wl, car_R_wl, MU * CNL, fa0);   // left wheel: rolling direction
+        fricb(1.f, 0.f, -0.13f, 0.1f, 0.f, nullptr, 0.f, car_iA_wt, car_R_wt, MU * CNL, fa1);          //             lateral
+        fricb(0.f, 1.f, 0.13f, 0.1f, ext[1], &eacc[1], car_iIw, car_iA_wl, car_R_wl, MU * CNL, fa2);    // right wheel
+        fricb(1.f, 0.f, 0.13f, 0.1f, 0.f, nullptr, 0.f, car_iA_wt, car_R_wt, MU * CNL, fa3);
+        float syacc = -eacc[3];                                                                           // rear ball (0, -.1)
+        fricb(1.f, 0.f, 0.f, -0.1f, -ext[3], &syacc, car_iIb, car_iA_bx, car_R_bx, MU * CNC, fa4);      // x slip <-> -ball_y
         eacc[3] = -syacc;
-        fric(-sy, cy, rx, ry, ext[2], &eacc[2], Ib, MU * CNC);              // y slip <-> +ball_x
+        fricb(0.f, 1.f, 0.f, -0.1f, ext[2], &eacc[2], car_iIb, car_iA_by, car_R_by, MU * CNC, fa5);     // y slip <-> +ball_x
       }
+      R.ax = cy * abx - sy * aby; R.ay = sy * abx + cy * aby; R.aw = aw;
     }
     CYC(CY_ROBOT);
     cost_contacts = 0; btn_mask = 0;
@@ -1328,7 +1445,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (on && dx * dx + dyy * dyy <= rs * rs) {
         BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
         St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-        const int n = collide_shapes<!DOGGO>(R, SH_ME, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
+        const int n = collide_list<SH_ME, false>(R, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
         if (is_p) cost_contacts += n;
         else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
       }
@@ -1354,7 +1471,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       dy.ensure(k, false);
       BV V; float cv, sv; load_body(dy, k, V, cv, sv);
       const float ax0 = V.ax, ay0 = V.ay, aw0 = V.aw;
-      const int n = collide_shapes<!DOGGO>(R, SH_ME, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
+      const int n = collide_list<SH_ME, HAS_TBOX>(R, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
       if (!isb) cost_contacts += n;   // the task object is not an obstacle (consts.OBSTACLES)
       if (n) { dy.set_acc(k, V.ax, V.ay, V.aw); active |= 1u << k; }
       (void)ax0; (void)ay0; (void)aw0;
@@ -1445,7 +1562,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         BV A, B; float ca, sa, cb, sb;
         load_body(dy, a, A, ca, sa);
         load_body(dy, b, B, cb, sb);
-        const int n = collide_shapes<!DOGGO>(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0);
+        const int n = collide_list<SH_VASE, HAS_TBOX>(A, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0);
         if (n) {
           dy.set_acc(a, A.ax, A.ay, A.aw); dy.set_acc(b, B.ax, B.ay, B.aw);
           active |= 1u << a | 1u << b;
@@ -1506,16 +1623,26 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (sub == nsub) break;
     }
     R.vx += h * R.ax; R.vy += h * R.ay; R.w += h * R.aw;
-    R.x += h * R.vx; R.y += h * R.vy; yaw += h * R.w;
+    R.x += h * R.vx; R.y += h * R.vy; yaw_turn = h * R.w; yaw += yaw_turn;
     if constexpr (CAR) {
 #pragma unroll
       for (int k = 0; k < 5; k++) ext[k] += h * eacc[k];
       // ball quaternion: rate relative to the base, in base axes: q <- exp(h W / 2) q
       const float wx = ext[2], wy = ext[3], wz = ext[4];
-      const float n = sqrtf(wx * wx + wy * wy + wz * wz);
-      if (n > 0) {
-        float sn, cs; sincosf(0.5f * h * n, &sn, &cs);
-        sn /= n;
+      const float n2 = wx * wx + wy * wy + wz * wz;
+      if (n2 > 0) {
+        // exp(h W / 2) = (cos th, sin th W / |W|), th = h |W| / 2: for th < 1/2 the even series of cos th and
+        // sin th / th in th^2 (no sqrt, no division; truncation < 2e-9), else the closed form
+        const float th2 = 0.25f * h * h * n2;
+        float sn, cs;
+        if (th2 < 0.25f) {
+          cs = 1.0f - th2 * 0.5f * (1.0f - th2 * (1.0f / 12.0f) * (1.0f - th2 * (1.0f / 30.0f) * (1.0f - th2 * (1.0f / 56.0f))));
+          sn = 0.5f * h * (1.0f - th2 * (1.0f / 6.0f) * (1.0f - th2 * (1.0f / 20.0f) * (1.0f - th2 * (1.0f / 42.0f) * (1.0f - th2 * (1.0f / 72.0f)))));
+        } else {
+          const float n = sqrtf(n2);
+          sincosf(0.5f * h * n, &sn, &cs);
+          sn /= n;
+        }
         const float dw = cs, dx = sn * wx, dy_ = sn * wy, dz = sn * wz;
         const float qw = dw * ext[5] - dx * ext[6] - dy_ * ext[7] - dz * ext[8];
         const float qx = dw * ext[6] + dx * ext[5] + dy_ * ext[8] - dz * ext[7];
@@ -2298,38 +2425,154 @@ __global__ void k_bump_episode(int32_t* rec_i, int n) {
 }
 
 // ---------------------------------------------------------------------------
-// stand-alone lidar + hazard cost (BASELINE config 2): one env per lane
+// stand-alone lidar + hazard cost on explicit poses (BASELINE config 2)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_lidar_cost(int n, int K, const float* robot,
-                                                     const float* points, const uint8_t* group,
-                                                     float hazard_size, float* lidar,
-                                                     int32_t* bins, uint8_t* cost) {
-  int i = blockIdx.x * WAVE + threadIdx.x;
-  if (i >= n) return;
-  double obs[48];
-#pragma unroll
-  for (int k = 0; k < 48; k++) obs[k] = 0;
-  const double rx = robot[(size_t)i * 3], ry = robot[(size_t)i * 3 + 1], yaw = robot[(size_t)i * 3 + 2];
-  const double c = cos(yaw), s = sin(yaw);
-  int cst = 0;
-  for (int j = 0; j < K; j++) {
-    uint8_t gg = group[(size_t)i * K + j];
-    int g = gg & 127;
-    double px = points[((size_t)i * K + j) * 2], py = points[((size_t)i * K + j) * 2 + 1];
-    if (gg & 128) {
-      if (dist2d(rx, ry, px, py) <= (double)hazard_size) cst = 1;
+// (bin, alias) of the direction (ex, ey), alias = fraction of the bin.  The 11-term odd minimax polynomial gives
+// the angle INSIDE the octant, in [0, 2] bins (error 4e-10); whole bins and fraction are split there and carried
+// through the three reflections as (C - 1 - bin, 1 - fraction), so the fraction never sees the 1e-6 ulp of a
+// number near 16: |error| < 3.5e-7 bins in fp32 arithmetic (tools/fit_atan_bins.py).  NaN (ex = ey = 0) comes
+// out as a NaN alias, which fails the caller's band test and goes to the fp64 evaluation.
+__device__ inline void lidar_bin_alias(float ex, float ey, int& bin, float& alias) {
+  const float ax = fabsf(ex), ay = fabsf(ey);
+  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float q = mn / mx, z = q * q;
+  float t = 2.352551941e-03f;
+  t = t * z + -1.610619163e-02f;
+  t = t * z + 5.173371997e-02f;
+  t = t * z + -1.067070450e-01f;
+  t = t * z + 1.662277135e-01f;
+  t = t * z + -2.217355754e-01f;
+  t = t * z + 2.807958079e-01f;
+  t = t * z + -3.634874369e-01f;
+  t = t * z + 5.092729113e-01f;
+  t = t * z + -8.488255360e-01f;
+  t = t * z + 2.546479081e+00f;
+  t *= q;
+  int b = t >= 1.0f ? 1 : 0;
+  float f = t - (float)b;
+  auto reflect = [&](bool on, int C) {
+    if (on) { b = f > 0.f ? C - 1 - b : C - b; f = f > 0.f ? 1.0f - f : 0.f; }
+  };
+  reflect(ay > ax, 4);
+  reflect(ex < 0.f, 8);
+  reflect(ey < 0.f, 16);
+  bin = b; alias = f;
+}
+
+// One env per lane, 64 envs per single-wavefront workgroup, everything of the 64 envs staged through LDS so that
+// every HBM access is a coalesced 16-byte-per-lane stream:
+//   in   the workgroup's points [64][K][2] and group bytes [64][K] are contiguous in the caller's arrays: copied
+//        linearly (float4 / dword per lane) into LDS; a lane then reads ITS env's K points from LDS
+//   acc  closeness values accumulate with ds_max_i32 into a [48 bins][64 lanes] tile: the bank is the lane, so
+//        the data-dependent bin index never conflicts
+//   out  the tile is transposed through LDS into [64][49] rows and leaves as the contiguous [64][48] block
+// Arithmetic: fp32 estimate of (bin, alias) + the reference's fp64 expression inside a 2e-5-bin band of a bin
+// boundary (as the fused step does; bins are therefore always the fp64 ones), hazard test in fp32 with the fp64
+// expression within 1e-5 m^2 of the threshold (cost flags exact).  Algorithmic bytes: 376 per env at K = 21.
+constexpr int LC_TILE_A = 48 * WAVE, LC_TILE_B = WAVE * 49;   // floats
+__host__ __device__ constexpr size_t lidar_cost_in_floats(int K) { return ((size_t)WAVE * 2 * K * 4 + (size_t)WAVE * K + 15) / 16 * 4; }
+__host__ __device__ constexpr size_t lidar_cost_lds_bytes(int K) {
+  return (LC_TILE_A + (lidar_cost_in_floats(K) > (size_t)LC_TILE_B ? lidar_cost_in_floats(K) : (size_t)LC_TILE_B)) * sizeof(float);
+}
+__global__ __launch_bounds__(WAVE) void k_lidar_cost(int n, int K, const float* __restrict__ robot,
+                                                     const float* __restrict__ points, const uint8_t* __restrict__ group,
+                                                     float hazard_size, float* __restrict__ lidar,
+                                                     int32_t* __restrict__ bins, uint8_t* __restrict__ cost) {
+  HIP_DYNAMIC_SHARED(float4, lc_smem)
+  float* tile_a = reinterpret_cast<float*>(lc_smem);        // [48][64]
+  float* in_pts = tile_a + LC_TILE_A;                       // [64][K][2], then the group bytes; later tile B [64][49]
+  uint8_t* in_grp = reinterpret_cast<uint8_t*>(in_pts + (size_t)WAVE * 2 * K);
+  const int lane = threadIdx.x;
+  const size_t e0 = (size_t)blockIdx.x * WAVE;
+  const int nenv = (int)((size_t)n - e0 < (size_t)WAVE ? (size_t)n - e0 : (size_t)WAVE);
+  const size_t i = e0 + lane;
+  const bool live = lane < nenv;
+  // ---- coalesced copy in ----------------------------------------------------------------
+  {
+    const float* src = points + e0 * 2 * K;
+    const int nf = nenv * 2 * K;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      float4* d4 = reinterpret_cast<float4*>(in_pts);
+      for (int q = lane; q < nf / 4; q += WAVE) d4[q] = s4[q];
+      for (int q = (nf & ~3) + lane; q < nf; q += WAVE) in_pts[q] = src[q];
+    } else {
+      for (int q = lane; q < nf; q += WAVE) in_pts[q] = src[q];
     }
-    int b = -1;
-    double w0 = px - rx, w1 = py - ry;
-    double ex = w0 * c + w1 * s, ey = w0 * -s + w1 * c;
-    if (g == 1) b = lidar_accum(ex, ey, obs);
-    else if (g == 3) b = lidar_accum(ex, ey, obs + 16);
-    else if (g == 2) b = lidar_accum(ex, ey, obs + 32);
-    if (bins) bins[(size_t)i * K + j] = b;
+    const uint8_t* gs = group + e0 * K;
+    const int nb = nenv * K;
+    if ((reinterpret_cast<uintptr_t>(gs) & 3) == 0) {
+      const uint32_t* s32 = reinterpret_cast<const uint32_t*>(gs);
+      uint32_t* d32 = reinterpret_cast<uint32_t*>(in_grp);
+      for (int q = lane; q < nb / 4; q += WAVE) d32[q] = s32[q];
+      for (int q = (nb & ~3) + lane; q < nb; q += WAVE) in_grp[q] = gs[q];
+    } else {
+      for (int q = lane; q < nb; q += WAVE) in_grp[q] = gs[q];
+    }
   }
 #pragma unroll
-  for (int k = 0; k < 48; k++) lidar[(size_t)i * 48 + k] = (float)obs[k];
-  cost[i] = (uint8_t)cst;
+  for (int k = 0; k < 48; k++) tile_a[k * WAVE + lane] = 0.0f;
+  __syncthreads();
+  // ---- one env per lane ---------------------------------------------------------------------
+  int cst = 0;
+  if (live) {
+    const float rxf = robot[i * 3], ryf = robot[i * 3 + 1], yawf = robot[i * 3 + 2];
+    const double rx = rxf, ry = ryf, cd = cos((double)yawf), sd = sin((double)yawf);
+    const float t2 = hazard_size * hazard_size;
+    int* acc = reinterpret_cast<int*>(tile_a) + lane;
+#pragma unroll 1
+    for (int j = 0; j < K; j++) {
+      const float2 p = reinterpret_cast<const float2*>(in_pts)[lane * K + j];
+      const int gg = in_grp[lane * K + j], g = gg & 127;
+      // relative position and ego rotation in fp64 (8 operations: exact inputs, 6e-8 relative after the
+      // conversion back), everything after it in fp32
+      const double W0 = (double)p.x - rx, W1 = (double)p.y - ry;
+      if (gg & 128) {
+        const float d2 = (float)(W0 * W0 + W1 * W1);
+        bool in = d2 <= t2;
+        if (fabsf(d2 - t2) < 1e-5f) in = dist2d(rx, ry, p.x, p.y) <= (double)hazard_size;
+        cst |= in;
+      }
+      int b = -1;
+      if (g >= 1 && g <= 3) {
+        const float ex = (float)(W0 * cd + W1 * sd), ey = (float)(W0 * -sd + W1 * cd);
+        const float dist = sqrtf(ex * ex + ey * ey);
+        float alias, sensor = fmaxf(5.0f - dist, 0.0f) / 5.0f;
+        lidar_bin_alias(ex, ey, b, alias);
+        const float edge = fminf(alias, 1.0f - alias);
+        if (!(edge * dist >= 2e-5f * dist + 1.5e-6f) || b > 15) {
+          const LidarHit h = lidar_exact(rxf, ryf, yawf, p.x, p.y);
+          b = h.bin; alias = h.alias; sensor = h.sensor;
+        }
+        const int base = (g == 1 ? 0 : (g == 3 ? 16 : 32)) * WAVE;
+        atomicMax(acc + base + b * WAVE, __float_as_int(sensor));
+        atomicMax(acc + base + ((b + 1) & 15) * WAVE, __float_as_int(alias * sensor));
+        atomicMax(acc + base + ((b + 15) & 15) * WAVE, __float_as_int((1.0f - alias) * sensor));
+      }
+      if (bins) bins[i * K + j] = b;
+    }
+  }
+  __syncthreads();   // every lane is done with the staged inputs: their LDS becomes tile B
+  // ---- transpose [48][64] -> [64][49] and leave as one contiguous block ---------------------------
+  float* tile_b = in_pts;
+#pragma unroll
+  for (int k = 0; k < 48; k++) tile_b[lane * 49 + k] = tile_a[k * WAVE + lane];
+  __syncthreads();
+  {
+    float* dst = lidar + e0 * 48;
+    const int nq = nenv * 12;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int q = lane; q < nq; q += WAVE) {
+        const int env = (int)(((uint32_t)q * 43691u) >> 19);   // q / 12, exact for q < 768
+        const float* t = tile_b + env * 49 + 4 * (q - 12 * env);
+        d4[q] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    } else {
+      for (int q = lane; q < nenv * 48; q += WAVE) { const int env = q / 48; dst[q] = tile_b[env * 49 + (q - 48 * env)]; }
+    }
+  }
+  if (live) cost[i] = (uint8_t)cst;
 }
 
 // synthetic policy: U(-1,1)^nu from Philox stream 2

@@ -423,14 +423,14 @@ struct DgWorld {
   uint32_t valid;   // free bodies that exist
 };
 
-struct DgRows { DgRow row[DG_MAXROWS]; int n; };
+struct DgRows { DgRow row[DG_MAXROWS]; int n; int overflow; };  // overflow: a row did not fit (reported as record flag bit 2)
 
 // Row from right-hand-side slot `slot` of K.xs: J (as stored, fp32) was written there and solved in
 // place, so the slot now holds W = M^-1 J^T.  The other body (if any) moves along (dx, dy) at lever
 // (px, py) - its centre.
 __device__ __attribute__((noinline)) DgRow* dg_add_row(DgRows& R, const DgWork& K, const DgWorld& Wd, const float* Jf,
                                                        int slot, int other, double dx, double dy, double px, double py) {
-  if (R.n >= DG_MAXROWS) return nullptr;
+  if (R.n >= DG_MAXROWS) { R.overflow = 1; return nullptr; }
   DgRow& r = R.row[R.n++];
   double A = 0;
   for (int i = 0; i < DG_NV; i++) {
@@ -485,7 +485,7 @@ __device__ inline double dg_row_acc(const DgRow& r, const DgWorld& Wd, const dou
 __device__ __attribute__((noinline)) void dg_add_contact(DgRows& R, const DgState& D, const DgWork& K, const DgWorld& Wd,
                                                          const double* qd, int s, const double* n, const double* c,
                                                          double depth, int other, double bcoef, double kcoef, double mu) {
-  if (R.n + 3 > DG_MAXROWS) return;
+  if (R.n + 3 > DG_MAXROWS) { R.overflow = 1; return; }
   const int b = g_dg.sph_body[s];
   const int first = R.n;
   double dir[3][3];

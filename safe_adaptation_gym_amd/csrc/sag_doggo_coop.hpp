@@ -260,7 +260,7 @@ __device__ __attribute__((noinline)) void dc_cholesky(int hf, int u) {
 #pragma unroll
     for (int k = 0; k < DG_NV; k++) rj = k == j ? row[k] : rj;
     if (u == j) {
-      if (!(rj > 0)) E.flag = 1;
+      if (!(rj > 0)) E.flag |= 1;
       E.col[0] = sqrt(rj);
     }
     __syncthreads();
@@ -545,6 +545,7 @@ __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int& nro
   const int excl = dc_scan32(cnt, u, total);
   if (total == 0) return 0;
   const int fit = min(total, (DC_ROWS - nrows) / 3);
+  if (fit < total && u == 0) E.flag |= 2;   // a contact did not fit the row budget (reported, not silent)
   for (int k = 0; k < cnt; k++) {
     const int idx = excl + k;
     if (idx < fit) {
@@ -690,6 +691,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       int total;
       const int excl = dc_scan32(sign != 0 ? 1 : 0, u, total);
       const int fit = min(total, DC_ROWS - nrows);
+      if (fit < total && u == 0) E.flag |= 2;
       if (sign != 0 && excl < fit) {
         const int r = nrows + excl;
         for (int k = 0; k < DG_NV; k++) E.rJ[r][k] = k == 6 + u ? (float)sign : 0.f;
@@ -707,6 +709,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       int total;
       const int excl = dc_scan32(depth > 0 ? 1 : 0, u, total);
       const int fit = min(total, (DC_ROWS - nrows) / 3);
+      if (fit < total && u == 0) E.flag |= 2;
       if (depth > 0 && excl < fit) {
         const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dg.sph_r[u])};
         dc_contact_rows(hf, nrows + 3 * excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
@@ -740,6 +743,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       if (near(E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], box_r))
         dc_collide_body(hf, u, nrows, BOX_ID, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], E.wfb[BOX_ID][2], box_r, W.vsz, 0.f,
                         top_box, (double)W.solb.bcoef, (double)W.solb.kcoef, (double)W.solb.mu);
+      if (W.haul && nrows >= DC_ROWS && u == 0) E.flag |= 2;
       if (W.haul && nrows < DC_ROWS) {   // haul_box.py:21-29: tendon base site <-> box site (z .2), range [0, .75]
         const double dx = (double)E.wfb[BOX_ID][0] - E.pos[0], dy = (double)E.wfb[BOX_ID][1] - E.pos[1], dz = 0.2 - E.pos[2];
         const double d2 = dx * dx + dy * dy, Lt = sqrt(d2 + dz * dz), viol = Lt - 0.75;
@@ -894,7 +898,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         const double nn = sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
         for (int k = 0; k < 4; k++) E.quat[k] = o[k] / nn;
       }
-      if (E.flag) E.pos[0] = __longlong_as_double(0x7ff8000000000000ll);   // not positive definite: PhysicsError
+      if (E.flag & 1) E.pos[0] = __longlong_as_double(0x7ff8000000000000ll);   // not positive definite: PhysicsError
     }
     __syncthreads();
   }
@@ -913,7 +917,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         for (int j = 3; j < DG_NV; j++) P += E.Mlin[k][j] * E.qdv[j];
         dr[13 + k] = P / m;
       }
-      dr[15] = (double)cost_contacts; dr[16] = (double)btn_mask;
+      dr[15] = (double)cost_contacts; dr[16] = (double)btn_mask; dr[17] = (E.flag & 2) ? 1.0 : 0.0;
     }
     if (!p.observe_only) {
       if (u == 0) {

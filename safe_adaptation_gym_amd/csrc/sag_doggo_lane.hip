@@ -9,7 +9,7 @@
 //     clean and bit-identical to the shipped kernel's GPU results,
 //   * -O1, or -mllvm -amdgpu-spill-sgpr-to-vgpr=false at -O3, make the GPU results of the changed source
 //     bit-identical to them as well, and the machine verifier is silent
-// (tests/diag_doggo_variant.py).  That puts the fault in the backend's SGPR-spill-to-VGPR-lane path
+// (tests/diag_traj.py).  That puts the fault in the backend's SGPR-spill-to-VGPR-lane path
 // for this function, not in the source.  This unit is therefore built with SGPR spills going to scratch memory
 // (build.py: LANE_TU_FLAGS); applied to the whole library the same switch costs the Point kernels 50 %.
 #define SAG_DOGGO_LANE_TU 1

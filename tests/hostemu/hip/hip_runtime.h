@@ -51,6 +51,7 @@ extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const voi
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define address_space(n) unused   // __attribute__((address_space(3))) -> __attribute__((unused))
+#define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(hostemu::g_blk.dyn_smem);
 
 // ---- vector types ---------------------------------------------------------------------------------
 struct float2 { float x, y; };
@@ -85,6 +86,7 @@ struct Block {
   uint64_t xchg[1024];
   unsigned long progress = 0;  // bumped whenever a rendezvous completes or a lane finishes
   const std::function<void()>* body = nullptr;
+  void* dyn_smem = nullptr;    // dynamic LDS of the launch (malloc'ed: ASan checks its bounds)
 };
 
 inline Block g_blk;
@@ -227,12 +229,14 @@ inline void run_block() {
   g_cur = nullptr;
 }
 
-inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   Block& B = g_blk;
+  B.dyn_smem = shmem ? aligned_alloc(16, (shmem + 15) & ~(size_t)15) : nullptr;
   if (block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1 || block.x > 1024) { fprintf(stderr, "hostemu: 1-D launches of <= 1024 threads only\n"); abort(); }
   B.nthreads = (int)block.x; B.block_dim = block; B.grid_dim = grid; B.body = &body;
   for (unsigned b = 0; b < grid.x; b++) { B.block_idx = {b, 0, 0}; run_block(); }
   B.body = nullptr;
+  free(B.dyn_smem); B.dyn_smem = nullptr;
 }
 
 }  // namespace hostemu
@@ -342,7 +346,7 @@ static inline hipError_t hipMemcpyFromSymbol(void* dst, const void* sym, size_t 
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                         \
   do {                                                                                      \
-    (void)(shmem); (void)(stream);                                                          \
+    (void)(stream);                                                                         \
     const std::function<void()> hostemu_body_ = [&]() { (kernel)(__VA_ARGS__); }; \
-    hostemu::launch((grid), (block), hostemu_body_);                                        \
+    hostemu::launch((grid), (block), (size_t)(shmem), hostemu_body_);                       \
   } while (0)

@@ -273,6 +273,12 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
     for wf in [46] + [81 + 6 * k + 5 for k in range(10)]:
       tol32[wf] = 2e-4
       tol64[wf] = 2e-4
+    if robot == 'car':
+      # the rear ball (2.6 g, I = 2.6e-6 kg m^2, joint damping 1e-3: time constant I / d = 2.6 ms < h) and the wheels
+      # are stiff spinning parts: the fp32 oracle (world-frame friction, divisions) and the device (body-frame
+      # constants, reciprocals) round differently by an ulp per operation, amplified here ~100x; values are O(10) rad/s
+      for wf in range(144, 149):
+        tol32[wf] = 2e-4
     if task in ('dribble_ball', MIXED):
       # the ball's spin (unobservable; I = 4.5e-8 kg m^2) is set by friction torques of a stiff,
       # underdamped contact (solref .018 .2): fp32 rounding is amplified ~1000x there

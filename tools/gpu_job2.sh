@@ -5,7 +5,7 @@ export PYTHONPATH=$PWD:$PWD/tests SAG_DOGGO_COOP=0
 for v in "" v0 v1 v2 v4; do
   lib=$PWD/safe_adaptation_gym_amd/libsag${v:+_$v}.so
   echo "== ${v:-shipping}"
-  SAG_LIB=$lib timeout -k 10 120 python tests/diag_doggo_variant.py gpurun_out/diag/gpu_${v:-ship}.npz 30 2>&1 | tail -8
+  SAG_LIB=$lib timeout -k 10 120 python tests/diag_traj.py gpurun_out/diag/gpu_${v:-ship}.npz 30 2>&1 | tail -8
 done
 unset SAG_DOGGO_COOP
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r02_gputest2.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02_gputest2.log

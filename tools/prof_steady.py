@@ -1,13 +1,17 @@
 """Steady-state figures from a tools/prof.sh output directory: only the LAST `n` steps of the run
 (bench.py ages the population for 200 steps first; young steps are cheaper and would bias a mean
 over all dispatches).
-  python tools/prof_steady.py gpurun_out/prof_<tag> [n=30] [envs] -> text + profiles/traffic.json body"""
+  python tools/prof_steady.py gpurun_out/prof_<tag> [n=30] [envs] [key=point] -> text; the traffic figure is merged
+into profiles/traffic.json under configs[key], keyed to the hash of the device sources (bench.source_sha16): bench.py
+quotes it as roofline.traffic only while the sources are the ones it was measured on."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 out = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 envs = int(sys.argv[3]) if len(sys.argv) > 3 else 1 << 22
-KEYS = ('k_compact', 'k_step_quiet', 'k_step_busy')
+ckey = sys.argv[4] if len(sys.argv) > 4 else 'point'
+ALG = {'point': 892, 'car': 804, 'lidar_cost': 376}.get(ckey, 892)
+KEYS = ('k_lidar_cost',) if ckey == 'lidar_cost' else ('k_compact', 'k_step_quiet', 'k_step_busy')
 
 
 def key_of(name):
@@ -35,8 +39,8 @@ if tr:
       dur[k].append(rows[k][s][1] - rows[k][s][0])
   print(f'kernel trace, last {n} of {steps} steps: step span (compact start .. last kernel end) '
         f'{sum(span) / n / 1e3:.1f} us; ' + '; '.join(f'{k} {sum(dur[k]) / n / 1e3:.1f} us' for k in KEYS))
-  print(f'  algorithmic 892 B x {envs} envs / span = {892 * envs / (sum(span) / n) :.0f} GB/s = '
-        f'{892 * envs / (sum(span) / n) / 8000:.4f} of 8 TB/s')
+  print(f'  algorithmic {ALG} B x {envs} envs / span = {ALG * envs / (sum(span) / n) :.0f} GB/s = '
+        f'{ALG * envs / (sum(span) / n) / 8000:.4f} of 8 TB/s')
 
 res = {}
 for d, cname in (('pmc3', 'FETCH_SIZE'), ('pmc4', 'WRITE_SIZE')):
@@ -54,8 +58,23 @@ if len(res) == 2:
   fetch = 2 * sum(res['FETCH_SIZE'].values()) * 1024   # gfx950: 128-B requests counted as 64 B
   write = sum(res['WRITE_SIZE'].values()) * 1024
   print(f'HBM traffic per step: fetch {fetch / 1e6:.1f} MB (x2 corrected) + write {write / 1e6:.1f} MB = '
-        f'{(fetch + write) / envs:.1f} B per env-step (algorithmic 892)')
-  print(json.dumps({'envs': envs, 'last_launches': n,
-                    'FETCH_SIZE_KB_per_step': res['FETCH_SIZE'], 'WRITE_SIZE_KB_per_step': res['WRITE_SIZE'],
-                    'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact',
-                    'bytes_per_env_step': (fetch + write) / envs}, indent=1))
+        f'{(fetch + write) / envs:.1f} B per env-step (algorithmic {ALG})')
+  entry = {'envs': envs, 'last_launches': n, 'FETCH_SIZE_KB_per_step': res['FETCH_SIZE'], 'WRITE_SIZE_KB_per_step': res['WRITE_SIZE'],
+           'correction': 'gfx950: FETCH_SIZE counts 128-B requests at 64 B (MI355X_MICROARCH.md, HBM) -> x2; WRITE_SIZE exact',
+           'bytes_per_env_step': (fetch + write) / envs, 'source': os.path.basename(os.path.normpath(out))}
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, root)
+  import bench
+  sha = bench.source_sha16()
+  path = os.path.join(root, 'profiles', 'traffic.json')
+  try:
+    doc = json.load(open(path))
+    if doc.get('src_sha16') != sha:
+      doc = {}
+  except (OSError, ValueError):
+    doc = {}
+  doc.setdefault('configs', {})[ckey] = entry
+  doc['src_sha16'] = sha
+  json.dump(doc, open(path, 'w'), indent=1)
+  print(json.dumps(entry, indent=1))
+  print('merged into', path, 'for sources', sha)
