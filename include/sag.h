@@ -262,6 +262,18 @@ int sag_debug_doggo_coop(sag_ctx* ctx, double* out);
 int sag_render_rgb(sag_ctx* ctx, uint8_t* out);
 int sag_render_rgb_device(sag_ctx* ctx, void* d_out);
 
+/* Human / debugging view (safe_adaptation_gym.py:109-111 render() with render_options, render.py,
+ * mujoco_bridge.py:126-153): the same device ray caster with any of the scene's cameras -
+ *   camera 0 the robot's `vision` camera, 1 `fixednear` (pos 0 -2 2, zaxis 0 -1 1), 2 `fixedfar` (0 -5 5),
+ *          3 `track` (fixednear's view, following the robot body)
+ * any image size, and with flags & 1 the overlays of render_lidars_and_collision: three rings of 16 spheres above
+ * the robot (obstacles red, goal green, objects blue; alpha = min(1, lidar value + .1), safe_adaptation_gym.py:239-257)
+ * and the red cost sphere.  out[n_envs][height][width][3] uint8, row 0 = top.  sag_render shows the observation / cost
+ * of the context's last host-buffer step; the device variant takes them as (device) pointers or NULL. */
+int sag_render(sag_ctx* ctx, int32_t camera, int32_t width, int32_t height, int32_t flags, uint8_t* out);
+int sag_render_device(sag_ctx* ctx, int32_t camera, int32_t width, int32_t height, int32_t flags,
+                      const float* d_obs, const uint8_t* d_cost, void* d_out);
+
 /* Diagnostic: how many envs the last split step handed to the busy kernel (0 for the
  * single-kernel form).  Synchronises the context stream. */
 int sag_busy_count(sag_ctx* ctx, int32_t* count);

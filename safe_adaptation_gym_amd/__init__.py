@@ -11,14 +11,12 @@ def make(robot_name: str,
          config: Optional[Dict] = None,
          rgb_observation: bool = False,
          render_options: Optional[Dict] = None,
-         render_lidar_and_collision=False,
+         render_lidar_and_collision=True,
          n_envs: int = 1,
          devices=None,
          parity_rng: bool = False):
   from safe_adaptation_gym_amd.benchmark import ROBOTS_BASENAMES, TASKS
   from safe_adaptation_gym_amd.envs import BatchedSafeAdaptationGym
-  if render_lidar_and_collision or render_options:
-    raise NotImplementedError('human visualisation is out of scope for this build')
   env = BatchedSafeAdaptationGym(
       ROBOTS_BASENAMES[robot_name.lower()],
       n_envs=n_envs,
@@ -26,7 +24,8 @@ def make(robot_name: str,
       rgb_observation=rgb_observation,
       devices=devices,
       parity_rng=parity_rng,
-      device_seed=seed)
+      render_lidars_and_collision=render_lidar_and_collision,
+      render_options=render_options)
   env.seed(seed)
   if task_name is not None:
     env.set_task(TASKS[task_name.lower()])

@@ -31,7 +31,7 @@ EXPORTS = [
     'sag_robot_info', 'sag_create', 'sag_destroy', 'sag_last_error', 'sag_set_layout',
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
     'sag_observe', 'sag_lidar_cost', 'sag_lidar_cost_device', 'sag_set_seed', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
-    'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device', 'sag_debug_doggo_coop',
+    'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device', 'sag_render', 'sag_render_device', 'sag_debug_doggo_coop',
     'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts'
 ]
 
@@ -96,6 +96,8 @@ def load():
   lib.sag_busy_count.argtypes = [vp, C.POINTER(C.c_int32)]
   lib.sag_render_rgb.argtypes = [vp, C.POINTER(C.c_uint8)]
   lib.sag_render_rgb_device.argtypes = [vp, vp]
+  lib.sag_render.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
+  lib.sag_render_device.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
   lib.sag_debug_doggo_coop.argtypes = [vp, C.POINTER(C.c_double)]
   lib.sag_debug_cycles.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint64), C.c_int32]
   lib.sag_world_config_default.argtypes = [C.POINTER(WorldConfig)]
@@ -330,6 +332,17 @@ class Context:
     """[n_envs, 64, 64, 3] uint8: the robots' first-person camera images (rgb_observation)."""
     img = np.zeros((self.n_envs, 64, 64, 3), np.uint8)
     self._check(self.lib.sag_render_rgb(self.h, img.ctypes.data_as(C.POINTER(C.c_uint8))), 'sag_render_rgb')
+    return img
+
+  CAMERAS = {'vision': 0, 'fixednear': 1, 'fixedfar': 2, 'track': 3}
+
+  def render(self, camera='fixedfar', width=256, height=256, overlays=True):
+    """[n_envs, height, width, 3] uint8 from one of the scene's cameras (name or id), optionally with the lidar
+    rings and the cost indicator of the last step."""
+    cam = self.CAMERAS[camera] if isinstance(camera, str) else int(camera)
+    img = np.zeros((self.n_envs, int(height), int(width), 3), np.uint8)
+    self._check(self.lib.sag_render(self.h, cam, int(width), int(height), 1 if overlays else 0,
+                                    img.ctypes.data_as(C.POINTER(C.c_uint8))), 'sag_render')
     return img
 
   def debug_doggo_coop(self):

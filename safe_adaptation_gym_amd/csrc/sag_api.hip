@@ -100,7 +100,7 @@ struct sag_ctx {
   int phase = 0;       // busy-bit copy read by the next step launch
   int phase_used = 0;  // (the phase of the launch being built)
   int n_cu = 256;      // compute units of the device
-  uint8_t* d_rgb = nullptr;  // [N][64][64][3], allocated by the first sag_render_rgb
+  uint8_t* d_rgb = nullptr; size_t rgb_bytes = 0;  // [N][H][W][3] staging of sag_render, grown on demand
   double* d_dr = nullptr;    // Doggo cooperative form: per-env result block of the physics kernel
   // Doggo: wave-cooperative physics kernel (2 envs per wavefront, 3 wavefronts per CU) for batches up
   // to ~12k envs (measured 8.4 vs 16.8 ms at 4096), the lane-per-env kernel above that (36 vs 48 ms at
@@ -225,6 +225,13 @@ void dg_build_model(DgModel& M) {
   for (int s = 0; s < DG_NS; s++) {
     M.sph_body[s] = spheres[s].body; M.sph_touch[s] = spheres[s].touch; M.sph_r[s] = spheres[s].r;
     for (int k = 0; k < 3; k++) M.sph_p[s][k] = spheres[s].p[k];
+  }
+  static_assert(DG_NGEOM == 14, "geom table");
+  for (int g = 0; g < DG_NGEOM; g++) {
+    M.geom_body[g] = geoms[g].body; M.geom_capsule[g] = geoms[g].capsule ? 1 : 0; M.geom_r[g] = geoms[g].r;
+    // ankle geoms = the shin capsules on bodies 2, 4 (front legs: blue) and 7, 9 (rear legs: green)
+    M.geom_ankle[g] = (geoms[g].body == 2 || geoms[g].body == 4) ? 1 : ((geoms[g].body == 7 || geoms[g].body == 9) ? 2 : 0);
+    for (int k = 0; k < 3; k++) { M.geom_a[g][k] = geoms[g].a[k]; M.geom_b[g][k] = geoms[g].b[k]; }
   }
 }
 
@@ -354,7 +361,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
 #define SAG_LAUNCH3(ROB, B_, X_)                                                                         \
   do {                                                                                                  \
     if (split) {                                                                                        \
-      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3((c->N + SAG_BUSY_ENVS - 1) / SAG_BUSY_ENVS), dim3(WAVE), 0, c->stream, a); \
+      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3((c->N + busy_envs(ROB) - 1) / busy_envs(ROB)), dim3(WAVE), 0, c->stream, a); \
       hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), quiet_lds_extra, quiet_stream, a); \
     } else {                                                                                            \
       hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave), dim3(WAVE), 0, c->stream, a); \
@@ -367,8 +374,19 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     else if (!btn && tbox) SAG_LAUNCH3(ROB, false, true); \
     else SAG_LAUNCH3(ROB, true, true);             \
   } while (0)
-  if (c->cfg.robot == SAG_ROBOT_POINT) SAG_LAUNCH(SAG_ROBOT_POINT);
+  // (-DSAG_ONLY_ROBOT=<id>: kernel-tuning builds that instantiate one robot's step kernels only - a third of the
+  // compile time; the shipped library has them all)
+#ifndef SAG_ONLY_ROBOT
+#define SAG_ONLY_ROBOT -1
+#endif
+  if (false) {}
+#if SAG_ONLY_ROBOT < 0 || SAG_ONLY_ROBOT == 0
+  else if (c->cfg.robot == SAG_ROBOT_POINT) SAG_LAUNCH(SAG_ROBOT_POINT);
+#endif
+#if SAG_ONLY_ROBOT < 0 || SAG_ONLY_ROBOT == 1
   else if (c->cfg.robot == SAG_ROBOT_CAR) SAG_LAUNCH(SAG_ROBOT_CAR);
+#endif
+  else if (c->cfg.robot != SAG_ROBOT_DOGGO) return fail(c, SAG_ERR_UNSUPPORTED, "this build holds the step kernels of robot %d only", SAG_ONLY_ROBOT);
   else if (c->doggo_coop) {
     // Doggo, wave-cooperative physics (32 lanes per env) + the generic step without physics
     a.DR = c->d_dr;
@@ -489,6 +507,8 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
     CREATE_CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dg), &model, sizeof(model)));
     CREATE_CHK(doggo_lane_upload_model(&model));
   }
+  CREATE_CHK(hipMemsetAsync(c->d_cost, 0, N, c->stream));
+  CREATE_CHK(hipMemsetAsync(c->d_obs, 0, N * c->rb.obs_dim * sizeof(float), c->stream));
   CREATE_CHK(hipMemsetAsync(c->S, 0, N * DEV_FLOATS * sizeof(float), c->stream));
   CREATE_CHK(hipMemsetAsync(c->I, 0, N * DI_COUNT * sizeof(int32_t), c->stream));
   CREATE_CHK(hipStreamSynchronize(c->stream));
@@ -834,25 +854,39 @@ int sag_debug_doggo_coop(sag_ctx* c, double* out) {
   return SAG_OK;
 }
 
-// rgb_observation: [n_envs][64][64][3] uint8 image of the robot camera at the current state
-int sag_render_rgb_device(sag_ctx* c, void* d_out) {
+// images of every env at its current state, ray-cast on the device (sag_render.hpp): [n_envs][height][width][3] uint8.
+// d_obs / d_cost: the observation and cost flags the overlays show (device pointers or NULL)
+int sag_render_device(sag_ctx* c, int32_t camera, int32_t width, int32_t height, int32_t flags, const float* d_obs,
+                      const uint8_t* d_cost, void* d_out) {
   if (!c || !d_out) return c ? fail(c, SAG_ERR_ARG, "null argument") : SAG_ERR_ARG;
+  if (camera < 0 || camera > SAG_CAM_TRACK || width <= 0 || height <= 0 || width > 4096 || height > 4096)
+    return fail(c, SAG_ERR_ARG, "bad camera %d or image size %d x %d", camera, width, height);
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  hipLaunchKernelGGL(k_render_rgb, dim3(c->N), dim3(256), 0, c->stream, c->S, c->I, c->N, c->cfg.robot, (uint8_t*)d_out);
+  hipLaunchKernelGGL(k_render_rgb, dim3(c->N), dim3(256), 0, c->stream, c->S, c->I, c->N, c->cfg.robot, camera, width, height,
+                     flags, d_obs, c->rb.obs_dim, d_cost, (uint8_t*)d_out);
   HIPCHK(c, hipGetLastError());
   return SAG_OK;
 }
-int sag_render_rgb(sag_ctx* c, uint8_t* out) {
+int sag_render(sag_ctx* c, int32_t camera, int32_t width, int32_t height, int32_t flags, uint8_t* out) {
   if (!c || !out) return c ? fail(c, SAG_ERR_ARG, "null argument") : SAG_ERR_ARG;
   HIPCHK(c, hipSetDevice(c->cfg.device));
-  const size_t bytes = (size_t)c->N * 64 * 64 * 3;
-  if (!c->d_rgb) HIPCHK(c, hipMalloc(&c->d_rgb, bytes));
-  int rc = sag_render_rgb_device(c, c->d_rgb);
+  const size_t bytes = (size_t)c->N * (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0) * 3;
+  if (c->rgb_bytes < bytes) {
+    if (c->d_rgb) (void)hipFree(c->d_rgb);
+    c->d_rgb = nullptr; c->rgb_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->d_rgb, bytes ? bytes : 1));
+    c->rgb_bytes = bytes;
+  }
+  // the overlays show what the last host-buffer step / observe left in the context's output buffers
+  int rc = sag_render_device(c, camera, width, height, flags, c->d_obs, c->d_cost, c->d_rgb);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(out, c->d_rgb, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SAG_OK;
 }
+// rgb_observation: the 64 x 64 image of the robot's own camera, no overlays
+int sag_render_rgb_device(sag_ctx* c, void* d_out) { return sag_render_device(c, SAG_CAM_VISION, R_W, R_H, 0, nullptr, nullptr, d_out); }
+int sag_render_rgb(sag_ctx* c, uint8_t* out) { return sag_render(c, SAG_CAM_VISION, R_W, R_H, 0, out); }
 
 int sag_busy_count(sag_ctx* c, int32_t* count) {
   if (!c || !count) return SAG_ERR_ARG;

@@ -480,7 +480,11 @@ __device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB,
   const float bound_b = shape_bound(shB, vsz, rstatic) * 1.000001f;
   typedef typename std::conditional<(NA > 4), uint64_t, uint32_t>::type mask_t;
   mask_t mask = 0;   // bit 8 ga + gb
-#pragma unroll
+#ifndef SAG_CL_UNROLL_A
+#define SAG_CL_UNROLL_A 8
+#endif
+  // (the car's 8 x 5 pairs fully unrolled keep 15 + temporaries alive and spill: its geom loop stays rolled)
+#pragma unroll(NA * NB > SAG_CL_UNROLL_A ? 1 : NA)
   for (int ga = 0; ga < NA; ga++) {
     const Geom a = shape_geom(SHA, ga, vsz, rstatic);
     const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;
@@ -525,6 +529,9 @@ __device__ inline int collide_list(BV& A, float ca, float sa, BV& B, int shB, fl
   if constexpr (MULTI) {
     if (shape_ngeom(shB) > 1) return collide_list_nb<SHA, 5>(A, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
   }
+  // one or two pairs (Point robot or a vase against a single-geom body): nothing to gain from a list, the plain loop
+  // is the shorter code (measured: the list form costs the Point step 5 %)
+  if constexpr (SHA != SH_CAR) return collide_shapes<true>(A, SHA, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
   return collide_list_nb<SHA, 1>(A, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
 }
 
@@ -2201,8 +2208,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_step_doggo_post(StepArgs p) {
 #ifndef SAG_QUIET_MIN_WAVES
 #define SAG_QUIET_MIN_WAVES 4
 #endif
+#ifndef SAG_CAR_QUIET_MIN_WAVES
+#define SAG_CAR_QUIET_MIN_WAVES 3   // 155 VGPRs instead of 128 + spills (measured: 1.159 -> 1.146 ms at 1 M envs)
+#endif
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
-__global__ __launch_bounds__(WAVE, SAG_QUIET_MIN_WAVES) void k_step_quiet(StepArgs p) {
+__global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_QUIET_MIN_WAVES : SAG_QUIET_MIN_WAVES) void k_step_quiet(StepArgs p) {
   // positions (x, y) of the free bodies + the observation staging tile; no dynamic pool:
   // 10 KB (Point) -> 16 wavefronts per CU
   constexpr int QSLOTS = LS_YAW + (ROBOT == SAG_ROBOT_CAR ? 25 : 17);
@@ -2270,8 +2280,15 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int ph
 #ifndef SAG_BUSY_ENVS
 #define SAG_BUSY_ENVS 64  // envs per busy wavefront
 #endif
+#ifndef SAG_CAR_BUSY_ENVS
+#define SAG_CAR_BUSY_ENVS SAG_BUSY_ENVS
+#endif
+__host__ __device__ constexpr int busy_envs(int robot) { return robot == SAG_ROBOT_CAR ? SAG_CAR_BUSY_ENVS : SAG_BUSY_ENVS; }
+#ifndef SAG_CAR_BUSY_MIN_WAVES
+#define SAG_CAR_BUSY_MIN_WAVES SAG_STEP_MIN_WAVES
+#endif
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
-__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
+__global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_BUSY_MIN_WAVES : SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
 #ifndef SAG_BUSY_LDS_PAD
 #define SAG_BUSY_LDS_PAD 0
 #endif
@@ -2282,10 +2299,11 @@ __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs
   // kernel's wavefronts that share their SIMDs
   __builtin_amdgcn_s_setprio(SAG_BUSY_PRIO);
 #endif
-  const int lane = threadIdx.x, c0 = blockIdx.x * SAG_BUSY_ENVS;
+  constexpr int BE = busy_envs(ROBOT);
+  const int lane = threadIdx.x, c0 = blockIdx.x * BE;
   const int count = *p.count;
   if (c0 >= count) return;
-  const int nval = min(SAG_BUSY_ENVS, count - c0);
+  const int nval = min(BE, count - c0);
   const bool live = lane < nval;
   const int i = p.rows[c0 + (live ? lane : 0)];
   rows[lane] = i;

@@ -15,7 +15,7 @@
 
 namespace sag {
 
-constexpr int DG_NB = 10, DG_NV = 19, DG_NJ = 13, DG_NS = 17, DG_MAXROWS = 3 * 12 + DG_NJ + 1;
+constexpr int DG_NB = 10, DG_NV = 19, DG_NJ = 13, DG_NS = 17, DG_MAXROWS = 3 * 12 + DG_NJ + 1, DG_NGEOM = 14;
 constexpr int DG_PGS_ITERS = 4;
 constexpr double DG_GEAR = 0.0125, DG_STIFF = 0.01, DG_Z0 = 0.22, DG_PI = 3.14159265358979323846, DG_GRAV = 9.81;
 
@@ -31,6 +31,10 @@ struct DgModel {
   int sph_body[DG_NS], sph_touch[DG_NS];
   double sph_p[DG_NS][3], sph_r[DG_NS];
   unsigned anc[DG_NB];            // bit a set: body a is on the path root -> b (inclusive)
+  // the XML's geoms (rendering): body, end points in the body frame, radius, capsule (1) / cylinder (0),
+  // ankle colour class (0 default red, 1 front ankles blue, 2 rear ankles green: doggo.xml:26,40,58,72)
+  int geom_body[DG_NGEOM], geom_capsule[DG_NGEOM], geom_ankle[DG_NGEOM];
+  double geom_a[DG_NGEOM][3], geom_b[DG_NGEOM][3], geom_r[DG_NGEOM];
 };
 // one copy per translation unit (sag_api.hip: cooperative form + post kernel; sag_doggo_lane.hip: lane-per-env
 // form); sag_create uploads the model to both

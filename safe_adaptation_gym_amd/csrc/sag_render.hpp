@@ -2,24 +2,48 @@
 // the robot's `vision` camera, ray-cast on the device.  The reference renders with MuJoCo's OpenGL
 // rasteriser ("parity unpinned"); the specification of this image - camera from the robot XML
 // (point.xml:14, car.xml:14, doggo.xml:13), scene of mujoco_bridge.py:88-123, geoms and colours of
-// consts.py / primitive_objects.py / the task files, one blend layer, Lambert + headlight shade,
-// own body not drawn - is written out in DESIGN.md "rgb_observation".  fp64: a pixel is a hard
+// consts.py / primitive_objects.py / the task files and the robot XMLs (the robot's own geoms included),
+// translucent layers composited back to front, Lambert + headlight shade - is written out in DESIGN.md
+// "rgb_observation".  The same ray caster serves the human view (render.py,
+// safe_adaptation_gym.py:109-111,239-257): fixed / tracking cameras, any image size, lidar rings and cost indicator.  fp64: a pixel is a hard
 // decision (which surface, which checker square, rounding to 8 bits), like a lidar bin.
-// One workgroup per env: lane 0 builds the scene (<= 40 geoms) in LDS, 256 threads x 16 pixels.
+// One workgroup per env: lane 0 builds the scene (<= 112 geoms) in LDS, 256 threads share the pixels.
 #pragma once
 
 namespace sag {
 
+// Cameras (mujoco_bridge.py:126-153 + the robot XMLs): the robot's own `vision` camera, the two fixed world cameras
+// and the tracking camera of the human view (render.py, safe_adaptation_gym.py:109-111 render_options['camera_id']).
+enum { SAG_CAM_VISION = 0, SAG_CAM_FIXEDNEAR = 1, SAG_CAM_FIXEDFAR = 2, SAG_CAM_TRACK = 3 };
+enum { SAG_RENDER_OVERLAYS = 1 };   // lidar rings + cost indicator (render.py)
+
 struct RCam { double o[3], X[3], Y[3], Z[3], tanh_; };
-struct RObj { int kind; double c[3], a, b, h, cs, sn, rgb[3], alpha; };  // 0 box, 1 cylinder, 2 sphere
-constexpr int R_MAXOBJ = 40, R_W = 64, R_H = 64;
+// kind 0 box (yaw-rotated; half extents a, b, h), 1 vertical cylinder (a = r, h = half height), 2 sphere (a = r),
+// 3 rod: cylinder (b = 0) or capsule (b = 1) of radius a from c to e (any orientation: wheels, the Doggo's limbs)
+struct RObj { int kind; double c[3], a, b, h, cs, sn, rgb[3], alpha, e[3]; };
+constexpr int R_MAXOBJ = 112, R_W = 64, R_H = 64, R_MAXLAYERS = 12;
 
 __device__ inline void r_norm(double* v) {
   const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   v[0] /= n; v[1] /= n; v[2] /= n;
 }
 
-__device__ inline void r_camera(int robot, const double* R, const double* p, RCam& cam) {
+// R: body -> world (row-major), p: body origin
+__device__ inline void r_camera(int robot, int cam_id, const double* R, const double* p, RCam& cam) {
+  if (cam_id != SAG_CAM_VISION) {
+    // <camera name="fixednear" pos="0 -2 2" zaxis="0 -1 1"/>, "fixedfar" pos="0 -5 5"; the tracking camera has the
+    // same world orientation and keeps the offset (0, -2, 2) from the robot body (mode="track": position only).
+    // zaxis = the direction the camera looks AWAY from; x = world x; default fovy 45
+    const double off = cam_id == SAG_CAM_FIXEDFAR ? 5.0 : 2.0, q = 0.70710678118654752440;
+    cam.o[0] = cam_id == SAG_CAM_TRACK ? p[0] : 0.0;
+    cam.o[1] = (cam_id == SAG_CAM_TRACK ? p[1] : 0.0) - off;
+    cam.o[2] = (cam_id == SAG_CAM_TRACK ? p[2] : 0.0) + off;
+    cam.X[0] = 1; cam.X[1] = 0; cam.X[2] = 0;
+    cam.Y[0] = 0; cam.Y[1] = q; cam.Y[2] = q;
+    cam.Z[0] = 0; cam.Z[1] = -q; cam.Z[2] = q;
+    cam.tanh_ = tan(0.5 * 45.0 * PI_D / 180);
+    return;
+  }
   const double CPOS[3][3] = {{0, 0, .15}, {0, .1, .2}, {.125, 0, .2}};
   const double CX[3][3] = {{0, -1, 0}, {-1, 0, 0}, {0, -1, 0}};
   const double CY[3][3] = {{.4, 0, 1}, {0, -.4, 1}, {.4, 0, 1}};
@@ -40,18 +64,61 @@ __device__ inline void r_camera(int robot, const double* R, const double* p, RCa
   cam.tanh_ = tan(0.5 * FOVY[robot] * PI_D / 180);
 }
 
+// entry of the ray o + t d into the sphere (centre c, radius r), t > 1e-6
+__device__ inline bool r_sphere(const double* c, double r, const double* o, const double* d, double& tout, double* n) {
+  const double oc[3] = {o[0] - c[0], o[1] - c[1], o[2] - c[2]};
+  const double b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
+  const double cc = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - r * r;
+  const double disc = b * b - cc;
+  if (disc <= 0) return false;
+  const double t = -b - sqrt(disc);
+  if (t <= 1e-6) return false;
+  tout = t;
+  for (int k = 0; k < 3; k++) n[k] = (oc[k] + t * d[k]) / r;
+  return true;
+}
+
 // nearest intersection t > 1e-6 of the ray o + t d with the geom; n = surface normal there
 __device__ inline bool r_hit(const RObj& ob, const double* o, const double* d, double& tout, double* n) {
-  if (ob.kind == 2) {
+  if (ob.kind == 2) return r_sphere(ob.c, ob.a, o, d, tout, n);
+  if (ob.kind == 3) {
+    // axis u from c to e, length L; side: |(oc + t d) - ((oc + t d).u) u| = r with 0 <= s <= L
+    double u[3] = {ob.e[0] - ob.c[0], ob.e[1] - ob.c[1], ob.e[2] - ob.c[2]};
+    const double L = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    for (int k = 0; k < 3; k++) u[k] /= L;
     const double oc[3] = {o[0] - ob.c[0], o[1] - ob.c[1], o[2] - ob.c[2]};
-    const double b = oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2];
-    const double c = oc[0] * oc[0] + oc[1] * oc[1] + oc[2] * oc[2] - ob.a * ob.a;
-    const double disc = b * b - c;
-    if (disc <= 0) return false;
-    const double t = -b - sqrt(disc);
-    if (t <= 1e-6) return false;
-    tout = t;
-    for (int k = 0; k < 3; k++) n[k] = (oc[k] + t * d[k]) / ob.a;
+    const double du = d[0] * u[0] + d[1] * u[1] + d[2] * u[2], ou = oc[0] * u[0] + oc[1] * u[1] + oc[2] * u[2];
+    const double dd[3] = {d[0] - du * u[0], d[1] - du * u[1], d[2] - du * u[2]};
+    const double oo[3] = {oc[0] - ou * u[0], oc[1] - ou * u[1], oc[2] - ou * u[2]};
+    const double A = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2], B = oo[0] * dd[0] + oo[1] * dd[1] + oo[2] * dd[2];
+    const double C = oo[0] * oo[0] + oo[1] * oo[1] + oo[2] * oo[2] - ob.a * ob.a;
+    double best = 1e30;
+    bool found = false;
+    if (A > 0) {
+      const double disc = B * B - A * C;
+      if (disc > 0) {
+        const double t = (-B - sqrt(disc)) / A, sax = ou + t * du;
+        if (t > 1e-6 && sax >= 0 && sax <= L) {
+          best = t; found = true;
+          for (int k = 0; k < 3; k++) n[k] = (oo[k] + t * dd[k]) / ob.a;
+        }
+      }
+    }
+    if (ob.b != 0) {   // capsule: the two end spheres
+      double t, m[3];
+      if (r_sphere(ob.c, ob.a, o, d, t, m) && t < best) { best = t; found = true; n[0] = m[0]; n[1] = m[1]; n[2] = m[2]; }
+      if (r_sphere(ob.e, ob.a, o, d, t, m) && t < best) { best = t; found = true; n[0] = m[0]; n[1] = m[1]; n[2] = m[2]; }
+    } else if (du != 0) {   // cylinder: the flat cap facing the ray
+      const double s = du < 0 ? 1.0 : 0.0, t = (s * L - ou) / du;
+      const double q[3] = {oo[0] + t * dd[0], oo[1] + t * dd[1], oo[2] + t * dd[2]};
+      if (t > 1e-6 && t < best && q[0] * q[0] + q[1] * q[1] + q[2] * q[2] <= ob.a * ob.a) {
+        best = t; found = true;
+        const double sg = du < 0 ? 1.0 : -1.0;
+        n[0] = sg * u[0]; n[1] = sg * u[1]; n[2] = sg * u[2];
+      }
+    }
+    if (!found) return false;
+    tout = best;
     return true;
   }
   const double ox = o[0] - ob.c[0], oy = o[1] - ob.c[1], oz = o[2] - ob.c[2];
@@ -110,14 +177,31 @@ __device__ inline void r_shade(const double* rgb, const double* n, const double*
 
 __device__ inline void r_obj(RObj* ob, int& n, int kind, double x, double y, double z, double a, double b, double h,
                              double yaw, double cr, double cg, double cb, double al) {
+  if (n >= R_MAXOBJ) return;
   RObj& q = ob[n++];
   q.kind = kind; q.c[0] = x; q.c[1] = y; q.c[2] = z; q.a = a; q.b = b; q.h = h;
   q.cs = cos(yaw); q.sn = sin(yaw); q.rgb[0] = cr; q.rgb[1] = cg; q.rgb[2] = cb; q.alpha = al;
+  q.e[0] = q.e[1] = q.e[2] = 0;
+}
+// rod from body-frame points a, b of the body with frame (R, p)
+__device__ inline void r_rod(RObj* ob, int& n, const double* R, const double* p, double ax, double ay, double az, double bx,
+                             double by, double bz, double r, bool capsule, double cr, double cg, double cb, double al) {
+  if (n >= R_MAXOBJ) return;
+  RObj& q = ob[n++];
+  q.kind = 3; q.a = r; q.b = capsule ? 1 : 0; q.h = 0; q.cs = 1; q.sn = 0;
+  for (int k = 0; k < 3; k++) {
+    q.c[k] = p[k] + R[3 * k] * ax + R[3 * k + 1] * ay + R[3 * k + 2] * az;
+    q.e[k] = p[k] + R[3 * k] * bx + R[3 * k + 1] * by + R[3 * k + 2] * bz;
+  }
+  q.rgb[0] = cr; q.rgb[1] = cg; q.rgb[2] = cb; q.alpha = al;
 }
 
-// out: [N][64][64][3] uint8
+// out: [N][H][W][3] uint8.  obs / cost (device pointers or nullptr): last observation [N][obs_dim] and cost flags for
+// the overlays (lidar rings, cost indicator).
 __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S, const int32_t* __restrict__ I, int N,
-                                                    int robot, uint8_t* __restrict__ out) {
+                                                    int robot, int cam_id, int W, int H, int flags,
+                                                    const float* __restrict__ obs, int obs_dim,
+                                                    const uint8_t* __restrict__ cost, uint8_t* __restrict__ out) {
   __shared__ RObj ob[R_MAXOBJ];
   __shared__ RCam cam;
   __shared__ int nob_s;
@@ -128,17 +212,18 @@ __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S,
     const int task = meta & 15, nH = meta >> 4 & 15, nV = meta >> 8 & 15, nP = meta >> 12 & 3, nB = meta >> 14 & 7,
               box_kind = meta >> 17 & 3;
     double R[9], p[3];
+    double yaw = F(SAG_F_ROBOT + 2);
     if (robot == SAG_ROBOT_DOGGO) {
       DgState D;
       dg_load(D, S, (size_t)N, i);
       dg_quat2mat(D.quat, R);
       p[0] = D.pos[0]; p[1] = D.pos[1]; p[2] = D.pos[2];
     } else {
-      const double yaw = F(SAG_F_ROBOT + 2), c = cos(yaw), s = sin(yaw);
+      const double c = cos(yaw), s = sin(yaw);
       R[0] = c; R[1] = -s; R[2] = 0; R[3] = s; R[4] = c; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
       p[0] = F(SAG_F_ROBOT); p[1] = F(SAG_F_ROBOT + 1); p[2] = PT_Z;
     }
-    r_camera(robot, R, p, cam);
+    r_camera(robot, cam_id, R, p, cam);
     int n = 0;
     const double vs = F(SAG_F_VASE_SIZE);
     for (int k = 0; k < nH; k++)
@@ -160,18 +245,69 @@ __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S,
       if (g == 2) r_obj(ob, n, 2, F(SAG_F_BUTTONS + 2 * b), F(SAG_F_BUTTONS + 2 * b + 1), (double)BUTTON_R, (double)BUTTON_R, 0, 0, 0.0, 0, 1, 0, 1.0);
       else r_obj(ob, n, 2, F(SAG_F_BUTTONS + 2 * b), F(SAG_F_BUTTONS + 2 * b + 1), (double)BUTTON_R, (double)BUTTON_R, 0, 0, 0.0, 1, 105.0 / 255, 180.0 / 255, 1.0);
     }
-    if (box_kind == SAG_BOX_BOX) r_obj(ob, n, 0, F(SAG_F_BOX), F(SAG_F_BOX + 1), 0.2, 0.2, 0.2, 0.2, F(SAG_F_BOX + 2), 1, 1, 0, 0.25);
+    if (box_kind == SAG_BOX_BOX) {
+      // push_box.py:28-72: the box (half .2) and its four corner columns (half .1 x .1 x .2 at (+-.2, +-.2)), one rgba
+      const double bx = F(SAG_F_BOX), by = F(SAG_F_BOX + 1), byaw = F(SAG_F_BOX + 2), c = cos(byaw), s = sin(byaw);
+      r_obj(ob, n, 0, bx, by, 0.2, 0.2, 0.2, 0.2, byaw, 1, 1, 0, 0.25);
+      for (int q = 0; q < 4; q++) {
+        const double lx = (q & 1) ? -0.2 : 0.2, ly = (q & 2) ? -0.2 : 0.2;
+        r_obj(ob, n, 0, bx + c * lx - s * ly, by + s * lx + c * ly, 0.2, 0.1, 0.1, 0.2, byaw, 1, 1, 0, 0.25);
+      }
+    }
     else if (box_kind == SAG_BOX_ROD) r_obj(ob, n, 0, F(SAG_F_BOX), F(SAG_F_BOX + 1), 0.08, 0.08, 0.3, 0.08, F(SAG_F_BOX + 2), 1, 1, 1, 1.0);
     else if (box_kind == SAG_BOX_BALL) r_obj(ob, n, 2, F(SAG_F_BOX), F(SAG_F_BOX + 1), 0.14, 0.14, 0, 0, 0.0, 1, 1, 1, 1.0);
+    // ---- the robot's own geoms (default rgba 1 0 0 1 in the three XMLs) ----------------------------------
+    if (robot == SAG_ROBOT_POINT) {          // point.xml:18-19: sphere r .1, arrow box half .05 at (.1, 0, 0)
+      r_obj(ob, n, 2, p[0], p[1], p[2], 0.1, 0, 0, 0.0, 1, 0, 0, 1.0);
+      r_obj(ob, n, 0, p[0] + 0.1 * R[0], p[1] + 0.1 * R[3], p[2], 0.05, 0.05, 0.05, yaw, 1, 0, 0, 1.0);
+    } else if (robot == SAG_ROBOT_CAR) {     // car.xml:16-32
+      const double BX[5][6] = {{0, 0, 0, .1, .1, .05}, {0, .15, 0, .1, .01, .05}, {0, .125, 0, .01, .025, .03},
+                               {0, -.165, 0, .05, .01, .05}, {0, -.13, .04, .05, .03, .01}};
+      for (int g = 0; g < 5; g++)
+        r_obj(ob, n, 0, p[0] + R[0] * BX[g][0] + R[1] * BX[g][1], p[1] + R[3] * BX[g][0] + R[4] * BX[g][1], p[2] + BX[g][2],
+              BX[g][3], BX[g][4], BX[g][5], yaw, 1, 0, 0, 1.0);
+      r_rod(ob, n, R, p, -.155, .1, -.05, -.105, .1, -.05, 0.05, false, 1, 0, 0, 1.0);   // left wheel (cylinder along x)
+      r_rod(ob, n, R, p, .105, .1, -.05, .155, .1, -.05, 0.05, false, 1, 0, 0, 1.0);     // right wheel
+      r_obj(ob, n, 2, p[0] + R[1] * -.1, p[1] + R[4] * -.1, p[2] - .05, 0.05, 0, 0, 0.0, 1, 0, 0, 1.0);   // rear ball
+    } else {                                 // doggo.xml: two torso cylinders, twelve capsules (ankles blue / green)
+      DgWork K;
+      K.L = nullptr; K.xs = nullptr; K.dinv = nullptr;
+      DgState D;
+      dg_load(D, S, (size_t)N, i);
+      dg_kinematics(D, K);
+      for (int g = 0; g < DG_NGEOM; g++) {
+        const int b = g_dg.geom_body[g];
+        const bool ankle = g_dg.geom_ankle[g] != 0, front = g_dg.geom_ankle[g] == 1;
+        r_rod(ob, n, K.R[b], K.p[b], g_dg.geom_a[g][0], g_dg.geom_a[g][1], g_dg.geom_a[g][2], g_dg.geom_b[g][0],
+              g_dg.geom_b[g][1], g_dg.geom_b[g][2], g_dg.geom_r[g], g_dg.geom_capsule[g] != 0,
+              ankle ? 0.0 : 1.0, ankle && !front ? 1.0 : 0.0, ankle && front ? 1.0 : 0.0, 1.0);
+      }
+    }
+    // ---- overlays of the human view (render.py): three lidar rings above the robot, the cost indicator --------
+    if (flags & SAG_RENDER_OVERLAYS) {
+      const float* o = obs ? obs + i * (size_t)obs_dim : nullptr;
+      for (int ring = 0; ring < 3; ring++) {          // obstacles (red, z .5), goal (green, .56), objects (blue, .62)
+        const int col0 = ring == 0 ? 0 : (ring == 1 ? 32 : 16);
+        for (int j = 0; j < SAG_LIDAR_BINS; j++) {
+          const double th = 2.0 * PI_D * (j + 0.5) / SAG_LIDAR_BINS, lx = 0.15 * cos(th), ly = 0.15 * sin(th), lz = 0.5 + 0.06 * ring;
+          double al = (o ? (double)o[col0 + j] : 0.0) + 0.1;
+          if (al > 1) al = 1;
+          r_obj(ob, n, 2, p[0] + R[0] * lx + R[1] * ly + R[2] * lz, p[1] + R[3] * lx + R[4] * ly + R[5] * lz,
+                p[2] + R[6] * lx + R[7] * ly + R[8] * lz, 0.025, 0, 0, 0.0, ring == 0 ? al : 0, ring == 1 ? al : 0, ring == 2 ? al : 0, al);
+        }
+      }
+      if (cost && cost[i]) r_obj(ob, n, 2, p[0], p[1], p[2], 0.25, 0, 0, 0.0, 1, 0, 0, 0.5);
+    }
     nob_s = n;
   }
   __syncthreads();
   const int nob = nob_s;
-  uint8_t* img = out + i * (size_t)(R_W * R_H * 3);
+  uint8_t* img = out + i * (size_t)W * H * 3;
+  const double aspect = (double)W / (double)H;
 #pragma unroll 1
-  for (int px = threadIdx.x; px < R_W * R_H; px += 256) {
-    const int r = px >> 6, c = px & 63;
-    const double u = ((c + 0.5) / 32.0 - 1.0) * cam.tanh_, v = (1.0 - (r + 0.5) / 32.0) * cam.tanh_;
+  for (int px = threadIdx.x; px < W * H; px += 256) {
+    const int r = px / W, c = px - r * W;
+    const double u = ((c + 0.5) / (0.5 * W) - 1.0) * cam.tanh_ * aspect, v = (1.0 - (r + 0.5) / (0.5 * H)) * cam.tanh_;
     double d[3];
     for (int k = 0; k < 3; k++) d[k] = u * cam.X[k] + v * cam.Y[k] - cam.Z[k];
     r_norm(d);
@@ -194,17 +330,24 @@ __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S,
       const double w = 0.5 * (d[2] + 1.0);
       col[0] = 0.1 + (0.527 - 0.1) * w; col[1] = 0.1 + (0.582 - 0.1) * w; col[2] = 0.35 + (0.906 - 0.35) * w;
     }
-    double tb = best, nb[3] = {0, 0, 1};
-    int kb = -1;
+    // translucent geoms in front of the opaque surface: the nearest R_MAXLAYERS of them, composited back to front
+    double lt[R_MAXLAYERS];
+    int lk[R_MAXLAYERS], nl = 0;
 #pragma unroll 1
     for (int k = 0; k < nob; k++) {
       double n[3];
-      if (ob[k].alpha < 1.0 && r_hit(ob[k], cam.o, d, t, n) && t < tb) { tb = t; kb = k; nb[0] = n[0]; nb[1] = n[1]; nb[2] = n[2]; }
+      if (ob[k].alpha < 1.0 && r_hit(ob[k], cam.o, d, t, n) && t < best) {
+        int pos = nl < R_MAXLAYERS ? nl++ : (t < lt[R_MAXLAYERS - 1] ? R_MAXLAYERS - 1 : -1);
+        if (pos < 0) continue;
+        while (pos > 0 && lt[pos - 1] > t) { lt[pos] = lt[pos - 1]; lk[pos] = lk[pos - 1]; pos--; }
+        lt[pos] = t; lk[pos] = k;
+      }
     }
-    if (kb >= 0) {
-      double sc[3];
-      r_shade(ob[kb].rgb, nb, d, sc);
-      for (int k = 0; k < 3; k++) col[k] = ob[kb].alpha * sc[k] + (1 - ob[kb].alpha) * col[k];
+    for (int q = nl - 1; q >= 0; q--) {
+      double n[3], sc[3];
+      r_hit(ob[lk[q]], cam.o, d, t, n);
+      r_shade(ob[lk[q]].rgb, n, d, sc);
+      for (int k = 0; k < 3; k++) col[k] = ob[lk[q]].alpha * sc[k] + (1 - ob[lk[q]].alpha) * col[k];
     }
     for (int k = 0; k < 3; k++) {
       const double x = col[k] < 0 ? 0 : (col[k] > 1 ? 1 : col[k]);

@@ -51,10 +51,14 @@ class BatchedSafeAdaptationGym:
   BASE_SENSORS = ['accelerometer', 'velocimeter', 'gyro', 'magnetometer']
 
   def __init__(self, robot_base, n_envs=1, rgb_observation=False, config=None, devices=None,
-               parity_rng=False, device_seed=None):
+               parity_rng=False, device_seed=None, render_lidars_and_collision=False, render_options=None):
     # rgb_observation: the observation is the robot camera's 64 x 64 x 3 uint8 image
     # (safe_adaptation_gym.py:122-126,148-149), ray-cast on the device
     self._rgb_observation = bool(rgb_observation)
+    # human view (safe_adaptation_gym.py:37-38,109-111): render(**render_options) of the scene's cameras, with the
+    # lidar rings / cost sphere of render.py when render_lidars_and_collision
+    self._render_lidars_and_collision = bool(render_lidars_and_collision)
+    self._render_options = dict(render_options) if render_options else {}
     self.robot = Robot(robot_base)
     self.n_envs = int(n_envs)
     self.base_config = config
@@ -177,8 +181,17 @@ class BatchedSafeAdaptationGym:
   def _render_rgb(self):
     return np.concatenate(self._map(lambda c, s, e: c.render_rgb()))
 
-  def render(self, mode='human'):
-    raise NotImplementedError('rendering is out of scope (SURVEY 8f rank 4)')
+  def render(self, mode='human', **options):
+    """Images of every env from one of the scene's cameras, ray-cast on the device: [N, height, width, 3] uint8.
+    Options as the reference passes to physics.render (render_options: camera_id 'vision' | 'fixednear' |
+    'fixedfar' | 'track', height, width); defaults 'fixedfar', 256 x 256.  There is no window: mode 'human' and
+    'rgb_array' both return the array (a viewer can show it)."""
+    opt = dict(self._render_options)
+    opt.update(options)
+    cam, h, w = opt.get('camera_id', 'fixedfar'), int(opt.get('height', 256)), int(opt.get('width', 256))
+    if isinstance(cam, str) and cam not in nat.Context.CAMERAS:
+      raise KeyError(f'unknown camera {cam!r}: one of {sorted(nat.Context.CAMERAS)}')
+    return np.concatenate(self._map(lambda c, s, e: c.render(cam, w, h, overlays=self._render_lidars_and_collision)))
 
   def close(self):
     for c in self._ctx:

@@ -87,6 +87,7 @@ class Oracle:
     lib.sago_philox.argtypes = [up, up, up]
     lib.sago_robot_info.argtypes = [C.c_int, ip, dp]
     lib.sago_render_rgb.argtypes = [C.POINTER(OEnv), C.c_int, bp]
+    lib.sago_render.argtypes = [C.POINTER(OEnv), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, bp]
     lib.sago_doggo_substeps.argtypes = [C.POINTER(OEnv), dp, C.c_int, C.c_double]
     lib.sago_doggo_energy.argtypes = [C.POINTER(OEnv)]
     lib.sago_doggo_energy.restype = C.c_double
@@ -95,6 +96,14 @@ class Oracle:
   def render_rgb(self, e, robot):
     img = np.zeros((64, 64, 3), np.uint8)
     self.lib.sago_render_rgb(C.byref(e), robot, img.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return img
+
+  def render(self, e, robot, camera, width, height, overlays=False, lidar48=None, cost=0):
+    img = np.zeros((height, width, 3), np.uint8)
+    lid = None if lidar48 is None else np.ascontiguousarray(lidar48, np.float32)
+    self.lib.sago_render(C.byref(e), robot, camera, width, height, 1 if overlays else 0,
+                         None if lid is None else lid.ctypes.data_as(C.POINTER(C.c_float)), int(cost),
+                         img.ctypes.data_as(C.POINTER(C.c_uint8)))
     return img
 
   # -- doggo diagnostics -----------------------------------------------------

@@ -834,6 +834,59 @@ def test_rgb_observation_matches_oracle(nat, oracle, robot, task):
   ctx.close()
 
 
+@pytest.mark.parametrize('robot,task,camera', [('point', 'go_to_goal', 'fixedfar'), ('car', 'push_box', 'track'),
+                                               ('doggo', 'press_buttons', 'fixednear'), ('point', 'collect', 'vision')])
+def test_human_view_matches_oracle(nat, oracle, robot, task, camera):
+  """SURVEY 8f rank 4 (render.py, safe_adaptation_gym.py:109-111,239-257): the scene's other cameras, a non-square
+  image, and the overlays of render_lidars_and_collision (three lidar rings whose alpha follows the last
+  observation, the cost sphere) - device ray caster against the oracle's statement of the same image."""
+  n, W, H = 12, 96, 64
+  rid = {'point': 0, 'car': 1, 'doggo': 2}[robot]
+  cam = nat.Context.CAMERAS[camera]
+  rf, ri = bu.sample_records_native(robot, task, n, seed=77)
+  ctx = nat.Context(robot, n, seed=5)
+  ctx.set_layout(rf, ri)
+  rng = np.random.RandomState(2)
+  cost_seen = 0
+  for rounds in range(3):
+    for _ in range(4):
+      out = ctx.step(rng.uniform(-1, 1, (n, ctx.info['nu'])).astype(np.float32))
+    if rounds == 1:   # put some robots onto a hazard so that the cost indicator is drawn
+      s_rf, s_ri = ctx.get_state()
+      s_rf[:n // 2, 0:2] = s_rf[:n // 2, nat.F_HAZARDS:nat.F_HAZARDS + 2]
+      ctx.set_state(s_rf, s_ri)
+      out = ctx.step(np.zeros((n, ctx.info['nu']), np.float32), nstep=0)
+    obs, cost = out[0], out[2]
+    cost_seen += int(cost.sum())
+    img = ctx.render(camera, W, H, overlays=True)
+    assert img.shape == (n, H, W, 3) and img.dtype == np.uint8
+    rf2, ri2 = ctx.get_state()
+    ref = np.stack([oracle.render(oracle.env(rf2[k], ri2[k]), rid, cam, W, H, True, obs[k, :48], cost[k]) for k in range(n)])
+    bad = np.abs(img.astype(int) - ref.astype(int)).max(-1) > 0
+    assert bad.mean() <= 1e-3, f'{bad.sum()} pixels differ'
+    plain = ctx.render(camera, W, H, overlays=False)
+    if camera != 'vision':   # (the rings float above the robot's own camera, out of its view)
+      assert (plain != img).any(), 'the overlays must be visible'
+  assert cost_seen > 0
+  ctx.close()
+
+
+def test_render_env_api(nat):
+  """env.render() / make(render_options=..., render_lidar_and_collision=...) mirror the reference's call
+  (safe_adaptation_gym/__init__.py:6-24, safe_adaptation_gym.py:109-111)."""
+  import safe_adaptation_gym_amd as sag
+  env = sag.make('car', 'go_to_goal', seed=3, n_envs=4, render_options=dict(camera_id='fixedfar', height=48, width=80),
+                 render_lidar_and_collision=True)
+  env.reset()
+  env.step(np.zeros((4, 2), np.float32))
+  img = env.render()
+  assert img.shape == (4, 48, 80, 3) and img.dtype == np.uint8 and len(np.unique(img.reshape(-1, 3), axis=0)) > 10
+  assert env.render(mode='rgb_array', camera_id='track', height=32, width=32).shape == (4, 32, 32, 3)
+  with pytest.raises(KeyError):
+    env.render(camera_id='nope')
+  env.close()
+
+
 def test_rgb_observation_env_api(nat):
   """make(..., rgb_observation=True): reset/step return [N, 64, 64, 3] uint8, the declared space."""
   import safe_adaptation_gym_amd as sag

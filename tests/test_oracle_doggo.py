@@ -222,16 +222,18 @@ def test_observation_layout(oracle):
 # ---- rgb_observation specification (oracle/sag_oracle_render.inc) ---------------------------
 def test_render_known_answers(oracle):
   """Camera of point.xml:14 (fovy 90, looking along +x, pitched 21.8 deg down): the top rows see
-  the sky (blue gradient), the bottom rows the grey checker floor; a pillar 1 m straight ahead
+  the sky (blue gradient), the rows below the horizon the grey checker floor and the bottom of the image the
+  robot's own red body (sphere r .1 right under the camera, point.xml:18-19); a pillar 1 m straight ahead
   fills the image centre with its colour (.5 .5 1) x shade; a hazard disc under the view tints the
   floor blue by alpha .25."""
   from golden_util import base_record
   rf, ri = base_record('go_to_goal', ['robot', 'goal'], {'robot': 0.4})
   rf[ol.F_GOAL:ol.F_GOAL + 2] = [-3.0, 0.0]   # behind the camera
   img = oracle.render_rgb(oracle.env(rf, ri), 0)
-  top, bottom = img[0].astype(int), img[-1].astype(int)
-  assert (top[:, 2] > top[:, 0] + 50).all() and (np.abs(bottom[:, 0] - bottom[:, 1]) <= 1).all()
-  assert set(np.unique(bottom[:, 0])) <= {int(0.7 * 255 + .5), int(0.8 * 255 + .5)}
+  top, floor_row, bottom = img[0].astype(int), img[34].astype(int), img[-1].astype(int)
+  assert (top[:, 2] > top[:, 0] + 50).all() and (np.abs(floor_row[:, 0] - floor_row[:, 1]) <= 1).all()
+  assert set(np.unique(floor_row[:, 0])) <= {int(0.7 * 255 + .5), int(0.8 * 255 + .5)}
+  assert (bottom[:, 0] > 200).all() and (bottom[:, 1:] == 0).all()        # its own body
   # pillar ahead
   rf2, ri2 = base_record('go_to_goal', ['robot', 'goal', 'pillars0'], {'robot': 0.4})
   rf2[ol.F_GOAL:ol.F_GOAL + 2] = [-3.0, 0.0]
@@ -245,7 +247,7 @@ def test_render_known_answers(oracle):
   rf3[ol.F_GOAL:ol.F_GOAL + 2] = [-3.0, 0.0]
   rf3[ol.F_HAZARDS:ol.F_HAZARDS + 2] = [0.5, 0.0]
   img3 = oracle.render_rgb(oracle.env(rf3, ri3), 0)
-  row = 40
+  row = 36   # (between the horizon and the robot's own body)
   px = img3[row, 32].astype(int)
   assert px[2] > px[0] + 20 and (img3[row, 2] == img[row, 2]).all()
   # yaw rotates the view: a pillar at +y is centred after turning the robot by 90 degrees
