@@ -212,6 +212,7 @@ def main(argv=None, run_factory=None, emit=print):
   ap.add_argument('--robot', default='point', help='point (headline) | car | doggo: profile another config as the main line')
   ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (stationary contact load)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='CPU time spent on the cpu_baseline sample')
   ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line')
   args = ap.parse_args(argv)
 
@@ -418,7 +419,7 @@ def main(argv=None, run_factory=None, emit=print):
                                                    'is fp64 compute per pixel (a hard decision like a lidar bin), not memory-bound'}
       r5.close()
     if not args.no_cpu_baseline:
-      res['cpu_baseline'] = cpu_baseline(args.task)
+      res['cpu_baseline'] = cpu_baseline(args.task, args.cpu_baseline_seconds)
   if rank == 0:
     emit(json.dumps(res))
   if dist is not None:

@@ -484,7 +484,8 @@ __device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB,
 #define SAG_CL_UNROLL_A 8
 #endif
   // (the car's 8 x 5 pairs fully unrolled keep 15 + temporaries alive and spill: its geom loop stays rolled)
-#pragma unroll(NA * NB > SAG_CL_UNROLL_A ? 1 : NA)
+  constexpr int UNROLL_A = NA * NB > SAG_CL_UNROLL_A ? 1 : NA;
+#pragma unroll UNROLL_A
   for (int ga = 0; ga < NA; ga++) {
     const Geom a = shape_geom(SHA, ga, vsz, rstatic);
     const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;

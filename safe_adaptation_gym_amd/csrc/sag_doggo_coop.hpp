@@ -433,28 +433,15 @@ __device__ inline double dc_sum32(double v) {
   return v;
 }
 
-// Row r whose Jacobian the owner lane has already written to E.rJ[r] (fp32): W = M^-1 J^T, A (+ other
-// body), velocity along the row (returned).  Everything indexed at run time lives in LDS - a private
-// array indexed by a loop variable would go to scratch memory.
+// Row r whose Jacobian the owner lane has already written to E.rJ[r] (fp32): the owner's part of the row - the other
+// (planar) body's terms and the velocity along the row (returned).  W = M^-1 J^T, A = J W and the regulariser are
+// computed afterwards by all lanes together (dc_rows_finish): one lane doing 19 x 19 products per row while 28
+// idle was 32 % of the kernel.
 __device__ __attribute__((noinline)) double dc_build_row(int hf, int r, int other, double dx, double dy, double px, double py) {
   DC_ENV;
-  // the row's Jacobian in registers (static indices: every loop over it is fully unrolled), so the
-  // LDS reads of a product are issued together instead of one round trip per multiply-add
-  double Jr[DG_NV];
-#pragma unroll
-  for (int k = 0; k < DG_NV; k++) Jr[k] = (double)E.rJ[r][k];
   double vel = 0;
 #pragma unroll
-  for (int k = 0; k < DG_NV; k++) vel += Jr[k] * E.qdv[k];
-  double A = 0;
-#pragma unroll 1
-  for (int i = 0; i < DG_NV; i++) {
-    double w = 0;
-#pragma unroll
-    for (int k = 0; k < DG_NV; k++) w += E.Minv[i][k] * Jr[k];
-    E.rW[r][i] = (float)w;
-    A += (double)E.rJ[r][i] * w;
-  }
+  for (int k = 0; k < DG_NV; k++) vel += (double)E.rJ[r][k] * E.qdv[k];
   E.rOther[r] = (short)other; E.rParent[r] = -1; E.rTouch[r] = -1; E.rF[r] = 0; E.rMu[r] = 0;
   float ou0 = 0, ou1 = 0, ou2 = 0, od0 = 0, od1 = 0, orx = 0, ory = 0;
   if (other >= 0) {
@@ -466,13 +453,82 @@ __device__ __attribute__((noinline)) double dc_build_row(int hf, int r, int othe
     ou0 = m[0] * od0 + m[1] * od1 + m[2] * rxd;
     ou1 = m[1] * od0 + m[3] * od1 + m[4] * rxd;
     ou2 = m[2] * od0 + m[4] * od1 + m[5] * rxd;
-    A += (double)(od0 * ou0 + od1 * ou1 + rxd * ou2);
     vel += (double)((B[3] - B[5] * ory) * od0 + (B[4] + B[5] * orx) * od1);
   }
   E.rOu[r][0] = ou0; E.rOu[r][1] = ou1; E.rOu[r][2] = ou2; E.rOd[r][0] = od0; E.rOd[r][1] = od1;
   E.rOrx[r] = orx; E.rOry[r] = ory;
-  E.rA[r] = A;
   return vel;
+}
+
+// fast PGS path: all rows of an env on its 32 lanes (one row per lane), the Delassus matrix A = J M^-1 J^T (+ the
+// coupling through a shared planar body) in LDS as fp32 [DC_PGS_LANES][DC_PGS_LANES + 1], aliasing M / Minv (dead once W exists)
+constexpr int DC_PGS_LANES = 32;
+static_assert(sizeof(float) * DC_PGS_LANES * (DC_PGS_LANES + 1) <= 2 * sizeof(double) * DG_NV * (DG_NV + 1), "A fits into M + Minv");
+
+// contribution of a unit force increment of row s to the acceleration along row r through the planar body they share
+__device__ inline double dc_body_coupling(const DcEnv& E, int r, int s) {
+  if (E.rOther[r] < 0 || E.rOther[r] != E.rOther[s]) return 0.0;
+  return (double)((E.rOu[s][0] - E.rOu[s][2] * E.rOry[r]) * E.rOd[r][0] + (E.rOu[s][1] + E.rOu[s][2] * E.rOrx[r]) * E.rOd[r][1]);
+}
+
+// All lanes: W = J M^-1 for every row, the diagonal A_rr with regulariser and 1 / (A + R), and - when every row has a
+// lane (fast) - the full Delassus matrix and each row's initial constraint acceleration J qacc0 (returned for the
+// lane's own row).  Barriers inside; qacc0 must be in E.qacc.
+__device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nrows, bool fast) {
+  DC_ENV;
+  if (u < DG_NV) {
+    double mi[DG_NV];   // row u of M^-1 (symmetric) in registers
+#pragma unroll
+    for (int k = 0; k < DG_NV; k++) mi[k] = E.Minv[u][k];
+#pragma unroll 1
+    for (int r = 0; r < nrows; r++) {
+      double w = 0;
+#pragma unroll
+      for (int k = 0; k < DG_NV; k++) w += mi[k] * (double)E.rJ[r][k];   // (the same address in every lane: LDS broadcast)
+      E.rW[r][u] = (float)w;
+    }
+  }
+  __syncthreads();   // W complete; M / Minv are dead from here on (A may overwrite them)
+  float* Abuf = reinterpret_cast<float*>(&E.M[0][0]);
+  double a0 = 0;
+#pragma unroll 1
+  for (int rr = u; rr < nrows; rr += 32) {
+    double Jr[DG_NV];
+#pragma unroll
+    for (int k = 0; k < DG_NV; k++) Jr[k] = (double)E.rJ[rr][k];
+    double Arr = 0;
+#pragma unroll
+    for (int k = 0; k < DG_NV; k++) Arr += Jr[k] * (double)E.rW[rr][k];
+    Arr += dc_body_coupling(E, rr, rr);
+    const double imp = E.rImp[rr], reg = Arr * (1 - imp) / imp;
+    E.rA[rr] = Arr; E.rReg[rr] = reg; E.rInv[rr] = 1.0 / (Arr + reg);
+    if (fast) {
+#pragma unroll
+      for (int k = 0; k < DG_NV; k++) a0 += Jr[k] * E.qacc[k];
+#pragma unroll 1
+      for (int sr = 0; sr < nrows; sr++) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < DG_NV; k++) v += Jr[k] * (double)E.rW[sr][k];
+        Abuf[rr * (DC_PGS_LANES + 1) + sr] = (float)(v + dc_body_coupling(E, rr, sr));
+      }
+    }
+  }
+  __syncthreads();
+  return a0;
+}
+
+// v of lane `lane_in_half` of this lane's own half, for every lane (lane index uniform across the wavefront)
+__device__ inline double dc_bcast(double v, int lane_in_half, int half) {
+  const long long b = __double_as_longlong(v);
+  const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  const int lo0 = __builtin_amdgcn_readlane(lo, lane_in_half), hi0 = __builtin_amdgcn_readlane(hi, lane_in_half);
+  int l = lo0, h = hi0;
+  if (DC_EPW == 2) {
+    const int lo1 = __builtin_amdgcn_readlane(lo, lane_in_half + 32), hi1 = __builtin_amdgcn_readlane(hi, lane_in_half + 32);
+    l = half ? lo1 : lo0; h = half ? hi1 : hi0;
+  }
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned int)h << 32) | (unsigned int)l));
 }
 
 // Jacobian of point c on body b along d, written to E.rJ[r] (fp32)
@@ -507,7 +563,6 @@ __device__ __attribute__((noinline)) void dc_contact_rows(int hf, int base, int 
     dc_jac(hf, base + k, b, c, dir[k]);
     const double vel = dc_build_row(hf, base + k, other, -dir[k][0], -dir[k][1], c[0], c[1]);
     E.rImp[base + k] = imp;
-    { const double A_ = E.rA[base + k], reg_ = A_ * (1 - imp) / imp; E.rReg[base + k] = reg_; E.rInv[base + k] = 1.0 / (A_ + reg_); }
     if (k == 0) { E.rAref[base] = -bcoef * vel + kcoef * depth; E.rTouch[base] = (short)g_dg.sph_touch[s]; }
     else { E.rAref[base + k] = -bcoef * vel; E.rParent[base + k] = (short)base; E.rMu[base + k] = mu; }
   }
@@ -697,7 +752,6 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         for (int k = 0; k < DG_NV; k++) E.rJ[r][k] = k == 6 + u ? (float)sign : 0.f;
         const double vel = dc_build_row(hf, r, -1, 0, 0, 0, 0);
         E.rImp[r] = dg_impedance(depth);
-        { const double A_ = E.rA[r], im_ = E.rImp[r], reg_ = A_ * (1 - im_) / im_; E.rReg[r] = reg_; E.rInv[r] = 1.0 / (A_ + reg_); }
         E.rAref[r] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * depth;
       }
       nrows += fit;
@@ -753,16 +807,68 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
             dc_jac(hf, nrows, 0, E.pos, j);
             const double vel = dc_build_row(hf, nrows, BOX_ID, -j[0], -j[1], (double)E.wfb[BOX_ID][0], (double)E.wfb[BOX_ID][1]);
             E.rImp[nrows] = dg_impedance(viol);
-            { const double A_ = E.rA[nrows], im_ = E.rImp[nrows], reg_ = A_ * (1 - im_) / im_; E.rReg[nrows] = reg_; E.rInv[nrows] = 1.0 / (A_ + reg_); }
             E.rAref[nrows] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * viol;
           }
           nrows += 1;
         }
       }
     }
+    if (u < DG_NV) E.qacc[u] = qacc_u;   // qacc0 for the rows' initial constraint accelerations
     __syncthreads();
-    // ---- projected Gauss-Seidel: rows in sequence, the dot product J.qacc across the lanes ---
-    const int nmax = DC_EPW == 2 ? max(nrows, __shfl(nrows, (lane + 32) & 63)) : nrows;   // both halves walk the longer list
+    // both envs of the wavefront take the same path: every row on its own lane (<= 32 rows: the usual case), or
+    // the row-by-row loop
+    const int nother = DC_EPW == 2 ? __shfl(nrows, (lane + 32) & 63) : nrows;
+    const int nmax = max(nrows, nother);
+    const bool fast = nmax <= DC_PGS_LANES;
+    const double a0 = dc_rows_finish(hf, u, nrows, fast);
+    if (fast) {
+      // ---- projected Gauss-Seidel on the Delassus matrix: lane r owns row r (its accumulated force f and its
+      //      constraint acceleration acc = J_r qacc + planar-body term).  Updating row r changes every row's acc by
+      //      A[.][r] df: one broadcast (v_readlane: r is uniform) and one multiply-add per lane, no barrier, no
+      //      19-term dot product.  Same sweep order, bounds and arithmetic as the row-by-row form (A in fp32).
+      const bool mine = u < nrows;
+      const int ur = mine ? u : 0;
+      const float* Arow = reinterpret_cast<const float*>(&E.M[0][0]) + ur * (DC_PGS_LANES + 1);
+      double acc = a0, f = 0, fn_contact = 0;
+      const double aref = E.rAref[ur], reg = E.rReg[ur], inv = E.rInv[ur], mu = E.rMu[ur];
+      const bool okA = mine && E.rA[ur] > 0, isfric = E.rParent[ur] >= 0;
+#pragma unroll 1
+      for (int it = 0; it < DG_PGS_ITERS; it++)
+#pragma unroll 1
+        for (int r = 0; r < nmax; r++) {
+          double fnew = f + (aref - acc - reg * f) * inv;
+          const double lo = isfric ? -mu * fn_contact : 0.0, hi = isfric ? mu * fn_contact : 1e30;
+          if (fnew < lo) fnew = lo;
+          if (fnew > hi) fnew = hi;
+          const double df_mine = (u == r && okA) ? fnew - f : 0.0;
+          const double df = dc_bcast(df_mine, r, half);
+          if (u == r) f += df;
+          // friction rows follow their contact's normal row: every lane remembers the last normal row's force
+          const double fb = dc_bcast(f, r, half);
+          const double nrm = dc_bcast(isfric ? 0.0 : 1.0, r, half);
+          if (nrm != 0.0) fn_contact = fb;
+          if (r < nrows) acc += (double)Arow[r] * df;
+        }
+      if (mine) E.rF[u] = f;
+      __syncthreads();
+      if (u < DG_NV) {
+        double q = qacc_u;
+#pragma unroll 1
+        for (int r = 0; r < nrows; r++) q += (double)E.rW[r][u] * E.rF[r];
+        qacc_u = q;
+      }
+      if (u < NBODY) {   // planar bodies: accelerations from the rows that act on them
+        float b6 = E.wfb[u][6], b7 = E.wfb[u][7], b8 = E.wfb[u][8];
+        for (int r = 0; r < nrows; r++)
+          if (E.rOther[r] == u) {
+            const double fr = E.rF[r];
+            b6 += (float)((double)E.rOu[r][0] * fr); b7 += (float)((double)E.rOu[r][1] * fr); b8 += (float)((double)E.rOu[r][2] * fr);
+          }
+        E.wfb[u][6] = b6; E.wfb[u][7] = b7; E.wfb[u][8] = b8;
+      }
+      __syncthreads();
+    } else {
+    // ---- projected Gauss-Seidel, row by row (an env with more than 32 rows): the dot product J.qacc across the lanes ---
 #pragma unroll 1
     for (int it = 0; it < DG_PGS_ITERS; it++)
 #pragma unroll 1
@@ -805,6 +911,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         }
         __syncthreads();
       }
+    }
     if (u < DG_NV) E.qacc[u] = qacc_u;
     if (u < 8) {
       double t = 0;

@@ -291,6 +291,7 @@ static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((ui
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline double __longlong_as_double(long long i) { double d; memcpy(&d, &i, 8); return d; }
+static inline long long __double_as_longlong(double d) { long long i; memcpy(&i, &d, 8); return i; }
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 static inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
@@ -303,6 +304,8 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define __builtin_amdgcn_sinf(x) sinf(6.28318530717958647692f * (x))   // argument in revolutions
 #define __builtin_amdgcn_cosf(x) cosf(6.28318530717958647692f * (x))
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+// v_readlane_b32 (the lane index is wave-uniform): the value of one lane, in every lane of the wavefront
+#define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l), 64)
 #if !defined(__clang__)
 #define __builtin_readcyclecounter() __builtin_ia32_rdtsc()
 #endif

