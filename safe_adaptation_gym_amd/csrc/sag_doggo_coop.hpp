@@ -295,47 +295,45 @@ __device__ __attribute__((noinline)) double dc_solve1(int hf, int u, double x) {
   }
   return x;
 }
-// M^-1: 19 right-hand sides (identity), lane i holds component i of each; result row i -> E.Minv[i][:]
-__device__ __attribute__((noinline)) void dc_inverse(int hf, int u) {
+// M^-1 = L^-T L^-1 from the Cholesky factor in E.M, and qacc0 = M^-1 tau on the way (returned: component u).
+// Lane j forward-substitutes COLUMN j of L^-1 on its own (171 multiply-adds on rows of L that every lane reads at the
+// same address: LDS broadcasts, no exchange between lanes), parks it in E.Minv, then lane a forms row a of
+// M^-1 = sum_k Linv[k][a] Linv[k][:].  4 barriers; the previous form - 19 right-hand sides through 2 x 19
+// substitution steps with two barriers each - was 11 % of the kernel.
+__device__ __attribute__((noinline)) double dc_inverse(int hf, int u) {
   DC_ENV;
-  double x[DG_NV];
+  if (u < DG_NV) E.col[u] = 1.0 / E.M[u][u];
+  __syncthreads();
+  double x[DG_NV];   // column u of L^-1 (zero above the diagonal)
+  const int uc = u < DG_NV ? u : DG_NV - 1;
 #pragma unroll
-  for (int r = 0; r < DG_NV; r++) x[r] = (u == r) ? 1.0 : 0.0;
-#pragma unroll 1
-  for (int j = 0; j < DG_NV; j++) {
-    if (u == j) {
-      const double inv = 1.0 / E.M[j][j];
+  for (int i = 0; i < DG_NV; i++) {
+    double sacc = 0;
 #pragma unroll
-      for (int r = 0; r < DG_NV; r++) { x[r] *= inv; E.Minv[0][r] = x[r]; }   // row 0 of Minv doubles as the broadcast buffer
-    }
-    __syncthreads();
-    if (u > j && u < DG_NV) {
-      const double l = E.M[u][j];
-#pragma unroll
-      for (int r = 0; r < DG_NV; r++) x[r] -= l * E.Minv[0][r];
-    }
-    __syncthreads();
-  }
-#pragma unroll 1
-  for (int j = DG_NV - 1; j >= 0; j--) {
-    if (u == j) {
-      const double inv = 1.0 / E.M[j][j];
-#pragma unroll
-      for (int r = 0; r < DG_NV; r++) { x[r] *= inv; E.Minv[0][r] = x[r]; }
-    }
-    __syncthreads();
-    if (u < j) {
-      const double l = E.M[j][u];
-#pragma unroll
-      for (int r = 0; r < DG_NV; r++) x[r] -= l * E.Minv[0][r];
-    }
-    __syncthreads();
+    for (int k = 0; k < i; k++) sacc += E.M[i][k] * x[k];
+    x[i] = i < uc ? 0.0 : (i == uc ? E.col[i] : -sacc * E.col[i]);
   }
   if (u < DG_NV) {
 #pragma unroll
-    for (int r = 0; r < DG_NV; r++) E.Minv[u][r] = x[r];
+    for (int i = 0; i < DG_NV; i++) E.Minv[i][u] = x[i];
   }
   __syncthreads();
+  double row[DG_NV], q0 = 0;
+#pragma unroll
+  for (int b = 0; b < DG_NV; b++) {
+    double v = 0;
+#pragma unroll
+    for (int k = b; k < DG_NV; k++) v += x[k] * E.Minv[k][b];   // (x[k] = 0 for k < u)
+    row[b] = v;
+    q0 += v * E.tau[b];
+  }
+  __syncthreads();   // every lane has read the parked columns
+  if (u < DG_NV) {
+#pragma unroll
+    for (int b = 0; b < DG_NV; b++) E.Minv[u][b] = row[b];
+  }
+  __syncthreads();
+  return q0;
 }
 
 }  // namespace sag
@@ -732,8 +730,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       for (int j = 0; j < DG_NV; j++) E.Mlin[u][j] = j >= u ? E.M[u][j] : 0.0;
     __syncthreads();
     dc_cholesky(hf, u);
-    qacc_u = dc_solve1(hf, u, u < DG_NV ? E.tau[u] : 0.0);
-    dc_inverse(hf, u);
+    qacc_u = dc_inverse(hf, u);   // M^-1 and qacc0 = M^-1 tau
     if (u < 8) E.touch[u] = 0;
     int nrows = 0;
     // ---- rows: joint limits (lane j), in ascending joint order ---------------------------------

@@ -12,7 +12,7 @@ from safe_adaptation_gym_amd import _native as nat
 from safe_adaptation_gym_amd.robot import Robot
 from safe_adaptation_gym_amd.tasks.task import Task
 from safe_adaptation_gym_amd.utils import ResamplingError
-from safe_adaptation_gym_amd.world import World
+from safe_adaptation_gym_amd import consts
 
 TAPE_WORDS = 1024  # raw generator words offered to the device per env per step (parity mode)
 
@@ -124,7 +124,9 @@ class BatchedSafeAdaptationGym:
     """A Task instance / class (every env gets its own instance of that class) or a
     sequence of n_envs instances (heterogeneous batch)."""
     self._tasks = self._expand_tasks(task)
-    World(np.random.RandomState(0), self._tasks[0], self.robot, self.base_config)  # validates config keys
+    unknown = set(self.base_config or {}) - set(consts.WORLD_DEFAULT)   # the reference accepts anything (world.py:43-44)
+    if unknown:
+      raise KeyError(f'unknown world config keys: {sorted(unknown)}')
     self._task_ids = np.array([t.TASK_ID for t in self._tasks], np.int32)
     self._reward_dim = max(t.REWARD_DIM for t in self._tasks)
     self._persist = None  # task attributes that outlive an episode (filled by _pull_task_state)

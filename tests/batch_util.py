@@ -5,7 +5,7 @@ import numpy as np
 from safe_adaptation_gym_amd import _native as nat
 from safe_adaptation_gym_amd import benchmark
 from safe_adaptation_gym_amd.robot import Robot
-from safe_adaptation_gym_amd.world import World
+from world import World
 
 
 def sample_records_native(robot_name, task_names, n, seed=666, config=None):

@@ -6,7 +6,7 @@ import pytest
 import golden_util as gu
 from safe_adaptation_gym_amd import benchmark
 from safe_adaptation_gym_amd.robot import Robot
-from safe_adaptation_gym_amd.world import World
+from world import World
 
 RESETS = gu.load_json_gz('resets.json.gz')
 
@@ -88,7 +88,7 @@ def test_impossible_layout_raises_resampling_error():
   cfg = {'hazards_size': 2.0, 'vases_size': 2.0, 'pillars_size': 2.0, 'gremlins_size': 2.0}
   w = World(np.random.RandomState(0), benchmark.TASKS['go_to_goal'](), Robot('xmls/doggo.xml'), cfg)
   w._generate_new_layout.__func__  # exists
-  import safe_adaptation_gym_amd.world as wm
+  import world as wm
   # keep the test fast: the first placement after the robot can never fit, so one
   # attempt already shows the failure mode; bound the outer loop
   orig = wm.World._generate_new_layout

@@ -7,7 +7,7 @@ import golden_util as gu
 from safe_adaptation_gym_amd import _native as nat
 from safe_adaptation_gym_amd import benchmark
 from safe_adaptation_gym_amd.robot import Robot
-from safe_adaptation_gym_amd.world import World
+from world import World
 
 RESETS = gu.load_json_gz('resets.json.gz')
 

@@ -1,5 +1,6 @@
-"""Host-side world: config, placements, rejection-sampled layout and the record that
-`sag_set_layout` installs on the device.
+"""TEST MIRROR of the reference's host-side World: config, placements, rejection-sampled layout and the record that
+`sag_set_layout` installs on the device.  The product samples layouts natively (`sag_sample_layouts`,
+csrc/sag_sampler.cpp); this Python restatement is what tests/test_native_sampler.py holds it against.
 
 Mirrors what the reference's World does at construction / reset time (world.py:36-137,
 172-217) with the same RandomState draw order, so a given seed yields

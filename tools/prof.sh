@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 # FULL=1: the whole default bench (every config: lidar+cost kernel, Car, Doggo, render) instead of the headline only
-ARGS="bench.py --steps ${STEPS:-30} --warmup 5 ${FULL:+--cpu-baseline-seconds 1} $([ -z "$FULL" ] && echo --no-c2 --no-cpu-baseline) ${BENCH_ARGS}"
+ARGS="bench.py --steps ${STEPS:-30} --warmup 5 ${FULL:+--cpu-baseline-seconds 1} $([ -z "$FULL" ] && echo --no-c2 --no-cpu-baseline || true) ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || true
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc1 -- python3 $ARGS > /dev/null 2> $OUT/pmc1.err || true
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc2 -- python3 $ARGS > /dev/null 2> $OUT/pmc2.err || true
