@@ -248,6 +248,15 @@ struct BV {  // body view used by the contact solver
 struct Sol { float bcoef, kcoef, mu; };  // soft-contact reference acceleration + friction of a pair
 
 __device__ inline float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// a[k] of a small register array for a run-time k, as a select chain: an indexed access would put the array into
+// scratch memory (the 32 B of scratch the quiet kernel had: the two pillar coordinates, read back in two loops)
+template <int N>
+__device__ inline float pick(const float (&a)[N], int k) {
+  float v = a[0];
+#pragma unroll
+  for (int z = 1; z < N; z++) v = k == z ? a[z] : v;
+  return v;
+}
 
 __device__ inline float minv_apply(const BV& b, float dx, float dy, float rxd, float u[3]) {
   u[0] = b.m0 * dx + b.m1 * dy + b.m2 * rxd;
@@ -336,10 +345,14 @@ __device__ inline int cb_contact(BV& Circ, BV& Box, float cx, float cy, float r,
 
 // vertices of box P strictly inside box Q. If q_is_A the normal A->B is Q's outward
 // normal, else its negative.  A/B are passed in solver order.
+// All four vertices are tested in one straight-line pass (a 4-bit mask per lane); each lane then solves ITS inside
+// vertices in ascending order, so a wavefront runs the contact solve max-inside-count times (1 - 2), not once per
+// vertex index that any lane has inside.  Same arithmetic per vertex as the plain loop (-DSAG_VERTS_REF keeps it).
 __device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp, float sp, float phx,
                                    float phy, float qxc, float qyc, float cq, float sq, float qhx,
                                    float qhy, bool q_is_A, const Sol& sol) {
   int n = 0;
+#ifdef SAG_VERTS_REF
 #pragma unroll 1
   for (int k = 0; k < 4; k++) {
     float sx = (k == 0 || k == 3) ? phx : -phx, sy = (k < 2) ? phy : -phy;
@@ -355,6 +368,32 @@ __device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp,
     solve_contact(A, B, sgn * (cq * onx - sq * ony), sgn * (sq * onx + cq * ony), vx, vy, depth, sol);
     n++;
   }
+#else
+  uint32_t inside = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float sx = (k == 0 || k == 3) ? phx : -phx, sy = (k < 2) ? phy : -phy;
+    const float vx = pxc + cp * sx - sp * sy, vy = pyc + sp * sx + cp * sy;
+    const float wx = vx - qxc, wy = vy - qyc;
+    const float lx = cq * wx + sq * wy, ly = -sq * wx + cq * wy;
+    const float dx = qhx - fabsf(lx), dy = qhy - fabsf(ly);
+    inside |= (uint32_t)!(dx <= 0 || dy <= 0) << k;
+  }
+  for (; inside; inside &= inside - 1) {
+    const int k = __ffs(inside) - 1;
+    const float sx = (k == 0 || k == 3) ? phx : -phx, sy = (k < 2) ? phy : -phy;
+    const float vx = pxc + cp * sx - sp * sy, vy = pyc + sp * sx + cp * sy;
+    const float wx = vx - qxc, wy = vy - qyc;
+    const float lx = cq * wx + sq * wy, ly = -sq * wx + cq * wy;
+    const float dx = qhx - fabsf(lx), dy = qhy - fabsf(ly);
+    float onx, ony, depth;
+    if (dx < dy) { onx = lx >= 0 ? 1.f : -1.f; ony = 0; depth = dx; }
+    else { onx = 0; ony = ly >= 0 ? 1.f : -1.f; depth = dy; }
+    const float sgn = q_is_A ? 1.f : -1.f;
+    solve_contact(A, B, sgn * (cq * onx - sq * ony), sgn * (sq * onx + cq * ony), vx, vy, depth, sol);
+    n++;
+  }
+#endif
   return n;
 }
 
@@ -1448,7 +1487,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (k == capP) k = SAG_MAX_PILLARS;  // jump over unused pillar slots to the buttons
       const bool is_p = k < SAG_MAX_PILLARS;
       const bool on = (is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB)) && !ABL(ABL_NO_RS);
-      const float sx = stx[k], syy = sty[k], sr = is_p ? psz : BUTTON_R;
+      const float sx = pick(stx, k), syy = pick(sty, k), sr = is_p ? psz : BUTTON_R;
       const float dx = sx - R.x, dyy = syy - R.y, rs = my_bound + sr;
       if (on && dx * dx + dyy * dyy <= rs * rs) {
         BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
@@ -1520,7 +1559,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
           if (q == capP) q = SAG_MAX_PILLARS;
           const bool is_p = q < SAG_MAX_PILLARS;
           const bool on = (is_p ? (q < nP) : (q - SAG_MAX_PILLARS < nB)) && !ABL(ABL_NO_VS);
-          const float dx = stx[q] - bx_, dyy = sty[q] - by_, rs = br + (is_p ? psz : BUTTON_R);
+          const float dx = pick(stx, q) - bx_, dyy = pick(sty, q) - by_, rs = br + (is_p ? psz : BUTTON_R);
           if (on && dx * dx + dyy * dyy <= rs * rs) shit |= 1u << q;
         }
         for (uint32_t mq = shit; mq; mq &= mq - 1) {
@@ -1734,9 +1773,10 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       const bool is_p = k < SAG_MAX_PILLARS;
       const bool on = is_p ? (k < nP) : (k - SAG_MAX_PILLARS < nB);
       const float sr = is_p ? psz : BUTTON_R;
-      const float dx = stx[k] - R.x, dyy = sty[k] - R.y, rs = rr + sr;
+      const float skx = pick(stx, k), sky = pick(sty, k);
+      const float dx = skx - R.x, dyy = sky - R.y, rs = rr + sr;
       if constexpr (FINE) {
-        const float ex = stx[k] - Bx, ey = sty[k] - By;
+        const float ex = skx - Bx, ey = sky - By;
         busy |= on && (dx * dx + dyy * dyy <= (fa + sr) * (fa + sr) || ex * ex + ey * ey <= (fb + sr) * (fb + sr));
       } else busy |= on && dx * dx + dyy * dyy <= rs * rs;
     }
@@ -2087,7 +2127,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
           lid(LP(LS_X, k), LP(LS_Y, k));
 #pragma unroll 1
         for (int k = 0; k < SAG_MAX_PILLARS; k++)
-          if (k < nP) lid(stx[k], sty[k]);
+          if (k < nP) lid(pick(stx, k), pick(sty, k));
       } else if (chunk == 1 || chunk == 2) {
         const int want = chunk == 1 ? 3 : 2;  // GROUP_OBJECTS then GROUP_GOAL (consts.py:13-16)
         if (chunk == 1 && has_box) lid(boxx, boxy);
@@ -2097,7 +2137,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
             int g;
             if (task == SAG_TASK_COLLECT) g = (act >> b & 1) ? 2 : 0;
             else g = bstate == 0 ? 0 : (b == gb ? 2 : 3);
-            if (g == want) lid(stx[(SAG_MAX_PILLARS + b) % NSTAT], sty[(SAG_MAX_PILLARS + b) % NSTAT]);
+            if (g == want) lid(pick(stx, (SAG_MAX_PILLARS + b) % NSTAT), pick(sty, (SAG_MAX_PILLARS + b) % NSTAT));
           }
         }
         if (chunk == 2 && nB == 0) lid(goalx, goaly);
@@ -2207,10 +2247,11 @@ __global__ __launch_bounds__(WAVE, 1) void k_step_doggo_post(StepArgs p) {
 
 #ifndef SAG_DOGGO_LANE_TU   // the rest of the file: kernels of the main translation unit (sag_api.hip)
 #ifndef SAG_QUIET_MIN_WAVES
-#define SAG_QUIET_MIN_WAVES 4
+#define SAG_QUIET_MIN_WAVES 4   // 128 VGPRs: a busy wavefront (250) and TWO quiet ones share a SIMD's 512 registers; at 3 (136 VGPRs, no
+                               // 16-B spill) only one fits beside it: measured 0.88 vs 0.97 ms per Point step at 4 M envs
 #endif
 #ifndef SAG_CAR_QUIET_MIN_WAVES
-#define SAG_CAR_QUIET_MIN_WAVES 3   // 155 VGPRs instead of 128 + spills (measured: 1.159 -> 1.146 ms at 1 M envs)
+#define SAG_CAR_QUIET_MIN_WAVES 3   // Car: 155 VGPRs without spills (at 4: 128 + 144 B of scratch; 1.159 -> 1.146 ms at 1 M envs)
 #endif
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_QUIET_MIN_WAVES : SAG_QUIET_MIN_WAVES) void k_step_quiet(StepArgs p) {
