@@ -83,6 +83,18 @@ __device__ inline void dc_rot_apply(double* R, const double* axis, double ang) {
 __device__ __attribute__((noinline)) void dc_kinematics(int hf, int u) {
   DC_ENV;
   const DgModel& M = g_dg;
+  // the 13 joint rotations once (lane j: two fp64 sin / cos, ~300 instructions), parked in LDS over F / fb, which are
+  // written only after this phase; every chain walk below then multiplies ready matrices - before, each lane
+  // re-derived up to three of them in each of its two roles
+  static_assert(sizeof(double) * DG_NJ * 9 <= sizeof(double) * (DG_NV * 6 + DG_NB * 6), "joint rotations fit into F + fb");
+  double* RJ = &E.F[0][0];
+  if (u < DG_NJ) {
+    double Rj[9];
+    dg_axis_rot(M.axis[u], E.q[u], Rj);
+#pragma unroll
+    for (int k = 0; k < 9; k++) RJ[u * 9 + k] = Rj[k];
+  }
+  __syncthreads();
   double R0[9];
   dg_quat2mat(E.quat, R0);
   // dof role
@@ -102,7 +114,7 @@ __device__ __attribute__((noinline)) void dc_kinematics(int hf, int u) {
         dg_matvec(R, M.bpos[c], off);
         for (int k = 0; k < 3; k++) p[k] += off[k];
         const int d0 = dc_first_dof(c), nd = dc_ndof(c);
-        for (int d = d0; d < d0 + nd && d < u; d++) dc_rot_apply(R, M.axis[d - 6], E.q[d - 6]);
+        for (int d = d0; d < d0 + nd && d < u; d++) dg_matmul(R, RJ + (d - 6) * 9, R);
       }
       dg_matvec(R, M.axis[u - 6], a);
       const double r[3] = {p[0] - E.pos[0], p[1] - E.pos[1], p[2] - E.pos[2]};
@@ -122,7 +134,7 @@ __device__ __attribute__((noinline)) void dc_kinematics(int hf, int u) {
       dg_matvec(R, M.bpos[c], off);
       for (int k = 0; k < 3; k++) p[k] += off[k];
       const int d0 = dc_first_dof(c), nd = dc_ndof(c);
-      for (int d = d0; d < d0 + nd; d++) dc_rot_apply(R, M.axis[d - 6], E.q[d - 6]);
+      for (int d = d0; d < d0 + nd; d++) dg_matmul(R, RJ + (d - 6) * 9, R);
     }
     for (int k = 0; k < 9; k++) E.R[u][k] = R[k];
     for (int k = 0; k < 3; k++) E.p[u][k] = p[k];
@@ -503,12 +515,20 @@ __device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nr
     if (fast) {
 #pragma unroll
       for (int k = 0; k < DG_NV; k++) a0 += Jr[k] * E.qacc[k];
+      // A is symmetric: lane rr computes the entries (rr, rr + k mod R) for k = 0 .. R / 2 and stores both copies
+      // (for even R the k = R / 2 entries would be computed twice: the lower half of the lanes takes them)
+      const int half_r = nrows >> 1;
 #pragma unroll 1
-      for (int sr = 0; sr < nrows; sr++) {
+      for (int kk = 0; kk <= half_r; kk++) {
+        if (kk == half_r && !(nrows & 1) && rr >= half_r) break;
+        int sr = rr + kk;
+        if (sr >= nrows) sr -= nrows;
         double v = 0;
 #pragma unroll
         for (int k = 0; k < DG_NV; k++) v += Jr[k] * (double)E.rW[sr][k];
-        Abuf[rr * (DC_PGS_LANES + 1) + sr] = (float)(v + dc_body_coupling(E, rr, sr));
+        const float av = (float)(v + dc_body_coupling(E, rr, sr));
+        Abuf[rr * (DC_PGS_LANES + 1) + sr] = av;
+        Abuf[sr * (DC_PGS_LANES + 1) + rr] = av;
       }
     }
   }

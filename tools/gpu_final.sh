@@ -1,0 +1,15 @@
+#!/bin/bash
+# round-end measurement: parity suite, the default bench line, steady-state traffic passes of the headline and the Car config
+export PYTHONPATH=$PWD:$PWD/tests
+rm -f gpurun_out/r02_free_running_drift.txt
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r02_gputest_final.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/r02_gputest_final.log
+STEPS=30 timeout -k 10 500 tools/prof.sh r02_point > gpurun_out/r02_prof_point.log 2>&1
+python tools/prof_steady.py gpurun_out/prof_r02_point 30 4194304 point > gpurun_out/r02_point_4M_steady.txt; grep -E "kernel trace|algorithmic|HBM traffic" gpurun_out/r02_point_4M_steady.txt
+BENCH_ARGS="--robot car --task push_box --envs 4194304 --burn-in 60" STEPS=20 timeout -k 10 600 tools/prof.sh r02_car > gpurun_out/r02_prof_car.log 2>&1
+python tools/prof_steady.py gpurun_out/prof_r02_car 20 4194304 car > gpurun_out/r02_car_4M_steady.txt; grep -E "kernel trace|algorithmic|HBM traffic" gpurun_out/r02_car_4M_steady.txt
+cp profiles/traffic.json gpurun_out/traffic_r02.json
+timeout -k 10 600 python bench.py > gpurun_out/r02_bench_all_configs.json 2> gpurun_out/r02_bench.err; python -c "
+import json; r=json.load(open('gpurun_out/r02_bench_all_configs.json'))
+print('headline', r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline']['traffic'])
+for k in ('c2_4096_envs','c2_lidar_cost_only','c3_car_push_box','c4_doggo_multitask_4096','c5_doggo_haul_box_rgb_4096','cpu_baseline'):
+  print(k, json.dumps(r.get(k))[:600])"
