@@ -32,12 +32,14 @@ def up_to_date():
   return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-  if not force and up_to_date():
+def build(force=False, verbose=False, extra=(), out=None):
+  """out: path of a VARIANT library (tools/ab.sh, profiling builds with -D switches) - always rebuilt, own object dir."""
+  if out is None and not force and up_to_date():
     return LIB
+  lib = out or LIB
   base = [hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-fast-math', '-ffp-contract=off', '-Wall',
           '-Wno-unused-function', '-pthread', *extra]
-  objdir = os.path.join(HERE, 'build')
+  objdir = os.path.join(HERE, 'build', os.path.basename(lib) if out else '')
   os.makedirs(objdir, exist_ok=True)
   jobs = []
   for src in SOURCES:   # the translation units compile side by side
@@ -49,14 +51,18 @@ def build(force=False, verbose=False, extra=()):
   for cmd, obj, proc in jobs:
     if proc.wait() != 0:
       raise subprocess.CalledProcessError(proc.returncode, cmd)
-  link = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB] + [j[1] for j in jobs]
+  link = [hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', lib] + [j[1] for j in jobs]
   if verbose:
     print(' '.join(link))
   subprocess.check_call(link)
-  return LIB
+  return lib
 
 
 if __name__ == '__main__':
-  build(force='--force' in sys.argv, verbose=True,
-        extra=['-Rpass-analysis=kernel-resource-usage'] if '--usage' in sys.argv else ())
-  print(LIB)
+  # python -m safe_adaptation_gym_amd.build [--force] [--usage] [--out libsag_<name>.so] [-DSWITCH ...]
+  argv = sys.argv[1:]
+  out = os.path.join(HERE, argv[argv.index('--out') + 1]) if '--out' in argv else None
+  extra = [a for a in argv if a.startswith('-D') or a.startswith('-mllvm') or a.startswith('-amdgpu')]
+  if '--usage' in argv:
+    extra.append('-Rpass-analysis=kernel-resource-usage')
+  print(build(force='--force' in argv, verbose=True, extra=extra, out=out))

@@ -605,7 +605,7 @@ enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL
 enum { CY_LOAD = 0, CY_ROBOT, CY_RS, CY_RV, CY_VS, CY_VV_BROAD, CY_VV_NARROW, CY_INTEG, CY_WRITEBACK,
        CY_REWARD, CY_RESAMPLE, CY_COST, CY_LIDAR, CY_OBS_STORE, CY_TAIL, CY_N };
 #ifdef SAG_CYCLES
-__device__ unsigned long long g_cyc[3][CY_N + 1];
+static __device__ unsigned long long g_cyc[3][CY_N + 1];
 #define CYC_DECL unsigned long long cyc_acc[CY_N] = {}; unsigned long long cyc_t = __builtin_readcyclecounter();
 #define CYC(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); cyc_acc[k] += t_ - cyc_t; cyc_t = t_; } while (0)
 #define CYC_FLUSH(mode) do { if (lane == 0) { for (int k_ = 0; k_ < CY_N; k_++) atomicAdd(&g_cyc[mode][k_], cyc_acc[k_]); atomicAdd(&g_cyc[mode][CY_N], 1ull); } } while (0)

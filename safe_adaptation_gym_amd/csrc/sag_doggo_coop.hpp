@@ -21,20 +21,33 @@
 namespace sag {
 
 constexpr int DC_ROWS = DG_MAXROWS;              // max constraint rows per env (same cap as the lane-per-env form)
+constexpr int DC_PGS_LANES = 32;                // fast PGS path: one constraint row per lane
 struct DcEnv {                                  // one env's working set in LDS
   double pos[3], quat[4], q[DG_NJ], vlin[3], wloc[3], qd[DG_NJ];
-  double R[DG_NB][9], p[DG_NB][3];
-  double S[DG_NV][6];                           // [a; l]
-  double Ib[DG_NB][10], Ic[DG_NB][10];          // m, mc[3], I[6]
-  double F[DG_NV][6];                           // CRBA: Ic[body(j)] S_j ; RNEA: scratch
-  double fb[DG_NB][6];
-  double M[DG_NV][DG_NV + 1];                   // mass matrix, then its Cholesky factor (lower); +1: bank padding
-  double Minv[DG_NV][DG_NV + 1];
-  double bias[DG_NV], tau[DG_NV], qacc[DG_NV], qdv[DG_NV], col[DG_NV];
-  double sph[DG_NS][3];
+  // Two regions are reused within a substep - 18.5 KB per env instead of 25.6, so that FOUR wavefronts (one per SIMD)
+  // fit a CU's 160 KB of LDS instead of three:
+  union {
+    struct {                                    // kinematics .. constraint Jacobians (dc_jac is the last reader)
+      double R[DG_NB][9], p[DG_NB][3];
+      double S[DG_NV][6];                       // [a; l]
+      double Ib[DG_NB][10], Ic[DG_NB][10];      // m, mc[3], I[6]
+      double F[DG_NV][6];                       // CRBA: Ic[body(j)] S_j ; RNEA: scratch
+      double fb[DG_NB][6];
+    };
+    float A[DC_PGS_LANES * DC_PGS_LANES];       // Delassus matrix J M^-1 J^T of the fast PGS path (symmetric, no padding:
+  };                                            // lane u reads its row as the column A[r][u] - consecutive words)
+  union {
+    struct {
+      double M[DG_NV][DG_NV + 1];               // mass matrix -> Cholesky factor L (lower) -> L and L^-1 -> M^-1
+      double bias[DG_NV], tau[DG_NV];
+      double sph[DG_NS][3];
+    };
+    float rW[DC_ROWS][DG_NV];                   // W = J M^-1 (fp32 like J): written once M^-1 sits in registers
+  };
+  double qacc[DG_NV], qdv[DG_NV], col[DG_NV];
   double touch[8];
-  float rJ[DC_ROWS][DG_NV], rW[DC_ROWS][DG_NV];   // W in fp32 like J: 51 KB per wavefront -> three per CU
-  double Mlin[2][DG_NV];                        // rows 0, 1 of the mass matrix (momentum, Unsupervised)
+  double com[2], mom[2];                        // centre of mass, momentum / mass (outputs; from Ib and M rows 0, 1)
+  float rJ[DC_ROWS][DG_NV];
   double rA[DC_ROWS], rAref[DC_ROWS], rImp[DC_ROWS], rF[DC_ROWS], rMu[DC_ROWS];
   double rReg[DC_ROWS], rInv[DC_ROWS];           // A (1 - d) / d and 1 / (A + reg): no division inside the PGS sweeps
   float rOu[DC_ROWS][3], rOd[DC_ROWS][2], rOrx[DC_ROWS], rOry[DC_ROWS];
@@ -42,16 +55,28 @@ struct DcEnv {                                  // one env's working set in LDS
   float wfb[NBODY][9], wminv[NBODY][6];         // planar free bodies
   int nrows, flag;
 };
+static_assert(sizeof(float) * DC_PGS_LANES * DC_PGS_LANES <= sizeof(double) * (DG_NB * 38 + DG_NV * 12), "A fits the kinematics region");
 
 // Both envs of the wavefront.  File scope, so that the (non-inlined) phase functions address it as LDS:
 // through a `DcEnv&` parameter every access would be a flat instruction.
-// DC_EPW envs per wavefront (32 lanes each): 2 = 51 KB of LDS per wavefront, three wavefronts per CU.
+// DC_EPW envs per wavefront (32 lanes each): 2 = 37 KB of LDS per wavefront, four wavefronts per CU.
 // 1 (a 32-thread workgroup per env, six per CU) was measured slower: 10.4 vs 8.4 ms at 4096 envs.
 #ifndef DC_EPW
 #define DC_EPW 2
 #endif
 __shared__ DcEnv g_dc_env[DC_EPW];
 #define DC_ENV DcEnv& E = g_dc_env[hf]
+// section profile of k_doggo_physics (tools/cycles_doggo.py, -DSAG_CYCLES): lane 0's clock per section -> g_cyc[1][.]
+enum { DCY_LOAD = 0, DCY_KIN, DCY_BODIES, DCY_CRBA_RNEA, DCY_CHOL, DCY_INV, DCY_ROWS_SELF, DCY_ROWS_WORLD, DCY_FINISH, DCY_PGS,
+       DCY_AFTER, DCY_PLANAR, DCY_STORE, DCY_N };
+#ifdef SAG_CYCLES
+static_assert(DCY_N <= CY_N, "sections fit g_cyc");
+__shared__ unsigned long long g_dc_cyc[DCY_N], g_dc_cyc_t;
+#define DCC(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                    g_dc_cyc[k] += t_ - g_dc_cyc_t; g_dc_cyc_t = t_; } } while (0)
+#else
+#define DCC(k) do {} while (0)
+#endif
 
 // paths of the kinematic tree (static): bodies from the root's child down to b
 struct DcPath { int n, c0, c1, c2; __device__ int at(int s) const { return s == 0 ? c0 : (s == 1 ? c1 : c2); } };
@@ -309,7 +334,7 @@ __device__ __attribute__((noinline)) double dc_solve1(int hf, int u, double x) {
 }
 // M^-1 = L^-T L^-1 from the Cholesky factor in E.M, and qacc0 = M^-1 tau on the way (returned: component u).
 // Lane j forward-substitutes COLUMN j of L^-1 on its own (171 multiply-adds on rows of L that every lane reads at the
-// same address: LDS broadcasts, no exchange between lanes), parks it in E.Minv, then lane a forms row a of
+// same address: LDS broadcasts, no exchange between lanes), parks it beside L in E.M, then lane a forms row a of
 // M^-1 = sum_k Linv[k][a] Linv[k][:].  4 barriers; the previous form - 19 right-hand sides through 2 x 19
 // substitution steps with two barriers each - was 11 % of the kernel.
 __device__ __attribute__((noinline)) double dc_inverse(int hf, int u) {
@@ -325,9 +350,10 @@ __device__ __attribute__((noinline)) double dc_inverse(int hf, int u) {
     for (int k = 0; k < i; k++) sacc += E.M[i][k] * x[k];
     x[i] = i < uc ? 0.0 : (i == uc ? E.col[i] : -sacc * E.col[i]);
   }
-  if (u < DG_NV) {
+  if (u < DG_NV) {   // Linv[i][u] (i >= u) -> E.M[u][i + 1]: the strict upper part of the 19 x 20 array, L keeps the lower
 #pragma unroll
-    for (int i = 0; i < DG_NV; i++) E.Minv[i][u] = x[i];
+    for (int i = 0; i < DG_NV; i++)
+      if (i >= u) E.M[u][i + 1] = x[i];
   }
   __syncthreads();
   double row[DG_NV], q0 = 0;
@@ -335,14 +361,14 @@ __device__ __attribute__((noinline)) double dc_inverse(int hf, int u) {
   for (int b = 0; b < DG_NV; b++) {
     double v = 0;
 #pragma unroll
-    for (int k = b; k < DG_NV; k++) v += x[k] * E.Minv[k][b];   // (x[k] = 0 for k < u)
+    for (int k = b; k < DG_NV; k++) v += x[k] * E.M[b][k + 1];   // Linv[k][b]; (x[k] = 0 for k < u)
     row[b] = v;
     q0 += v * E.tau[b];
   }
-  __syncthreads();   // every lane has read the parked columns
+  __syncthreads();   // every lane has read the parked columns; L is dead: M^-1 takes the array
   if (u < DG_NV) {
 #pragma unroll
-    for (int b = 0; b < DG_NV; b++) E.Minv[u][b] = row[b];
+    for (int b = 0; b < DG_NV; b++) E.M[u][b] = row[b];
   }
   __syncthreads();
   return q0;
@@ -370,10 +396,12 @@ __device__ inline void dc_smooth(int hf, int u, const float* ctrl12) {
   DC_ENV;
   dc_kinematics(hf, u);
   __syncthreads();
+  DCC(DCY_KIN);
   dc_spheres(hf, u);
   dc_composite(hf, u);
   dc_rnea_bodies(hf, u);
   __syncthreads();
+  DCC(DCY_BODIES);
   dc_crba_f(hf, u);
   dc_rnea_bias(hf, u);
   __syncthreads();
@@ -391,6 +419,7 @@ __device__ inline void dc_smooth(int hf, int u, const float* ctrl12) {
     E.qdv[u] = u < 3 ? E.vlin[u] : (u < 6 ? E.wloc[u - 3] : E.qd[u - 6]);
   }
   __syncthreads();
+  DCC(DCY_CRBA_RNEA);
 }
 
 // debug: mass matrix [19x19], bias [19], qacc0 [19], Minv [19x19] per env -> out[N][19*19*2 + 38]
@@ -414,7 +443,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_coop_debug(const float* _
   dc_inverse(hf, u);
   if (live && u < DG_NV) {
     o[DG_NV * DG_NV + DG_NV + u] = x;
-    for (int j = 0; j < DG_NV; j++) o[DG_NV * DG_NV + 2 * DG_NV + u * DG_NV + j] = E.Minv[u][j];
+    for (int j = 0; j < DG_NV; j++) o[DG_NV * DG_NV + 2 * DG_NV + u * DG_NV + j] = E.M[u][j];
   }
 }
 
@@ -471,9 +500,7 @@ __device__ __attribute__((noinline)) double dc_build_row(int hf, int r, int othe
 }
 
 // fast PGS path: all rows of an env on its 32 lanes (one row per lane), the Delassus matrix A = J M^-1 J^T (+ the
-// coupling through a shared planar body) in LDS as fp32 [DC_PGS_LANES][DC_PGS_LANES + 1], aliasing M / Minv (dead once W exists)
-constexpr int DC_PGS_LANES = 32;
-static_assert(sizeof(float) * DC_PGS_LANES * (DC_PGS_LANES + 1) <= 2 * sizeof(double) * DG_NV * (DG_NV + 1), "A fits into M + Minv");
+// coupling through a shared planar body) in LDS as fp32 [DC_PGS_LANES][DC_PGS_LANES] over the kinematics region
 
 // contribution of a unit force increment of row s to the acceleration along row r through the planar body they share
 __device__ inline double dc_body_coupling(const DcEnv& E, int r, int s) {
@@ -486,10 +513,14 @@ __device__ inline double dc_body_coupling(const DcEnv& E, int r, int s) {
 // lane's own row).  Barriers inside; qacc0 must be in E.qacc.
 __device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nrows, bool fast) {
   DC_ENV;
-  if (u < DG_NV) {
-    double mi[DG_NV];   // row u of M^-1 (symmetric) in registers
+  double mi[DG_NV];   // row u of M^-1 (symmetric) in registers
+  {
+    const int uc = u < DG_NV ? u : DG_NV - 1;
 #pragma unroll
-    for (int k = 0; k < DG_NV; k++) mi[k] = E.Minv[u][k];
+    for (int k = 0; k < DG_NV; k++) mi[k] = E.M[uc][k];
+  }
+  __syncthreads();   // every lane holds its row: W may overwrite M^-1
+  if (u < DG_NV) {
 #pragma unroll 1
     for (int r = 0; r < nrows; r++) {
       double w = 0;
@@ -498,8 +529,8 @@ __device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nr
       E.rW[r][u] = (float)w;
     }
   }
-  __syncthreads();   // W complete; M / Minv are dead from here on (A may overwrite them)
-  float* Abuf = reinterpret_cast<float*>(&E.M[0][0]);
+  __syncthreads();   // W complete; the Jacobians are final: A may overwrite the kinematics region
+  float* Abuf = E.A;
   double a0 = 0;
 #pragma unroll 1
   for (int rr = u; rr < nrows; rr += 32) {
@@ -527,8 +558,8 @@ __device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nr
 #pragma unroll
         for (int k = 0; k < DG_NV; k++) v += Jr[k] * (double)E.rW[sr][k];
         const float av = (float)(v + dc_body_coupling(E, rr, sr));
-        Abuf[rr * (DC_PGS_LANES + 1) + sr] = av;
-        Abuf[sr * (DC_PGS_LANES + 1) + rr] = av;
+        Abuf[rr * DC_PGS_LANES + sr] = av;
+        Abuf[sr * DC_PGS_LANES + rr] = av;
       }
     }
   }
@@ -649,6 +680,9 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
   const size_t i = live ? gi : N - 1;
   const int hf = half;
   DC_ENV;
+#ifdef SAG_CYCLES
+  if (lane == 0) { for (int k = 0; k < DCY_N; k++) g_dc_cyc[k] = 0; g_dc_cyc_t = __builtin_readcyclecounter(); }
+#endif
   float* __restrict__ S = p.S;
   const float* stx = stx_s[half];
   const float* sty = sty_s[half];
@@ -731,6 +765,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     ctrl_s[half][u] = c;
   }
   __syncthreads();
+  DCC(DCY_LOAD);
 
   const int nsub = p.observe_only ? 0 : p.nstep;
   int cost_contacts = 0;
@@ -746,11 +781,20 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       E.wminv[BOX_ID][3] = s * s * ix + c * c * iy;
     }
     dc_smooth(hf, u, ctrl_s[half]);
-    if (u < 2)
-      for (int j = 0; j < DG_NV; j++) E.Mlin[u][j] = j >= u ? E.M[u][j] : 0.0;
-    __syncthreads();
+    if (sub == nsub) {   // outputs of the final state: centre of mass and momentum / mass (M's rows 0, 1 before they turn into L)
+      double m = 0;
+      for (int b = 0; b < DG_NB; b++) m += E.Ib[b][0];
+      if (u < 2) {
+        double mc = 0, P = m * E.qdv[u];
+        for (int b = 0; b < DG_NB; b++) mc += E.Ib[b][1 + u];
+        for (int j = 3; j < DG_NV; j++) P += E.M[u][j] * E.qdv[j];
+        E.com[u] = E.pos[u] + mc / m; E.mom[u] = P / m;
+      }
+    }
     dc_cholesky(hf, u);
+    DCC(DCY_CHOL);
     qacc_u = dc_inverse(hf, u);   // M^-1 and qacc0 = M^-1 tau
+    DCC(DCY_INV);
     if (u < 8) E.touch[u] = 0;
     int nrows = 0;
     // ---- rows: joint limits (lane j), in ascending joint order ---------------------------------
@@ -787,6 +831,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       }
       nrows += 3 * fit;
     }
+    DCC(DCY_ROWS_SELF);
     // ---- world objects, in the specification's order -------------------------------------------
     int cc = 0;
     uint32_t mask = 0;
@@ -832,12 +877,14 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     }
     if (u < DG_NV) E.qacc[u] = qacc_u;   // qacc0 for the rows' initial constraint accelerations
     __syncthreads();
+    DCC(DCY_ROWS_WORLD);
     // both envs of the wavefront take the same path: every row on its own lane (<= 32 rows: the usual case), or
     // the row-by-row loop
     const int nother = DC_EPW == 2 ? __shfl(nrows, (lane + 32) & 63) : nrows;
     const int nmax = max(nrows, nother);
     const bool fast = nmax <= DC_PGS_LANES;
     const double a0 = dc_rows_finish(hf, u, nrows, fast);
+    DCC(DCY_FINISH);
     if (fast) {
       // ---- projected Gauss-Seidel on the Delassus matrix: lane r owns row r (its accumulated force f and its
       //      constraint acceleration acc = J_r qacc + planar-body term).  Updating row r changes every row's acc by
@@ -845,7 +892,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       //      19-term dot product.  Same sweep order, bounds and arithmetic as the row-by-row form (A in fp32).
       const bool mine = u < nrows;
       const int ur = mine ? u : 0;
-      const float* Arow = reinterpret_cast<const float*>(&E.M[0][0]) + ur * (DC_PGS_LANES + 1);
+      const float* Acol = E.A + ur;   // A[r][u] = A[u][r]
       double acc = a0, f = 0, fn_contact = 0;
       const double aref = E.rAref[ur], reg = E.rReg[ur], inv = E.rInv[ur], mu = E.rMu[ur];
       const bool okA = mine && E.rA[ur] > 0, isfric = E.rParent[ur] >= 0;
@@ -864,10 +911,11 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
           const double fb = dc_bcast(f, r, half);
           const double nrm = dc_bcast(isfric ? 0.0 : 1.0, r, half);
           if (nrm != 0.0) fn_contact = fb;
-          if (r < nrows) acc += (double)Arow[r] * df;
+          if (r < nrows) acc += (double)Acol[r * DC_PGS_LANES] * df;
         }
       if (mine) E.rF[u] = f;
       __syncthreads();
+      DCC(DCY_PGS);
       if (u < DG_NV) {
         double q = qacc_u;
 #pragma unroll 1
@@ -938,6 +986,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     }
     cost_contacts = cc; btn_mask = mask;
     __syncthreads();
+    DCC(DCY_AFTER);
     if (sub == nsub) break;
     // ---- planar world: body k on lane k vs the statics; pairs on lane 0; friction + integration --
     if (u < NBODY) {
@@ -1025,6 +1074,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       if (E.flag & 1) E.pos[0] = __longlong_as_double(0x7ff8000000000000ll);   // not positive definite: PhysicsError
     }
     __syncthreads();
+    DCC(DCY_PLANAR);
   }
 
   // ---- results: per-env block for the post kernel, state back to HBM ---------------------------
@@ -1033,14 +1083,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     if (u < 3) dr[u] = E.qacc[u];
     if (u < 8) dr[3 + u] = E.touch[u];
     if (u == 0) {
-      double m = 0, mc[2] = {0, 0};
-      for (int b = 0; b < DG_NB; b++) { m += E.Ib[b][0]; mc[0] += E.Ib[b][1]; mc[1] += E.Ib[b][2]; }
-      dr[11] = E.pos[0] + mc[0] / m; dr[12] = E.pos[1] + mc[1] / m;
-      for (int k = 0; k < 2; k++) {
-        double P = m * E.qdv[k];
-        for (int j = 3; j < DG_NV; j++) P += E.Mlin[k][j] * E.qdv[j];
-        dr[13 + k] = P / m;
-      }
+      dr[11] = E.com[0]; dr[12] = E.com[1]; dr[13] = E.mom[0]; dr[14] = E.mom[1];
       dr[15] = (double)cost_contacts; dr[16] = (double)btn_mask; dr[17] = (E.flag & 2) ? 1.0 : 0.0;
     }
     if (!p.observe_only) {
@@ -1062,6 +1105,10 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       }
     }
   }
+#ifdef SAG_CYCLES
+  DCC(DCY_STORE);
+  if (lane == 0) { for (int k = 0; k < DCY_N; k++) atomicAdd(&g_cyc[1][k], g_dc_cyc[k]); atomicAdd(&g_cyc[1][CY_N], 1ull); }
+#endif
 }
 
 }  // namespace sag

@@ -364,7 +364,7 @@ def test_free_running_drift(nat, oracle, robot, task):
   arr = oracle.make_batch(rf, ri)
   arr_r = oracle.make_batch(rf, ri)   # the oracle itself with its state rounded to fp32 after every step (as the ABI stores it)
   rng, mt = np.random.RandomState(3), np.random.RandomState(4)
-  dev_cost, orc_cost, dev_met, orc_met, dpos, rpos = [], [], [], [], [], []
+  dev_cost, orc_cost, dev_met, orc_met, dpos, rpos, ref_cost = [], [], [], [], [], [], []
   for t in range(T):
     if robot == 'doggo':
       act = mt.uniform(-1, 1, size=(n, nu)).astype(np.float32)
@@ -374,7 +374,8 @@ def test_free_running_drift(nat, oracle, robot, task):
     tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
     d = ctx.step(act, noise, tape)
     o = oracle.step_batch_full(arr, rid, act, noise, tape, obs_dim=od)
-    oracle.step_batch_full(arr_r, rid, act, noise, tape, obs_dim=od)
+    o_r = oracle.step_batch_full(arr_r, rid, act, noise, tape, obs_dim=od)
+    ref_cost.append(o_r[2])
     r_rf, r_ri = oracle.batch_records(arr_r)
     arr_r = oracle.make_batch(r_rf, r_ri)
     d_rf = ctx.get_state()[0]
@@ -386,12 +387,18 @@ def test_free_running_drift(nat, oracle, robot, task):
   dev_cost, orc_cost, dev_met, orc_met = (np.array(x) for x in (dev_cost, orc_cost, dev_met, orc_met))
   q = lambda t: np.quantile(dpos[t], [0.5, 0.9, 0.99])
   cost_agree = (dev_cost == orc_cost).mean()
+  # cost flags come in runs (an env inside a hazard stays there for many steps): the sampling unit of the rate
+  # comparison is the env, not the env-step
+  per_env = dev_cost.mean(0) - orc_cost.mean(0)
+  cost_se = per_env.std(ddof=1) / np.sqrt(n)
+  ref_rate = np.array(ref_cost).mean()
   met_agree = (dev_met == orc_met).mean()
   close = (dpos[-1] < 1e-3).mean()
   line = (f'{robot}/{task}: {n} envs x {T} steps free-running vs fp64 oracle | robot position drift [m] median/p90/p99 at '
           f'step 50: {q(49)[0]:.2e}/{q(49)[1]:.2e}/{q(49)[2]:.2e}, step 100: {q(99)[0]:.2e}/{q(99)[1]:.2e}/{q(99)[2]:.2e}, '
           f'step 200: {q(199)[0]:.2e}/{q(199)[1]:.2e}/{q(199)[2]:.2e} | envs within 1 mm at step 200: {close:.3f} | '
-          f'cost-flag agreement per env-step {cost_agree:.5f} (device rate {dev_cost.mean():.4f}, oracle {orc_cost.mean():.4f}) | '
+          f'cost-flag agreement per env-step {cost_agree:.5f} (device rate {dev_cost.mean():.4f}, oracle {orc_cost.mean():.4f}, its fp32-rounded '
+          f'twin {ref_rate:.4f}; standard error of the per-env rate difference {cost_se:.4f}) | '
           f'goal-met agreement {met_agree:.5f} (device {int(dev_met.sum())}, oracle {int(orc_met.sum())} events) | reference level - the '
           f'fp64 oracle against ITSELF with its state rounded to fp32 after every step: median/p90 at step 200 '
           f'{np.median(rpos[-1]):.2e}/{np.quantile(rpos[-1], 0.9):.2e}')
@@ -406,7 +413,8 @@ def test_free_running_drift(nat, oracle, robot, task):
   assert q(199)[0] <= 3 * np.median(rpos[-1]) + 1e-3, 'drift beyond what fp32 state storage alone causes in the oracle'
   if robot != 'doggo':
     assert q(199)[0] < 1e-3, 'the median env should not separate from its oracle twin'
-  assert cost_agree > (0.93 if robot == 'doggo' else 0.99) and abs(dev_cost.mean() - orc_cost.mean()) < 0.01
+  assert cost_agree > (0.93 if robot == 'doggo' else 0.99)
+  assert abs(per_env.mean()) < max(0.01, 4 * cost_se + 0.002), 'cost rates differ beyond the env-to-env scatter'
   assert met_agree > 0.995
   ctx.close()
 

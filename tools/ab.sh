@@ -33,9 +33,7 @@ cmd=$1; shift
 case "$cmd" in
   build)
     while [ $# -ge 2 ]; do
-      /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fno-fast-math -ffp-contract=off \
-        -Wno-unused-function $2 -pthread -o safe_adaptation_gym_amd/libsag_$1.so \
-        safe_adaptation_gym_amd/csrc/sag_api.hip safe_adaptation_gym_amd/csrc/sag_sampler.cpp 2>&1 | grep -E "error" || true
+      python -m safe_adaptation_gym_amd.build --out libsag_$1.so $2 2>&1 | grep -E "error" || true
       shift 2
     done
     ls -la safe_adaptation_gym_amd/libsag_*.so ;;

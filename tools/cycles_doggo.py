@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import bench
-NAMES = ['kinematics', 'mass matrix', 'bias (RNEA)', 'cholesky + solve', 'rows: world objects', 'PGS', 'planar world + integrate', 'loop head', 'rows: joint limits', 'rows: floor']
+NAMES = ['load', 'kinematics', 'spheres + composite + RNEA bodies', 'CRBA + bias + tau', 'cholesky', 'M^-1 + qacc0', 'rows: limits + floor',
+         'rows: world objects', 'rows finish (W, A)', 'PGS', 'after PGS (qacc, touch)', 'planar world + integrate', 'store']
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 run = bench.DeviceRun('multitask', envs, 0, 0, robot='doggo')
 run.burn_in(10)
@@ -15,7 +16,7 @@ run.run(K); run.wait()
 ms, _ = run.kernel_time_ms()
 c = run.ctx.debug_cycles().astype(np.float64)
 waves = c[1, 15]
-tot = c[1, :12].sum()
+tot = c[1, :len(NAMES)].sum()
 print(f'doggo multitask {envs} envs: {ms:.3f} ms/step, {tot / waves:.0f} ticks/wavefront in doggo_physics')
 for k, n in enumerate(NAMES):
   print(f'   {n:28s} {c[1, k] / waves:12.0f}  {100 * c[1, k] / tot:5.1f} %')
