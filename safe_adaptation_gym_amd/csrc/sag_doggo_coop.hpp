@@ -291,11 +291,9 @@ __device__ __attribute__((noinline)) void dc_cholesky(int hf, int u) {
   const int ur = u < DG_NV ? u : 0;
 #pragma unroll
   for (int k = 0; k < DG_NV; k++) row[k] = E.M[ur][k];
-#pragma unroll 1
-  for (int j = 0; j < DG_NV; j++) {
-    double rj = 0;   // row[j] without a run-time register index
 #pragma unroll
-    for (int k = 0; k < DG_NV; k++) rj = k == j ? row[k] : rj;
+  for (int j = 0; j < DG_NV; j++) {   // unrolled: static register indices, the updates stop at the matrix edge
+    const double rj = row[j];
     if (u == j) {
       if (!(rj > 0)) E.flag |= 1;
       E.col[0] = sqrt(rj);
@@ -895,7 +893,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       const float* Acol = E.A + ur;   // A[r][u] = A[u][r]
       double acc = a0, f = 0, fn_contact = 0;
       const double aref = E.rAref[ur], reg = E.rReg[ur], inv = E.rInv[ur], mu = E.rMu[ur];
-      const bool okA = mine && E.rA[ur] > 0, isfric = E.rParent[ur] >= 0;
+      const int parent = E.rParent[ur];
+      const bool okA = mine && E.rA[ur] > 0, isfric = parent >= 0;
 #pragma unroll 1
       for (int it = 0; it < DG_PGS_ITERS; it++)
 #pragma unroll 1
@@ -907,10 +906,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
           const double df_mine = (u == r && okA) ? fnew - f : 0.0;
           const double df = dc_bcast(df_mine, r, half);
           if (u == r) f += df;
-          // friction rows follow their contact's normal row: every lane remembers the last normal row's force
-          const double fb = dc_bcast(f, r, half);
-          const double nrm = dc_bcast(isfric ? 0.0 : 1.0, r, half);
-          if (nrm != 0.0) fn_contact = fb;
+          // a friction row tracks its contact's normal force by the same increments (f starts at 0 in both lanes)
+          if (r == parent) fn_contact += df;
           if (r < nrows) acc += (double)Acol[r * DC_PGS_LANES] * df;
         }
       if (mine) E.rF[u] = f;
@@ -1016,7 +1013,17 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       }
     }
     __syncthreads();
-    if (u == 0) {
+    // pairs of planar bodies: lane a tests its pairs' bounding circles; lane 0 walks the pairs only when one overlaps
+    bool pair_near = false;
+    if (u < W.nV)
+      for (int b = u + 1; b < NBODY; b++) {
+        const bool isb = b == BOX_ID;
+        if (isb ? !W.has_box : b >= W.nV) continue;
+        const float dx = E.wfb[b][0] - E.wfb[u][0], dyy = E.wfb[b][1] - E.wfb[u][1], rs = vase_r + (isb ? box_r : vase_r);
+        pair_near |= !(dx * dx + dyy * dyy > rs * rs);
+      }
+    const unsigned long long near_lanes = __ballot(pair_near);
+    if (u == 0 && (near_lanes >> (32 * half) & 0xffffffffull)) {
       for (int a = 0; a < W.nV; a++)
         for (int b = a + 1; b < NBODY; b++) {
           const bool isb = b == BOX_ID;
@@ -1063,7 +1070,9 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     if (u == 0) {
       const double wn = sqrt(dg_dot(E.wloc, E.wloc));
       if (wn > 0) {
-        const double ang = 0.5 * (double)h * wn, s = sin(ang) / wn, c = cos(ang);
+        double sn, c;
+        sincos(0.5 * (double)h * wn, &sn, &c);
+        const double s = sn / wn;
         const double dq[4] = {c, s * E.wloc[0], s * E.wloc[1], s * E.wloc[2]};
         const double q0 = E.quat[0], q1 = E.quat[1], q2 = E.quat[2], q3 = E.quat[3];
         const double o[4] = {q0 * dq[0] - q1 * dq[1] - q2 * dq[2] - q3 * dq[3], q0 * dq[1] + q1 * dq[0] + q2 * dq[3] - q3 * dq[2],
