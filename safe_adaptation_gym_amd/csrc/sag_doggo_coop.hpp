@@ -22,6 +22,11 @@ namespace sag {
 
 constexpr int DC_ROWS = DG_MAXROWS;              // max constraint rows per env (same cap as the lane-per-env form)
 constexpr int DC_PGS_LANES = 32;                // fast PGS path: one constraint row per lane
+struct DcContact {                              // a contact as its owner lane found it; its three rows are built by all lanes
+  double dir[3][3], c[3], depth;                // normal + two tangents, point, penetration
+  float bcoef, kcoef, mu;
+  short s, other;                               // robot sphere, planar body (-1: static / floor)
+};
 struct DcEnv {                                  // one env's working set in LDS
   double pos[3], quat[4], q[DG_NJ], vlin[3], wloc[3], qd[DG_NJ];
   // Two regions are reused within a substep - 18.5 KB per env instead of 25.6, so that FOUR wavefronts (one per SIMD)
@@ -30,9 +35,15 @@ struct DcEnv {                                  // one env's working set in LDS
     struct {                                    // kinematics .. constraint Jacobians (dc_jac is the last reader)
       double R[DG_NB][9], p[DG_NB][3];
       double S[DG_NV][6];                       // [a; l]
-      double Ib[DG_NB][10], Ic[DG_NB][10];      // m, mc[3], I[6]
-      double F[DG_NV][6];                       // CRBA: Ic[body(j)] S_j ; RNEA: scratch
-      double fb[DG_NB][6];
+      double Ib[DG_NB][10];                     // m, mc[3], I[6]
+      union {
+        struct {
+          double Ic[DG_NB][10];
+          double F[DG_NV][6];                   // CRBA: Ic[body(j)] S_j ; RNEA: scratch
+          double fb[DG_NB][6];
+        };
+        DcContact ct[DC_ROWS / 3];              // (collision phase: Ic, F, fb are dead)
+      };
     };
     float A[DC_PGS_LANES * DC_PGS_LANES];       // Delassus matrix J M^-1 J^T of the fast PGS path (symmetric, no padding:
   };                                            // lane u reads its row as the column A[r][u] - consecutive words)
@@ -594,30 +605,60 @@ __device__ inline void dc_jac(int hf, int r, int b, const double* c, const doubl
   }
 }
 
-// the three rows of one contact, built by its owner lane at rows [base, base + 3)
-__device__ __attribute__((noinline)) void dc_contact_rows(int hf, int base, int s, const double* n, const double* c, double depth, int other,
-                                       double bcoef, double kcoef, double mu) {
+// Contact j of the substep, registered by its owner lane (sphere s): directions, point and coefficients only.  Its
+// three rows - 57 Jacobian entries - are computed by all lanes together in dc_contacts_finish: one lane per contact
+// doing them while the others idle was 17 % of the kernel.
+__device__ inline void dc_contact_add(int hf, int j, int s, const double* n, const double* c, double depth, int other,
+                                      double bcoef, double kcoef, double mu) {
   DC_ENV;
-  const int b = g_dg.sph_body[s];
+  DcContact& C = E.ct[j];
   double dir[3][3];
   for (int k = 0; k < 3; k++) dir[0][k] = n[k];
   if (fabs(n[2]) > 0.5) { dir[1][0] = 1; dir[1][1] = 0; dir[1][2] = 0; }
   else { dir[1][0] = -n[1]; dir[1][1] = n[0]; dir[1][2] = 0; }
   dg_cross(dir[0], dir[1], dir[2]);
-  const double imp = dg_impedance(depth);
+  for (int k = 0; k < 3; k++)
+    for (int a = 0; a < 3; a++) C.dir[k][a] = dir[k][a];
+  for (int a = 0; a < 3; a++) C.c[a] = c[a];
+  C.depth = depth; C.bcoef = (float)bcoef; C.kcoef = (float)kcoef; C.mu = (float)mu;   // (float-valued: exact)
+  C.s = (short)s; C.other = (short)other;
+}
+
+// rows [r0, r0 + 3 nct) of the nct registered contacts: Jacobians entry by entry across the lanes, then one row per lane
+__device__ __attribute__((noinline)) void dc_contacts_finish(int hf, int u, int r0, int nct) {
+  DC_ENV;
+  __syncthreads();   // the owners' descriptors are visible
+  const int total = nct * (3 * DG_NV);
 #pragma unroll 1
-  for (int k = 0; k < 3; k++) {
-    dc_jac(hf, base + k, b, c, dir[k]);
-    const double vel = dc_build_row(hf, base + k, other, -dir[k][0], -dir[k][1], c[0], c[1]);
-    E.rImp[base + k] = imp;
-    if (k == 0) { E.rAref[base] = -bcoef * vel + kcoef * depth; E.rTouch[base] = (short)g_dg.sph_touch[s]; }
-    else { E.rAref[base + k] = -bcoef * vel; E.rParent[base + k] = (short)base; E.rMu[base + k] = mu; }
+  for (int e = u; e < total; e += 32) {
+    const int j = e / (3 * DG_NV), rem = e - j * (3 * DG_NV), k = rem / DG_NV, i = rem - k * DG_NV;
+    const DcContact& C = E.ct[j];
+    const int b = g_dg.sph_body[C.s];
+    double v = 0;
+    if (g_dg.anc[b] >> g_dg.dof_body[i] & 1u) {
+      const double rr[3] = {C.c[0] - E.pos[0], C.c[1] - E.pos[1], C.c[2] - E.pos[2]};
+      const double* d = C.dir[k];
+      double t[3];
+      dg_cross(E.S[i], rr, t);
+      v = d[0] * (E.S[i][3] + t[0]) + d[1] * (E.S[i][4] + t[1]) + d[2] * (E.S[i][5] + t[2]);
+    }
+    E.rJ[r0 + 3 * j + k][i] = (float)v;
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int q = u; q < 3 * nct; q += 32) {
+    const int j = q / 3, k = q - 3 * j, r = r0 + q, base = r0 + 3 * j;
+    const DcContact& C = E.ct[j];
+    const double vel = dc_build_row(hf, r, C.other, -C.dir[k][0], -C.dir[k][1], C.c[0], C.c[1]);
+    E.rImp[r] = dg_impedance(C.depth);
+    if (k == 0) { E.rAref[r] = -(double)C.bcoef * vel + (double)C.kcoef * C.depth; E.rTouch[r] = (short)g_dg.sph_touch[C.s]; }
+    else { E.rAref[r] = -(double)C.bcoef * vel; E.rParent[r] = (short)base; E.rMu[r] = (double)C.mu; }
   }
 }
 
 // spheres of the robot (one per lane) vs one planar body: appends the contact rows in (sphere, geom)
 // order; returns the number of contacts (uniform in the half)
-__device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int& nrows, int fbi, int shape, float bx, float by, float byaw,
+__device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, int& nrows, int fbi, int shape, float bx, float by, float byaw,
                                       float rbound, float vsz, float rstatic, double top, double bcoef, double kcoef, double mu) {
   DC_ENV;
   DgHit hits[5];
@@ -652,7 +693,7 @@ __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int& nro
     const int idx = excl + k;
     if (idx < fit) {
       const double nn[3] = {-(double)hits[k].nx, -(double)hits[k].ny, 0}, pc[3] = {(double)hits[k].px, (double)hits[k].py, cz};
-      dc_contact_rows(hf, nrows + 3 * idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu);
+      dc_contact_add(hf, (nrows - r0) / 3 + idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu);
     }
   }
   nrows += 3 * fit;
@@ -816,6 +857,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       nrows += fit;
     }
     // ---- floor (lane s) --------------------------------------------------------------------
+    const int r0 = nrows;   // the contacts' rows start here
     {
       double depth = 0;
       if (u < DG_NS) depth = g_dg.sph_r[u] - E.sph[u][2];
@@ -825,7 +867,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       if (fit < total && u == 0) E.flag |= 2;
       if (depth > 0 && excl < fit) {
         const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dg.sph_r[u])};
-        dc_contact_rows(hf, nrows + 3 * excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
+        dc_contact_add(hf, excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
       }
       nrows += 3 * fit;
     }
@@ -840,23 +882,26 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
 #pragma unroll 1
     for (int q = 0; q < W.nP; q++)
       if (near(stx[q], sty[q], W.psz))
-        cc += dc_collide_body(hf, u, nrows, -1, SH_STATIC, stx[q], sty[q], 0.f, W.psz, W.vsz, W.psz, 1.0,
+        cc += dc_collide_body(hf, u, r0, nrows, -1, SH_STATIC, stx[q], sty[q], 0.f, W.psz, W.vsz, W.psz, 1.0,
                               (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
 #pragma unroll 1
     for (int b = 0; b < W.nB; b++)
       if (near(stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], BUTTON_R) &&
-          dc_collide_body(hf, u, nrows, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f, BUTTON_R, W.vsz,
+          dc_collide_body(hf, u, r0, nrows, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f, BUTTON_R, W.vsz,
                           BUTTON_R, 0.2, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu))
         mask |= 1u << b;
 #pragma unroll 1
     for (int k = 0; k < W.nV; k++)
       if (near(E.wfb[k][0], E.wfb[k][1], vase_r))
-        cc += dc_collide_body(hf, u, nrows, k, SH_VASE, E.wfb[k][0], E.wfb[k][1], E.wfb[k][2], vase_r, W.vsz, 0.f, top_vase,
+        cc += dc_collide_body(hf, u, r0, nrows, k, SH_VASE, E.wfb[k][0], E.wfb[k][1], E.wfb[k][2], vase_r, W.vsz, 0.f, top_vase,
                               (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
     if (W.has_box) {
       if (near(E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], box_r))
-        dc_collide_body(hf, u, nrows, BOX_ID, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], E.wfb[BOX_ID][2], box_r, W.vsz, 0.f,
+        dc_collide_body(hf, u, r0, nrows, BOX_ID, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], E.wfb[BOX_ID][2], box_r, W.vsz, 0.f,
                         top_box, (double)W.solb.bcoef, (double)W.solb.kcoef, (double)W.solb.mu);
+    }
+    dc_contacts_finish(hf, u, r0, (nrows - r0) / 3);
+    if (W.has_box) {
       if (W.haul && nrows >= DC_ROWS && u == 0) E.flag |= 2;
       if (W.haul && nrows < DC_ROWS) {   // haul_box.py:21-29: tendon base site <-> box site (z .2), range [0, .75]
         const double dx = (double)E.wfb[BOX_ID][0] - E.pos[0], dy = (double)E.wfb[BOX_ID][1] - E.pos[1], dz = 0.2 - E.pos[2];
@@ -890,15 +935,18 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       //      19-term dot product.  Same sweep order, bounds and arithmetic as the row-by-row form (A in fp32).
       const bool mine = u < nrows;
       const int ur = mine ? u : 0;
-      const float* Acol = E.A + ur;   // A[r][u] = A[u][r]
+      float Ar[DC_PGS_LANES];         // the lane's row of A in registers (A[r][u] = A[u][r]: consecutive words across lanes)
+#pragma unroll
+      for (int r = 0; r < DC_PGS_LANES; r++) Ar[r] = r < nrows ? E.A[r * DC_PGS_LANES + ur] : 0.f;
       double acc = a0, f = 0, fn_contact = 0;
       const double aref = E.rAref[ur], reg = E.rReg[ur], inv = E.rInv[ur], mu = E.rMu[ur];
       const int parent = E.rParent[ur];
       const bool okA = mine && E.rA[ur] > 0, isfric = parent >= 0;
 #pragma unroll 1
       for (int it = 0; it < DG_PGS_ITERS; it++)
-#pragma unroll 1
-        for (int r = 0; r < nmax; r++) {
+#pragma unroll
+        for (int r = 0; r < DC_PGS_LANES; r++) {   // unrolled: lane index and register index of the row are constants
+          if (r >= nmax) break;
           double fnew = f + (aref - acc - reg * f) * inv;
           const double lo = isfric ? -mu * fn_contact : 0.0, hi = isfric ? mu * fn_contact : 1e30;
           if (fnew < lo) fnew = lo;
@@ -908,7 +956,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
           if (u == r) f += df;
           // a friction row tracks its contact's normal force by the same increments (f starts at 0 in both lanes)
           if (r == parent) fn_contact += df;
-          if (r < nrows) acc += (double)Acol[r * DC_PGS_LANES] * df;
+          acc += (double)Ar[r] * df;
         }
       if (mine) E.rF[u] = f;
       __syncthreads();
