@@ -102,9 +102,9 @@ struct sag_ctx {
   int n_cu = 256;      // compute units of the device
   uint8_t* d_rgb = nullptr; size_t rgb_bytes = 0;  // [N][H][W][3] staging of sag_render, grown on demand
   double* d_dr = nullptr;    // Doggo cooperative form: per-env result block of the physics kernel
-  // Doggo: wave-cooperative physics kernel (2 envs per wavefront, 3 wavefronts per CU) for batches up
-  // to ~12k envs (measured 8.4 vs 16.8 ms at 4096), the lane-per-env kernel above that (36 vs 48 ms at
-  // 32768: it keeps 64 envs per wavefront busy).  SAG_DOGGO_COOP=0/1 forces one.
+  // Doggo: the wave-cooperative physics kernel (2 envs per wavefront, 4 wavefronts per CU) at every batch size - 3.4 ms
+  // at 4096 envs, 2.15e6 env-steps/s at 131072 against 1.04e6 of the lane-per-env kernel, which stays as the
+  // second implementation the tests cross-check (SAG_DOGGO_COOP=0 selects it).
   bool doggo_coop = false;
   int epw_override = 0;  // SAG_EPW (read once at create): envs per wavefront of the single-launch form
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
@@ -475,7 +475,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
   if (const char* e = getenv("SAG_HOT")) c->use_hot = atoi(e) != 0;
   if (const char* e = getenv("SAG_EPW")) c->epw_override = atoi(e);
-  c->doggo_coop = cfg->robot == SAG_ROBOT_DOGGO && cfg->n_envs <= 12288;
+  c->doggo_coop = cfg->robot == SAG_ROBOT_DOGGO;
   if (const char* e = getenv("SAG_DOGGO_COOP")) c->doggo_coop = atoi(e) != 0;
   {
     hipDeviceProp_t prop;

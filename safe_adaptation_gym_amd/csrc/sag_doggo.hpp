@@ -20,7 +20,7 @@ constexpr int DG_PGS_ITERS = 4;
 constexpr double DG_GEAR = 0.0125, DG_STIFF = 0.01, DG_Z0 = 0.22, DG_PI = 3.14159265358979323846, DG_GRAV = 9.81;
 
 // model tables, built on the host in fp64 (sag_api.hip: dg_build_model) from the XML numbers
-struct DgModel {
+struct DgPhys {                    // what the dynamics read (the cooperative kernel keeps a copy in LDS)
   int parent[DG_NB];
   double bpos[DG_NB][3];
   int dof_body[DG_NV];
@@ -31,6 +31,8 @@ struct DgModel {
   int sph_body[DG_NS], sph_touch[DG_NS];
   double sph_p[DG_NS][3], sph_r[DG_NS];
   unsigned anc[DG_NB];            // bit a set: body a is on the path root -> b (inclusive)
+};
+struct DgModel : DgPhys {
   // the XML's geoms (rendering): body, end points in the body frame, radius, capsule (1) / cylinder (0),
   // ankle colour class (0 default red, 1 front ankles blue, 2 rear ankles green: doggo.xml:26,40,58,72)
   int geom_body[DG_NGEOM], geom_capsule[DG_NGEOM], geom_ankle[DG_NGEOM];

@@ -77,9 +77,26 @@ static_assert(sizeof(float) * DC_PGS_LANES * DC_PGS_LANES <= sizeof(double) * (D
 #endif
 __shared__ DcEnv g_dc_env[DC_EPW];
 #define DC_ENV DcEnv& E = g_dc_env[hf]
+// The model tables in LDS, one copy per workgroup.  From constant memory every lookup with a lane-dependent index
+// (dof -> body, body -> ancestors, sphere -> body ...) is a global load the lone wavefront of a SIMD waits out:
+// ten of them in a row made the bias sum of RNEA cost as much as the whole PGS.
+__shared__ DgPhys g_dc_phys;
+__shared__ int g_dc_first_dof[DG_NB], g_dc_ndof[DG_NB];
+__device__ inline void dc_load_model() {   // all threads of the workgroup; the caller's barrier publishes it
+  static_assert(sizeof(DgPhys) % 4 == 0, "word copy");
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&g_dg);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(&g_dc_phys);
+  for (int w = threadIdx.x; w < (int)(sizeof(DgPhys) / 4); w += blockDim.x) dst[w] = src[w];
+  if (threadIdx.x < DG_NB) {
+    int first = 0, n = 0;
+    for (int d = DG_NV - 1; d >= 0; d--)
+      if (g_dg.dof_body[d] == (int)threadIdx.x) { first = d; n++; }
+    g_dc_first_dof[threadIdx.x] = first; g_dc_ndof[threadIdx.x] = n;
+  }
+}
 // section profile of k_doggo_physics (tools/cycles_doggo.py, -DSAG_CYCLES): lane 0's clock per section -> g_cyc[1][.]
 enum { DCY_LOAD = 0, DCY_KIN, DCY_BODIES, DCY_CRBA_RNEA, DCY_CHOL, DCY_INV, DCY_ROWS_SELF, DCY_ROWS_WORLD, DCY_FINISH, DCY_PGS,
-       DCY_AFTER, DCY_PLANAR, DCY_STORE, DCY_N };
+       DCY_AFTER, DCY_PLANAR, DCY_STORE, DCY_CRBA_F, DCY_CRBA_ROWS, DCY_N };
 #ifdef SAG_CYCLES
 static_assert(DCY_N <= CY_N, "sections fit g_cyc");
 __shared__ unsigned long long g_dc_cyc[DCY_N], g_dc_cyc_t;
@@ -92,21 +109,15 @@ __shared__ unsigned long long g_dc_cyc[DCY_N], g_dc_cyc_t;
 // paths of the kinematic tree (static): bodies from the root's child down to b
 struct DcPath { int n, c0, c1, c2; __device__ int at(int s) const { return s == 0 ? c0 : (s == 1 ? c1 : c2); } };
 __device__ inline int dc_path(int b, DcPath& path) {  // bodies from the root's child down to b (depth <= 3), in registers
-  const int a1 = b, a2 = b > 0 ? g_dg.parent[a1] : 0, a3 = a2 > 0 ? g_dg.parent[a2] : 0;
+  const int a1 = b, a2 = b > 0 ? g_dc_phys.parent[a1] : 0, a3 = a2 > 0 ? g_dc_phys.parent[a2] : 0;
   if (b <= 0) { path.n = 0; path.c0 = path.c1 = path.c2 = 0; }
   else if (a2 <= 0) { path.n = 1; path.c0 = a1; path.c1 = path.c2 = 0; }
   else if (a3 <= 0) { path.n = 2; path.c0 = a2; path.c1 = a1; path.c2 = 0; }
   else { path.n = 3; path.c0 = a3; path.c1 = a2; path.c2 = a1; }
   return path.n;
 }
-__device__ inline int dc_first_dof(int b) {  // first dof of body b (b >= 1)
-  const int T[DG_NB] = {0, 6, 8, 9, 11, 12, 13, 15, 16, 18};
-  return T[b];
-}
-__device__ inline int dc_ndof(int b) {
-  const int T[DG_NB] = {6, 2, 1, 2, 1, 1, 2, 1, 2, 1};
-  return T[b];
-}
+__device__ inline int dc_first_dof(int b) { return g_dc_first_dof[b]; }  // first dof of body b
+__device__ inline int dc_ndof(int b) { return g_dc_ndof[b]; }
 
 // rotation matrix (3x3, registers) times axis-angle rotation
 __device__ inline void dc_rot_apply(double* R, const double* axis, double ang) {
@@ -118,7 +129,7 @@ __device__ inline void dc_rot_apply(double* R, const double* axis, double ang) {
 // phase 1: frames, motion vectors, inertias about O = base origin, sphere centres.  `u` = lane in the half.
 __device__ __attribute__((noinline)) void dc_kinematics(int hf, int u) {
   DC_ENV;
-  const DgModel& M = g_dg;
+  const DgPhys& M = g_dc_phys;
   // the 13 joint rotations once (lane j: two fp64 sin / cos, ~300 instructions), parked in LDS over F / fb, which are
   // written only after this phase; every chain walk below then multiplies ready matrices - before, each lane
   // re-derived up to three of them in each of its two roles
@@ -192,9 +203,9 @@ __device__ __attribute__((noinline)) void dc_kinematics(int hf, int u) {
 __device__ __attribute__((noinline)) void dc_spheres(int hf, int u) {
   DC_ENV;
   if (u < DG_NS) {
-    const int b = g_dg.sph_body[u];
+    const int b = g_dc_phys.sph_body[u];
     double o[3];
-    dg_matvec(E.R[b], g_dg.sph_p[u], o);
+    dg_matvec(E.R[b], g_dc_phys.sph_p[u], o);
     for (int k = 0; k < 3; k++) E.sph[u][k] = E.p[b][k] + o[k];
   }
 }
@@ -230,24 +241,24 @@ __device__ __attribute__((noinline)) void dc_composite(int hf, int u) {
     double acc[10];
     for (int k = 0; k < 10; k++) acc[k] = 0;
     for (int d = u; d < DG_NB; d++)
-      if (g_dg.anc[d] >> u & 1u)
+      if (g_dc_phys.anc[d] >> u & 1u)
         for (int k = 0; k < 10; k++) acc[k] += E.Ib[d][k];
     for (int k = 0; k < 10; k++) E.Ic[u][k] = acc[k];
   }
 }
 __device__ __attribute__((noinline)) void dc_crba_f(int hf, int u) {
   DC_ENV;
-  if (u < DG_NV) dc_inertia_apply(E.Ic[g_dg.dof_body[u]], E.S[u], E.F[u]);
+  if (u < DG_NV) dc_inertia_apply(E.Ic[g_dc_phys.dof_body[u]], E.S[u], E.F[u]);
 }
 __device__ __attribute__((noinline)) void dc_crba_rows(int hf, int u) {
   DC_ENV;
   if (u < DG_NV) {
-    const int bi = g_dg.dof_body[u];
+    const int bi = g_dc_phys.dof_body[u];
     for (int j = 0; j < DG_NV; j++) {
-      const int bj = g_dg.dof_body[j];
+      const int bj = g_dc_phys.dof_body[j];
       double v = 0;
-      if ((g_dg.anc[bj] >> bi & 1u) && (bi != bj || u <= j)) v = dc_dot6(E.S[u], E.F[j]);       // i above (or beside, i <= j)
-      else if (g_dg.anc[bi] >> bj & 1u) v = dc_dot6(E.S[j], E.F[u]);                           // j above i
+      if ((g_dc_phys.anc[bj] >> bi & 1u) && (bi != bj || u <= j)) v = dc_dot6(E.S[u], E.F[j]);       // i above (or beside, i <= j)
+      else if (g_dc_phys.anc[bi] >> bj & 1u) v = dc_dot6(E.S[j], E.F[u]);                           // j above i
       E.M[u][j] = v;
     }
   }
@@ -285,10 +296,10 @@ __device__ __attribute__((noinline)) void dc_rnea_bodies(int hf, int u) {
 __device__ __attribute__((noinline)) void dc_rnea_bias(int hf, int u) {
   DC_ENV;
   if (u < DG_NV) {
-    const int b = g_dg.dof_body[u];
+    const int b = g_dc_phys.dof_body[u];
     double F[6] = {0, 0, 0, 0, 0, 0};
     for (int d = b; d < DG_NB; d++)
-      if (g_dg.anc[d] >> b & 1u)
+      if (g_dc_phys.anc[d] >> b & 1u)
         for (int k = 0; k < 6; k++) F[k] += E.fb[d][k];
     E.bias[u] = dc_dot6(E.S[u], F);
   }
@@ -414,15 +425,17 @@ __device__ inline void dc_smooth(int hf, int u, const float* ctrl12) {
   dc_crba_f(hf, u);
   dc_rnea_bias(hf, u);
   __syncthreads();
+  DCC(DCY_CRBA_F);
   dc_crba_rows(hf, u);
+  DCC(DCY_CRBA_ROWS);
   if (u < DG_NV) {
     double t = 0;
     if (u >= 6) {
       const int j = u - 6;
-      t = -DG_STIFF * (E.q[j] - g_dg.springref[j]);
+      t = -DG_STIFF * (E.q[j] - g_dc_phys.springref[j]);
       if (ctrl12)
         for (int k = 0; k < 12; k++)
-          if (g_dg.act_joint[k] == j) t += DG_GEAR * (double)ctrl12[k];
+          if (g_dc_phys.act_joint[k] == j) t += DG_GEAR * (double)ctrl12[k];
     }
     E.tau[u] = t - E.bias[u];
     E.qdv[u] = u < 3 ? E.vlin[u] : (u < 6 ? E.wloc[u - 3] : E.qd[u - 6]);
@@ -438,6 +451,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_coop_debug(const float* _
   const bool live = i < (size_t)N;
   const int hf = half;
   DC_ENV;
+  dc_load_model();
   dc_load_state(hf, u, S, (size_t)N, live ? i : (size_t)N - 1);
   __syncthreads();
   dc_smooth(hf, u, nullptr);
@@ -596,7 +610,7 @@ __device__ inline void dc_jac(int hf, int r, int b, const double* c, const doubl
 #pragma unroll 1
   for (int i = 0; i < DG_NV; i++) {
     double v = 0;
-    if (g_dg.anc[b] >> g_dg.dof_body[i] & 1u) {
+    if (g_dc_phys.anc[b] >> g_dc_phys.dof_body[i] & 1u) {
       double t[3];
       dg_cross(E.S[i], rr, t);
       v = d[0] * (E.S[i][3] + t[0]) + d[1] * (E.S[i][4] + t[1]) + d[2] * (E.S[i][5] + t[2]);
@@ -633,9 +647,9 @@ __device__ __attribute__((noinline)) void dc_contacts_finish(int hf, int u, int 
   for (int e = u; e < total; e += 32) {
     const int j = e / (3 * DG_NV), rem = e - j * (3 * DG_NV), k = rem / DG_NV, i = rem - k * DG_NV;
     const DcContact& C = E.ct[j];
-    const int b = g_dg.sph_body[C.s];
+    const int b = g_dc_phys.sph_body[C.s];
     double v = 0;
-    if (g_dg.anc[b] >> g_dg.dof_body[i] & 1u) {
+    if (g_dc_phys.anc[b] >> g_dc_phys.dof_body[i] & 1u) {
       const double rr[3] = {C.c[0] - E.pos[0], C.c[1] - E.pos[1], C.c[2] - E.pos[2]};
       const double* d = C.dir[k];
       double t[3];
@@ -651,7 +665,7 @@ __device__ __attribute__((noinline)) void dc_contacts_finish(int hf, int u, int 
     const DcContact& C = E.ct[j];
     const double vel = dc_build_row(hf, r, C.other, -C.dir[k][0], -C.dir[k][1], C.c[0], C.c[1]);
     E.rImp[r] = dg_impedance(C.depth);
-    if (k == 0) { E.rAref[r] = -(double)C.bcoef * vel + (double)C.kcoef * C.depth; E.rTouch[r] = (short)g_dg.sph_touch[C.s]; }
+    if (k == 0) { E.rAref[r] = -(double)C.bcoef * vel + (double)C.kcoef * C.depth; E.rTouch[r] = (short)g_dc_phys.sph_touch[C.s]; }
     else { E.rAref[r] = -(double)C.bcoef * vel; E.rParent[r] = (short)base; E.rMu[r] = (double)C.mu; }
   }
 }
@@ -666,7 +680,7 @@ __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, 
   double cz = 0;
   if (u < DG_NS) {
     const double* c = E.sph[u];
-    double r = g_dg.sph_r[u];
+    double r = g_dc_phys.sph_r[u];
     cz = c[2];
     bool go = c[2] - r < top;
     if (go && c[2] > top) r = sqrt(r * r - (c[2] - top) * (c[2] - top));
@@ -763,7 +777,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
   const double top_vase = 2.0 * (double)W.vsz;
   const double top_box = W.bk.sh == SH_ROD ? 0.16 : (W.bk.sh == SH_BALL ? 0.28 : 0.4);
 
-  // ---- load: robot state (lane 0), planar bodies (lane k), statics, controls ----------------
+  // ---- load: model tables, robot state (lane 0), planar bodies (lane k), statics, controls ----
+  dc_load_model();
   dc_load_state(hf, u, S, N, i);
   if (u < NBODY) {
     const int k = u;
@@ -840,8 +855,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     {
       double depth = 0, sign = 0;
       if (u < DG_NJ) {
-        if (E.q[u] < g_dg.lo[u]) { depth = g_dg.lo[u] - E.q[u]; sign = 1; }
-        else if (E.q[u] > g_dg.hi[u]) { depth = E.q[u] - g_dg.hi[u]; sign = -1; }
+        if (E.q[u] < g_dc_phys.lo[u]) { depth = g_dc_phys.lo[u] - E.q[u]; sign = 1; }
+        else if (E.q[u] > g_dc_phys.hi[u]) { depth = E.q[u] - g_dc_phys.hi[u]; sign = -1; }
       }
       int total;
       const int excl = dc_scan32(sign != 0 ? 1 : 0, u, total);
@@ -860,13 +875,13 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     const int r0 = nrows;   // the contacts' rows start here
     {
       double depth = 0;
-      if (u < DG_NS) depth = g_dg.sph_r[u] - E.sph[u][2];
+      if (u < DG_NS) depth = g_dc_phys.sph_r[u] - E.sph[u][2];
       int total;
       const int excl = dc_scan32(depth > 0 ? 1 : 0, u, total);
       const int fit = min(total, (DC_ROWS - nrows) / 3);
       if (fit < total && u == 0) E.flag |= 2;
       if (depth > 0 && excl < fit) {
-        const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dg.sph_r[u])};
+        const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dc_phys.sph_r[u])};
         dc_contact_add(hf, excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
       }
       nrows += 3 * fit;

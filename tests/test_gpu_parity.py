@@ -695,7 +695,7 @@ def test_car_env_api(nat):
 # Doggo (3-D articulated; fp64 robot solve on the device, fp32 planar world)
 # ----------------------------------------------------------------------------------
 DOGGO_TASKS = ['go_to_goal', 'push_box', 'press_buttons', 'haul_box', 'unsupervised', 'collect', MIXED]
-# two device forms of the Doggo physics: wave-cooperative (default for small batches) and lane-per-env
+# two device forms of the Doggo physics: wave-cooperative (the default) and lane-per-env (SAG_DOGGO_COOP=0)
 DOGGO_CASES = [(t, '1') for t in DOGGO_TASKS] + [('go_to_goal', '0'), ('haul_box', '0'), (MIXED, '0')]
 
 

@@ -4,8 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import bench
-NAMES = ['load', 'kinematics', 'spheres + composite + RNEA bodies', 'CRBA + bias + tau', 'cholesky', 'M^-1 + qacc0', 'rows: limits + floor',
-         'rows: world objects', 'rows finish (W, A)', 'PGS', 'after PGS (qacc, touch)', 'planar world + integrate', 'store']
+NAMES = ['load', 'kinematics', 'spheres + composite + RNEA bodies', 'tau', 'cholesky', 'M^-1 + qacc0', 'rows: limits + floor',
+         'rows: world objects', 'rows finish (W, A)', 'PGS', 'after PGS (qacc, touch)', 'planar world + integrate', 'store', 'CRBA forces + RNEA bias', 'CRBA rows']
 envs = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 run = bench.DeviceRun('multitask', envs, 0, 0, robot='doggo')
 run.burn_in(10)

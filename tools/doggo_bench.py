@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import bench
-for n in (4096, 32768):
+for n in [int(a) for a in sys.argv[1:]] or (4096, 32768):
   for flag in ('0', '1'):
     os.environ['SAG_DOGGO_COOP'] = flag
     r = bench.DeviceRun('multitask', n, 0, 0, robot='doggo')
