@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
 # fp64 flops of one Doggo env-step in the wave-cooperative kernel, counted by rocprofv3
 # (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes, FMA = 2: issued lane-operations), profiles/r02_doggo_flops.txt
-DOGGO_FP64_FLOPS_PER_ENV_STEP = 3.57e6
+DOGGO_FP64_FLOPS_PER_ENV_STEP = 2.56e6
 N_ACTION_BUFS = 8
 
 
