@@ -706,14 +706,16 @@ __device__ inline float angle_bins(float ex, float ey) {
   const float ax = fabsf(ex), ay = fabsf(ey);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
   const float q = mn * __builtin_amdgcn_rcpf(mx), z = q * q;
+  // (explicit fused multiply-adds: the translation unit is built with -ffp-contract=off, and this estimate - the
+  // step's most executed arithmetic, ~20 points per env - only has to stay inside the band the caller re-checks in fp64)
   float t = -1.017929272e-02f;
-  t = t * z + 5.515013699e-02f;
-  t = t * z + -1.416326720e-01f;
-  t = t * z + 2.449992122e-01f;
-  t = t * z + -3.539759922e-01f;
-  t = t * z + 5.078958901e-01f;
-  t = t * z + -8.487346847e-01f;
-  t = t * z + 2.546477322e+00f;
+  t = __builtin_fmaf(t, z, 5.515013699e-02f);
+  t = __builtin_fmaf(t, z, -1.416326720e-01f);
+  t = __builtin_fmaf(t, z, 2.449992122e-01f);
+  t = __builtin_fmaf(t, z, -3.539759922e-01f);
+  t = __builtin_fmaf(t, z, 5.078958901e-01f);
+  t = __builtin_fmaf(t, z, -8.487346847e-01f);
+  t = __builtin_fmaf(t, z, 2.546477322e+00f);
   t *= q;
   if (ay > ax) t = 4.0f - t;
   if (ex < 0) t = 8.0f - t;
@@ -725,8 +727,8 @@ template <int STG_STRIDE>
 __device__ inline void lidar_point(float* lds, int lane, float rxf, float ryf, float yawf, float cf, float sf,
                                    float px, float py) {
   const float w0 = px - rxf, w1 = py - ryf;
-  const float ex = w0 * cf + w1 * sf, ey = w1 * cf - w0 * sf;
-  const float dist = __builtin_amdgcn_sqrtf(ex * ex + ey * ey);   // 1 ulp: feeds the closeness value only
+  const float ex = __builtin_fmaf(w0, cf, w1 * sf), ey = __builtin_fmaf(w1, cf, -(w0 * sf));
+  const float dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(ex, ex, ey * ey));   // 1 ulp: feeds the closeness value only
   const float t = angle_bins(ex, ey);
   // NaN (the point is the robot's own position: 0 * rcp(0)), or a non-finite state: no float -> int
   // conversion of it (undefined in C++ and poison in LLVM, whatever v_cvt_i32_f32 does with it); bin 16
@@ -738,7 +740,7 @@ __device__ inline void lidar_point(float* lds, int lane, float rxf, float ryf, f
   // the fp32 estimate is off by < 4e-6 bins + 1e-6 / dist (rounding of the relative position);
   // inside that band of a bin boundary fp64 decides
   const float edge = fminf(alias, 1.0f - alias);
-  if (!(edge * dist >= 2e-5f * dist + 1.5e-6f) || bin > 15) {
+  if (!(edge * dist >= __builtin_fmaf(2e-5f, dist, 1.5e-6f)) || bin > 15) {
     const LidarHit h = lidar_exact(rxf, ryf, yawf, px, py);
     bin = h.bin; alias = h.alias; sensor = h.sensor;
   }
@@ -1387,6 +1389,19 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     car_iA_wl = 1.0f / (A_wl + car_R_wl); car_iA_wt = 1.0f / (A_wt + car_R_wt);
     car_iA_bx = 1.0f / (A_bx + car_R_bx); car_iA_by = 1.0f / (A_by + car_R_by);
   }
+  // Point: what does not change over the substeps - the inverse inertia's determinant (a^2 + b^2 = mc^2 for any
+  // heading), its yaw element, the yaw servo's denominator, the drive force - leaves the loop with its two divisions
+  float pt_mIz = 0, pt_id = 0, pt_mid = 0, pt_m5 = 0, pt_iw = 0, pt_c1 = 0, pt_f0 = 0;
+  if constexpr (!CAR) {
+    const float m = PT_MASS + h * damp, Iz = PT_IO + h * PT_DAMP_Z;
+    pt_mIz = m * Iz;
+    pt_id = 1.0f / (m * (pt_mIz - PT_MC * PT_MC));
+    pt_mid = m * pt_id; pt_m5 = m * pt_mid;
+    const float g = h * pt_m5;
+    pt_iw = 1.0f / (1 + g * (PT_GEAR_Z * PT_GEAR_Z));
+    pt_c1 = g * PT_GEAR_Z * ctrl1;
+    pt_f0 = gear * clampf(ctrl0, -PT_FLIM, PT_FLIM);
+  }
 #pragma unroll 1
   for (int sub = 0; sub <= nsub; sub++) {
     // heading: exact at the first substep and at the final forward evaluation (its cos / sin also serve the
@@ -1395,32 +1410,30 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     if (sub == 0 || sub == nsub || !(fabsf(yaw_turn) < 0.25f)) sincosf(yaw, &sy, &cy);
     else {
       const float d2 = yaw_turn * yaw_turn;
-      const float sd = yaw_turn * (1.0f - d2 * (1.0f / 6.0f) * (1.0f - d2 * (1.0f / 20.0f) * (1.0f - d2 * (1.0f / 42.0f))));
-      const float cd = 1.0f - d2 * 0.5f * (1.0f - d2 * (1.0f / 12.0f) * (1.0f - d2 * (1.0f / 30.0f)));
-      const float c1 = cy * cd - sy * sd, s1 = sy * cd + cy * sd;
+      const float sd = yaw_turn * __builtin_fmaf(d2, __builtin_fmaf(d2, __builtin_fmaf(d2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+      const float cd = __builtin_fmaf(d2, __builtin_fmaf(d2, __builtin_fmaf(d2, -1.0f / 720.0f, 1.0f / 24.0f), -0.5f), 1.0f);
+      const float c1 = __builtin_fmaf(cy, cd, -(sy * sd)), s1 = __builtin_fmaf(sy, cd, cy * sd);
       cy = c1; sy = s1;
     }
     if constexpr (!CAR) {
     // robot smooth dynamics (point.xml)
     {
-      float f0 = gear * clampf(ctrl0, -PT_FLIM, PT_FLIM);
-      float Fx = f0 * cy - damp * R.vx + PT_MC * cy * R.w * R.w;
-      float Fy = f0 * sy - damp * R.vy + PT_MC * sy * R.w * R.w;
-      float Tz0 = -PT_DAMP_Z * R.w;
-      float m = PT_MASS + h * damp, Iz = PT_IO + h * PT_DAMP_Z;
-      float a = -PT_MC * sy, b = PT_MC * cy;
-      float id = 1.0f / (m * (m * Iz - a * a - b * b));
-      R.m0 = (m * Iz - b * b) * id; R.m1 = (a * b) * id; R.m2 = (-a * m) * id;
-      R.m3 = (m * Iz - a * a) * id; R.m4 = (-b * m) * id; R.m5 = (m * m) * id;
+      // (fused multiply-adds written out; the drive force and the centrifugal term of the offset COM share the
+      // heading factor: (f0 + mc w^2) (cos, sin))
+      const float fw = __builtin_fmaf(PT_MC * R.w, R.w, pt_f0);
+      const float Fx = __builtin_fmaf(fw, cy, -(damp * R.vx)), Fy = __builtin_fmaf(fw, sy, -(damp * R.vy));
+      const float Tz0 = -PT_DAMP_Z * R.w;
+      const float a = -PT_MC * sy, b = PT_MC * cy;
+      R.m0 = __builtin_fmaf(-b, b, pt_mIz) * pt_id; R.m1 = (a * b) * pt_id; R.m2 = -a * pt_mid;
+      R.m3 = __builtin_fmaf(-a, a, pt_mIz) * pt_id; R.m4 = -b * pt_mid; R.m5 = pt_m5;
       // yaw servo evaluated at the end-of-substep rate (implicit, exact for the clipped-linear
       // law; see DESIGN.md "servo"): explicit feedback would have gain 12.7 per substep
-      float A = R.w + h * (R.m2 * Fx + R.m4 * Fy + R.m5 * Tz0);
-      float g = h * R.m5;
-      float w_lin = (A + g * PT_GEAR_Z * ctrl1) / (1 + g * (PT_GEAR_Z * PT_GEAR_Z));
-      float Tz = PT_GEAR_Z * clampf(ctrl1 - PT_GEAR_Z * w_lin, -PT_FLIM, PT_FLIM) + Tz0;
-      R.ax = R.m0 * Fx + R.m1 * Fy + R.m2 * Tz;
-      R.ay = R.m1 * Fx + R.m3 * Fy + R.m4 * Tz;
-      R.aw = R.m2 * Fx + R.m4 * Fy + R.m5 * Tz;
+      const float A = __builtin_fmaf(h, __builtin_fmaf(R.m2, Fx, __builtin_fmaf(R.m4, Fy, R.m5 * Tz0)), R.w);
+      const float w_lin = (A + pt_c1) * pt_iw;
+      const float Tz = __builtin_fmaf(PT_GEAR_Z, clampf(__builtin_fmaf(-PT_GEAR_Z, w_lin, ctrl1), -PT_FLIM, PT_FLIM), Tz0);
+      R.ax = __builtin_fmaf(R.m0, Fx, __builtin_fmaf(R.m1, Fy, R.m2 * Tz));
+      R.ay = __builtin_fmaf(R.m1, Fx, __builtin_fmaf(R.m3, Fy, R.m4 * Tz));
+      R.aw = __builtin_fmaf(R.m2, Fx, __builtin_fmaf(R.m4, Fy, R.m5 * Tz));
     }
     } else {
       // Car (car.xml; DESIGN.md "Car"): planar base with COM offset, two driven wheels and a
@@ -1676,8 +1689,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     } else {
       if (sub == nsub) break;
     }
-    R.vx += h * R.ax; R.vy += h * R.ay; R.w += h * R.aw;
-    R.x += h * R.vx; R.y += h * R.vy; yaw_turn = h * R.w; yaw += yaw_turn;
+    R.vx = __builtin_fmaf(h, R.ax, R.vx); R.vy = __builtin_fmaf(h, R.ay, R.vy); R.w = __builtin_fmaf(h, R.aw, R.w);
+    R.x = __builtin_fmaf(h, R.vx, R.x); R.y = __builtin_fmaf(h, R.vy, R.y); yaw_turn = h * R.w; yaw += yaw_turn;
     if constexpr (CAR) {
 #pragma unroll
       for (int k = 0; k < 5; k++) ext[k] += h * eacc[k];
