@@ -258,7 +258,12 @@ __device__ inline float pick(const float (&a)[N], int k) {
   return v;
 }
 
+// The planar contact code below contracts a * b + c within an expression into one fused multiply-add
+// (`#pragma clang fp contract(on)`; the translation unit is built with -ffp-contract=off for the fp64 paths that
+// follow the reference's arithmetic operation by operation).  The busy kernels are chains of dependent fp32
+// operations at two wavefronts per SIMD: a fused pair is one link instead of two.
 __device__ inline float minv_apply(const BV& b, float dx, float dy, float rxd, float u[3]) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   u[0] = b.m0 * dx + b.m1 * dy + b.m2 * rxd;
   u[1] = b.m1 * dx + b.m3 * dy + b.m4 * rxd;
   u[2] = b.m2 * dx + b.m4 * dy + b.m5 * rxd;
@@ -267,6 +272,7 @@ __device__ inline float minv_apply(const BV& b, float dx, float dy, float rxd, f
 
 __device__ inline void rel_at(const BV& A, const BV& B, float rax, float ray, float rbx, float rby,
                               float& vx, float& vy, float& ax, float& ay) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   vx = (B.vx - B.w * rby) - (A.vx - A.w * ray);
   vy = (B.vy + B.w * rbx) - (A.vy + A.w * rax);
   ax = (B.ax - B.aw * rby) - (A.ax - A.aw * ray);
@@ -274,6 +280,7 @@ __device__ inline void rel_at(const BV& A, const BV& B, float rax, float ray, fl
 }
 
 __device__ inline float impedance(float depth) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   float x = fminf(depth * (1.0f / SOL_WIDTH), 1.0f);
   float y = x < 0.5f ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x);
   return SOL_D0 + (SOL_D1 - SOL_D0) * y;
@@ -282,6 +289,7 @@ __device__ inline float impedance(float depth) {
 // soft contact, normal then friction; n points from A to B
 __device__ inline void solve_contact(BV& A, BV& B, float nx, float ny, float px, float py,
                                      float depth, const Sol& sol) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   float rax = px - A.x, ray = py - A.y, rbx = px - B.x, rby = py - B.y;
   float vx, vy, ax, ay, ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
   rel_at(A, B, rax, ray, rbx, rby, vx, vy, ax, ay);
@@ -308,6 +316,7 @@ __device__ inline void solve_contact(BV& A, BV& B, float nx, float ny, float px,
 // circle (A, centre ax,ay radius ra) vs circle (B)
 __device__ inline int cc_contact(BV& A, BV& B, float ax, float ay, float ra, float bx, float by,
                                  float rb, const Sol& sol) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   float dx = bx - ax, dy = by - ay, d2 = dx * dx + dy * dy, rs = ra + rb;
   if (d2 >= rs * rs) return 0;
   float d = sqrtf(d2), nx = 1, ny = 0;
@@ -321,6 +330,7 @@ __device__ inline int cc_contact(BV& A, BV& B, float ax, float ay, float ra, flo
 __device__ inline int cb_contact(BV& Circ, BV& Box, float cx, float cy, float r, float bx, float by,
                                  float cb, float sb, float hx, float hy, bool circle_is_A,
                                  const Sol& sol) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   float wx = cx - bx, wy = cy - by;
   float lx = cb * wx + sb * wy, ly = -sb * wx + cb * wy;
   float qx = clampf(lx, -hx, hx), qy = clampf(ly, -hy, hy);
@@ -351,6 +361,7 @@ __device__ inline int cb_contact(BV& Circ, BV& Box, float cx, float cy, float r,
 __device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp, float sp, float phx,
                                    float phy, float qxc, float qyc, float cq, float sq, float qhx,
                                    float qhy, bool q_is_A, const Sol& sol) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   int n = 0;
 #ifdef SAG_VERTS_REF
 #pragma unroll 1
@@ -466,6 +477,7 @@ __device__ inline float shape_bound(int sh, float vsz, float rstatic) {
 template <bool CONST_R = false>
 __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, int shB, float cb,
                                      float sb, float vsz, float rstatic, const Sol& sol) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   int n = 0;
   const int na = shape_ngeom(shA), nb = shape_ngeom(shB);
 #pragma unroll 1
@@ -508,6 +520,7 @@ __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, 
 template <int SHA, int NB>
 __device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB, float cb, float sb, float vsz,
                                       float rstatic, const Sol& sol) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   constexpr int NA = SHA == SH_ROBOT ? 2 : (SHA == SH_CAR ? 8 : 1);
   static_assert(SHA == SH_ROBOT || SHA == SH_CAR || SHA == SH_VASE, "shapes with a compile-time geom list");
   float bx[NB], by[NB], brr[NB];
@@ -1436,6 +1449,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       R.aw = __builtin_fmaf(R.m2, Fx, __builtin_fmaf(R.m4, Fy, R.m5 * Tz));
     }
     } else {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
       // Car (car.xml; DESIGN.md "Car"): planar base with COM offset, two driven wheels and a
       // rear ball; floor contact = regularised Coulomb friction at the three contact points.
       // Evaluated in the BODY frame: there the generalised inverse inertia, the six friction directions (body x
@@ -1468,6 +1482,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       // converged solution, two 2 %: profiles/r02_sweep_convergence.txt; oracle car_smooth)
       auto fricb = [&](const float dx, const float dy, const float rx, const float ry, float rate, float* sacc,
                        float iIsp, float iAR, float Rr, float lim, float& facc) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
         const float rxd = rx * dy - ry * dx;
         const float u0 = M0 * dx + M2 * rxd, u1 = M3 * dy, u2 = M2 * dx + M5 * rxd;
         const float slip = (vbx - R.w * ry) * dx + (vby + R.w * rx) * dy + (sacc ? CRW * rate : 0.f);
@@ -1639,6 +1654,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       CYC(CY_VV_BROAD);
       // floor friction + semi-implicit Euler + rest capture for the active bodies
       for (uint32_t m = active; m; m &= m - 1) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
         const int k = __ffs(m) - 1;
         float vx_, vy_, w_, ax_, ay_, aw_;
         dy.get(k, vx_, vy_, w_, ax_, ay_, aw_);
@@ -1692,6 +1708,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     R.vx = __builtin_fmaf(h, R.ax, R.vx); R.vy = __builtin_fmaf(h, R.ay, R.vy); R.w = __builtin_fmaf(h, R.aw, R.w);
     R.x = __builtin_fmaf(h, R.vx, R.x); R.y = __builtin_fmaf(h, R.vy, R.y); yaw_turn = h * R.w; yaw += yaw_turn;
     if constexpr (CAR) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
 #pragma unroll
       for (int k = 0; k < 5; k++) ext[k] += h * eacc[k];
       // ball quaternion: rate relative to the base, in base axes: q <- exp(h W / 2) q
