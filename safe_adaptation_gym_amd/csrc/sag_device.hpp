@@ -290,6 +290,9 @@ __device__ inline float impedance(float depth) {
 __device__ inline void solve_contact(BV& A, BV& B, float nx, float ny, float px, float py,
                                      float depth, const Sol& sol) {
 #pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
+#if defined(SAG_ABL_CL) && SAG_ABL_CL == 4   // timing-only: pair and vertex tests without the contact solve
+  return;
+#endif
   float rax = px - A.x, ray = py - A.y, rbx = px - B.x, rby = py - B.y;
   float vx, vy, ax, ay, ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
   rel_at(A, B, rax, ray, rbx, rby, vx, vy, ax, ay);
@@ -357,29 +360,10 @@ __device__ inline int cb_contact(BV& Circ, BV& Box, float cx, float cy, float r,
 // normal, else its negative.  A/B are passed in solver order.
 // All four vertices are tested in one straight-line pass (a 4-bit mask per lane); each lane then solves ITS inside
 // vertices in ascending order, so a wavefront runs the contact solve max-inside-count times (1 - 2), not once per
-// vertex index that any lane has inside.  Same arithmetic per vertex as the plain loop (-DSAG_VERTS_REF keeps it).
-__device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp, float sp, float phx,
-                                   float phy, float qxc, float qyc, float cq, float sq, float qhx,
-                                   float qhy, bool q_is_A, const Sol& sol) {
+// vertex index that any lane has inside.
+__device__ inline uint32_t verts_inside_mask(float pxc, float pyc, float cp, float sp, float phx, float phy, float qxc,
+                                             float qyc, float cq, float sq, float qhx, float qhy) {
 #pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
-  int n = 0;
-#ifdef SAG_VERTS_REF
-#pragma unroll 1
-  for (int k = 0; k < 4; k++) {
-    float sx = (k == 0 || k == 3) ? phx : -phx, sy = (k < 2) ? phy : -phy;
-    float vx = pxc + cp * sx - sp * sy, vy = pyc + sp * sx + cp * sy;
-    float wx = vx - qxc, wy = vy - qyc;
-    float lx = cq * wx + sq * wy, ly = -sq * wx + cq * wy;
-    float dx = qhx - fabsf(lx), dy = qhy - fabsf(ly);
-    if (dx <= 0 || dy <= 0) continue;
-    float onx, ony, depth;
-    if (dx < dy) { onx = lx >= 0 ? 1.f : -1.f; ony = 0; depth = dx; }
-    else { onx = 0; ony = ly >= 0 ? 1.f : -1.f; depth = dy; }
-    float sgn = q_is_A ? 1.f : -1.f;
-    solve_contact(A, B, sgn * (cq * onx - sq * ony), sgn * (sq * onx + cq * ony), vx, vy, depth, sol);
-    n++;
-  }
-#else
   uint32_t inside = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -390,21 +374,32 @@ __device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp,
     const float dx = qhx - fabsf(lx), dy = qhy - fabsf(ly);
     inside |= (uint32_t)!(dx <= 0 || dy <= 0) << k;
   }
-  for (; inside; inside &= inside - 1) {
-    const int k = __ffs(inside) - 1;
-    const float sx = (k == 0 || k == 3) ? phx : -phx, sy = (k < 2) ? phy : -phy;
-    const float vx = pxc + cp * sx - sp * sy, vy = pyc + sp * sx + cp * sy;
-    const float wx = vx - qxc, wy = vy - qyc;
-    const float lx = cq * wx + sq * wy, ly = -sq * wx + cq * wy;
-    const float dx = qhx - fabsf(lx), dy = qhy - fabsf(ly);
-    float onx, ony, depth;
-    if (dx < dy) { onx = lx >= 0 ? 1.f : -1.f; ony = 0; depth = dx; }
-    else { onx = 0; ony = ly >= 0 ? 1.f : -1.f; depth = dy; }
-    const float sgn = q_is_A ? 1.f : -1.f;
-    solve_contact(A, B, sgn * (cq * onx - sq * ony), sgn * (sq * onx + cq * ony), vx, vy, depth, sol);
+  return inside;
+}
+// the contact of vertex k of P (known to be inside Q): the same expressions as the test above
+__device__ inline void vert_contact(BV& A, BV& B, int k, float pxc, float pyc, float cp, float sp, float phx, float phy,
+                                    float qxc, float qyc, float cq, float sq, float qhx, float qhy, bool q_is_A,
+                                    const Sol& sol) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
+  const float sx = (k == 0 || k == 3) ? phx : -phx, sy = (k < 2) ? phy : -phy;
+  const float vx = pxc + cp * sx - sp * sy, vy = pyc + sp * sx + cp * sy;
+  const float wx = vx - qxc, wy = vy - qyc;
+  const float lx = cq * wx + sq * wy, ly = -sq * wx + cq * wy;
+  const float dx = qhx - fabsf(lx), dy = qhy - fabsf(ly);
+  float onx, ony, depth;
+  if (dx < dy) { onx = lx >= 0 ? 1.f : -1.f; ony = 0; depth = dx; }
+  else { onx = 0; ony = ly >= 0 ? 1.f : -1.f; depth = dy; }
+  const float sgn = q_is_A ? 1.f : -1.f;
+  solve_contact(A, B, sgn * (cq * onx - sq * ony), sgn * (sq * onx + cq * ony), vx, vy, depth, sol);
+}
+__device__ inline int verts_in_box(BV& A, BV& B, float pxc, float pyc, float cp, float sp, float phx,
+                                   float phy, float qxc, float qyc, float cq, float sq, float qhx,
+                                   float qhy, bool q_is_A, const Sol& sol) {
+  int n = 0;
+  for (uint32_t inside = verts_inside_mask(pxc, pyc, cp, sp, phx, phy, qxc, qyc, cq, sq, qhx, qhy); inside; inside &= inside - 1) {
+    vert_contact(A, B, __ffs(inside) - 1, pxc, pyc, cp, sp, phx, phy, qxc, qyc, cq, sq, qhx, qhy, q_is_A, sol);
     n++;
   }
-#endif
   return n;
 }
 
@@ -415,6 +410,27 @@ __device__ inline int bb_contact(BV& A, BV& B, float ax, float ay, float ca, flo
   n += verts_in_box(A, B, bx, by, cb, sb, bhx, bhy, ax, ay, ca, sa, ahx, ahy, true, sol);
   return n;
 }
+
+// Separating-axis test of two oriented boxes (centre, cos / sin, half extents): true = some axis of one of them
+// separates the two, so no vertex of either lies inside the other and bb_contact would find nothing.  A cull the
+// specification does not have; SAT_EPS makes it conservative against its own rounding (a pair is only skipped when
+// the gap along an axis exceeds 1e-5 m; bb_contact's vertices must be strictly inside).  Most pairs that pass the
+// bounding circles are thin bumpers beside a box: 40 instructions here instead of 2 x 4 vertex transforms there.
+constexpr float SAT_EPS = 1e-5f;
+#ifndef SAG_NO_SAT
+__device__ inline bool boxes_separated(float ax, float ay, float ca, float sa, float ahx, float ahy, float bx, float by,
+                                       float cb, float sb, float bhx, float bhy) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
+  const float c = fabsf(ca * cb + sa * sb), s = fabsf(sa * cb - ca * sb);   // |axis . axis| of the two frames
+  const float tx = bx - ax, ty = by - ay;
+  const float ta_x = ca * tx + sa * ty, ta_y = ca * ty - sa * tx;   // centre offset in A's frame
+  const float tb_x = cb * tx + sb * ty, tb_y = cb * ty - sb * tx;   // ... in B's
+  return fabsf(ta_x) > ahx + bhx * c + bhy * s + SAT_EPS || fabsf(ta_y) > ahy + bhx * s + bhy * c + SAT_EPS ||
+         fabsf(tb_x) > bhx + ahx * c + ahy * s + SAT_EPS || fabsf(tb_y) > bhy + ahx * s + ahy * c + SAT_EPS;
+}
+#else   // (diagnosis: results must be bit-identical with and without the cull - tests/diag_traj.py)
+__device__ inline bool boxes_separated(float, float, float, float, float, float, float, float, float, float, float, float) { return false; }
+#endif
 
 __device__ inline double dist2d(double ax, double ay, double bx, double by) {
   double dx = ax - bx, dy = ay - by;
@@ -505,31 +521,48 @@ __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, 
       if (!a.box && !b.box) n += cc_contact(A, B, ax, ay, a.a, bx, by, b.a, sol);
       else if (!a.box) n += cb_contact(A, B, ax, ay, a.a, bx, by, cb, sb, b.a, b.b, true, sol);
       else if (!b.box) n += cb_contact(B, A, bx, by, b.a, ax, ay, ca, sa, a.a, a.b, false, sol);
-      else n += bb_contact(A, B, ax, ay, ca, sa, a.a, a.b, bx, by, cb, sb, b.a, b.b, sol);
+      else if (!boxes_separated(ax, ay, ca, sa, a.a, a.b, bx, by, cb, sb, b.a, b.b))
+        n += bb_contact(A, B, ax, ay, ca, sa, a.a, a.b, bx, by, cb, sb, b.a, b.b, sol);
     }
   }
   return n;
 }
 
-// The same pair tests for a compile-time shape A (the robot's footprint, a vase), organised for the wavefront:
-// one branch-free pass culls every geom pair with the bounding circles (A's geoms are constants after unrolling)
-// into a per-lane bit mask, then each lane walks ITS OWN hits in ascending (geom of A, geom of B) order - the
-// specification's order.  collide_shapes runs its 8 x 5 loop for the union of what 64 lanes need (the car pushing
-// a box: ~40 culls + ~10 narrowphases per substep); here a wavefront pays 40 straight-line culls + the maximum
-// number of hits of one lane (2 - 3).  Arithmetic per pair is collide_shapes<true>'s, so results are bit-identical.
+// The same pair tests for a compile-time shape A (the robot's footprint, a vase), organised for the wavefront: one
+// branch-free pass tests every geom pair for a separating axis into a per-lane bit mask, then each lane walks ITS OWN
+// hits in ascending (geom of A, geom of B) order - the specification's order.  collide_shapes runs its 8 x 5 loop for
+// the union of what 64 lanes need; here a wavefront pays 40 straight-line tests + the maximum number of pairs of one
+// lane that really overlap (2 - 3).
+// The test: every geom is axis-aligned in its body's frame, so ONE relative rotation (|cos|, |sin| of the angle between
+// the two bodies) serves all pairs; a pair costs four compares of a centre offset against half extents + projected
+// half extents (circles count as their bounding squares).  With bounding circles alone (the first version) a thin
+// bumper 'hit' everything within 0.1 m of its centre and the contact loop ran ~8 times a substep for a car at the
+// box, finding nothing in most of them: 70 % of the busy kernel's instructions (PMC, contact solve switched off).
+// Conservative by SAT_EPS; the contacts found are the same (bit-identical trajectories, tests/diag_traj.py).
 template <int SHA, int NB>
 __device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB, float cb, float sb, float vsz,
                                       float rstatic, const Sol& sol) {
 #pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
   constexpr int NA = SHA == SH_ROBOT ? 2 : (SHA == SH_CAR ? 8 : 1);
   static_assert(SHA == SH_ROBOT || SHA == SH_CAR || SHA == SH_VASE, "shapes with a compile-time geom list");
-  float bx[NB], by[NB], brr[NB];
+#if defined(SAG_ABL_CL) && SAG_ABL_CL == 2   // timing-only: no pair test at all
+  return 0;
+#endif
+  const float rc = ca * cb + sa * sb, rs = sa * cb - ca * sb;   // x axis of A . x axis of B, x axis of A . y axis of B
+  const float ac = fabsf(rc), as = fabsf(rs);
+  // B's geoms: centre in A's frame (relative to A's origin), half extents projected on A's axes
+  float lbx[NB], lby[NB], pax[NB], pay[NB];
 #pragma unroll
   for (int gb = 0; gb < NB; gb++) {
     const Geom b = shape_geom(shB, gb, vsz, rstatic);
-    bx[gb] = B.x + cb * b.ox - sb * b.oy; by[gb] = B.y + sb * b.ox + cb * b.oy; brr[gb] = b.r;
+    const float wx = B.x + cb * b.ox - sb * b.oy - A.x, wy = B.y + sb * b.ox + cb * b.oy - A.y;
+    lbx[gb] = ca * wx + sa * wy; lby[gb] = ca * wy - sa * wx;
+    const float hb = b.box ? b.b : b.a;
+    pax[gb] = b.a * ac + hb * as + SAT_EPS; pay[gb] = b.a * as + hb * ac + SAT_EPS;
   }
-  const float bound_b = shape_bound(shB, vsz, rstatic) * 1.000001f;
+  // A's origin in B's frame
+  const float odx = A.x - B.x, ody = A.y - B.y;
+  const float obx = cb * odx + sb * ody, oby = cb * ody - sb * odx;
   typedef typename std::conditional<(NA > 4), uint64_t, uint32_t>::type mask_t;
   mask_t mask = 0;   // bit 8 ga + gb
 #ifndef SAG_CL_UNROLL_A
@@ -540,29 +573,92 @@ __device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB,
 #pragma unroll UNROLL_A
   for (int ga = 0; ga < NA; ga++) {
     const Geom a = shape_geom(SHA, ga, vsz, rstatic);
-    const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;
-    bool outer = true;
-    if constexpr (NB > 1) {
-      const float ex = B.x - ax, ey = B.y - ay, rb_all = a.r + bound_b;
-      outer = !(ex * ex + ey * ey > rb_all * rb_all);
-    }
+    const float ha = a.box ? a.b : a.a;
+    // this geom's centre in B's frame, its half extents projected on B's axes
+    const float lax = obx + a.ox * rc - a.oy * rs, lay = oby + a.ox * rs + a.oy * rc;
+    const float pbx = a.a * ac + ha * as + SAT_EPS, pby = a.a * as + ha * ac + SAT_EPS;
 #pragma unroll
     for (int gb = 0; gb < NB; gb++) {
-      // the ball's centre is .04 above the robot sphere's: it presents sqrt(.24^2-.04^2)-.1
-      const float rb = (SHA == SH_ROBOT && ga == 0 && shB == SH_BALL) ? 0.13664319132398464f : brr[gb];
-      const float dx = bx[gb] - ax, dy = by[gb] - ay, rs = a.r + rb;
-      const bool hit = outer && !(dx * dx + dy * dy > rs * rs);
+      const Geom b = shape_geom(shB, gb, vsz, rstatic);
+      const float hb = b.box ? b.b : b.a;
+      const bool hit = !(fabsf(lbx[gb] - a.ox) > a.a + pax[gb]) && !(fabsf(lby[gb] - a.oy) > ha + pay[gb]) &&
+                       !(fabsf(lax - b.ox) > b.a + pbx) && !(fabsf(lay - b.oy) > hb + pby);
       mask |= (mask_t)hit << (8 * ga + gb);
     }
   }
   int n = 0;
+#if defined(SAG_ABL_CL) && SAG_ABL_CL == 1   // timing-only: the bounding-circle pass alone
+  mask = 0;
+#endif
+#ifdef SAG_CL_QUEUE   // (-DSAG_CL_QUEUE: contacts queued per lane and solved in one loop; bit-identical results, measured SLOWER: 3.04 vs 2.40 ms per Car step at 4 M envs)
+  if constexpr (SHA == SH_CAR) {
+    // Per lane over ITS circle hits, in the specification's pair order: box pairs an axis separates drop out
+    // (boxes_separated); the others QUEUE their contacts - one item per inside vertex, [pair:6][box pair:1][dir:1]
+    // [vertex:2], six to a 64-bit word - and the queue is solved afterwards in one loop.  Solved pair by pair, a
+    // wavefront ran the vertex tests and both solve loops once per pair index ANY lane still had (~8 a substep for
+    // a car pushing the 5-geom box, most lanes idle in each); now it runs the solve max-contacts-of-a-lane times
+    // (3 - 5).  Insideness depends on positions only, which the contact solves (accelerations) do not change.
+    constexpr int ITEM_BITS = 10, PER_WORD = 6, CAP = 2 * PER_WORD;
+    uint64_t q0 = 0, q1 = 0;
+    int cnt = 0;
+    auto pair_geoms = [&](int pbit, Geom& a, Geom& b, float& ax, float& ay, float& qx, float& qy) {
+      a = shape_geom(SHA, pbit >> 3, vsz, rstatic);
+      b = shape_geom(shB, NB > 1 ? pbit & 7 : 0, vsz, rstatic);
+      ax = A.x + ca * a.ox - sa * a.oy; ay = A.y + sa * a.ox + ca * a.oy;
+      qx = B.x + cb * b.ox - sb * b.oy; qy = B.y + sb * b.ox + cb * b.oy;
+    };
+    auto push = [&](uint32_t item) {
+      const bool lo = cnt < PER_WORD;
+      const uint64_t v = (uint64_t)item << (ITEM_BITS * (lo ? cnt : cnt - PER_WORD));
+      q0 |= lo ? v : 0ull; q1 |= lo ? 0ull : v;
+      cnt++;
+    };
+    auto drain = [&]() {
+      for (int it = 0; it < cnt; it++) {
+        const uint32_t item = (uint32_t)((it < PER_WORD ? q0 >> (ITEM_BITS * it) : q1 >> (ITEM_BITS * (it - PER_WORD))) & 1023ull);
+        Geom a, b; float ax, ay, qx, qy;
+        pair_geoms((int)(item & 63u), a, b, ax, ay, qx, qy);
+        if (item >> 6 & 1u) {
+          const int k = (int)(item >> 8 & 3u);
+          if (item >> 7 & 1u) vert_contact(A, B, k, qx, qy, cb, sb, b.a, b.b, ax, ay, ca, sa, a.a, a.b, true, sol);
+          else vert_contact(A, B, k, ax, ay, ca, sa, a.a, a.b, qx, qy, cb, sb, b.a, b.b, false, sol);
+          n++;
+        } else if (!a.box && !b.box) n += cc_contact(A, B, ax, ay, a.a, qx, qy, b.a, sol);
+        else if (!a.box) n += cb_contact(A, B, ax, ay, a.a, qx, qy, cb, sb, b.a, b.b, true, sol);
+        else n += cb_contact(B, A, qx, qy, b.a, ax, ay, ca, sa, a.a, a.b, false, sol);
+      }
+      q0 = 0; q1 = 0; cnt = 0;
+    };
+    for (mask_t mm = mask; mm; mm &= mm - 1) {
+      const int pbit = __ffsll((unsigned long long)mm) - 1;
+      Geom a, b; float ax, ay, qx, qy;
+      pair_geoms(pbit, a, b, ax, ay, qx, qy);
+      if (a.box && b.box) {
+        if (boxes_separated(ax, ay, ca, sa, a.a, a.b, qx, qy, cb, sb, b.a, b.b)) continue;
+        const uint32_t in_ab = verts_inside_mask(ax, ay, ca, sa, a.a, a.b, qx, qy, cb, sb, b.a, b.b);   // A's vertices in B
+        const uint32_t in_ba = verts_inside_mask(qx, qy, cb, sb, b.a, b.b, ax, ay, ca, sa, a.a, a.b);   // B's in A
+        if (cnt + __popc(in_ab) + __popc(in_ba) > CAP) drain();   // (a lane's own decision; never in practice)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (in_ab >> k & 1u) push((uint32_t)pbit | 64u | (uint32_t)k << 8);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (in_ba >> k & 1u) push((uint32_t)pbit | 64u | 128u | (uint32_t)k << 8);
+      } else {
+        if (cnt + 1 > CAP) drain();
+        push((uint32_t)pbit);
+      }
+    }
+    drain();
+    return n;
+  }
+#endif
   while (mask) {
     const int pbit = (NA > 4 ? __ffsll((unsigned long long)mask) : __ffs((unsigned int)mask)) - 1;
     mask &= mask - 1;
     const int ga = NA > 1 ? pbit >> 3 : 0, gb = NB > 1 ? pbit & 7 : 0;
     const Geom a = shape_geom(SHA, ga, vsz, rstatic);
     Geom b = shape_geom(shB, gb, vsz, rstatic);
-    if (SHA == SH_ROBOT && ga == 0 && shB == SH_BALL) b.a = b.r = 0.13664319132398464f;
     const float ax = A.x + ca * a.ox - sa * a.oy, ay = A.y + sa * a.ox + ca * a.oy;
     const float qx = B.x + cb * b.ox - sb * b.oy, qy = B.y + sb * b.ox + cb * b.oy;
     if (!a.box && !b.box) n += cc_contact(A, B, ax, ay, a.a, qx, qy, b.a, sol);
@@ -580,7 +676,7 @@ __device__ inline int collide_list(BV& A, float ca, float sa, BV& B, int shB, fl
   return collide_shapes<true>(A, SHA, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
 #endif
   if constexpr (MULTI) {
-    if (shape_ngeom(shB) > 1) return collide_list_nb<SHA, 5>(A, ca, sa, B, shB, cb, sb, vsz, rstatic, sol);
+    if (shape_ngeom(shB) > 1) return collide_list_nb<SHA, 5>(A, ca, sa, B, SH_BOX, cb, sb, vsz, rstatic, sol);   // (the only 5-geom shape)
   }
   // one or two pairs (Point robot or a vase against a single-geom body): nothing to gain from a list, the plain loop
   // is the shorter code (measured: the list form costs the Point step 5 %)
