@@ -560,7 +560,8 @@ __device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB,
     const float hb = b.box ? b.b : b.a;
     pax[gb] = b.a * ac + hb * as + SAT_EPS; pay[gb] = b.a * as + hb * ac + SAT_EPS;
   }
-  // A's origin in B's frame
+  // A's origin in B's frame  (tried: a wave-uniform skip of A's geoms that no lane has within B's bounding circle -
+  // no gain, some lane always needs each geom)
   const float odx = A.x - B.x, ody = A.y - B.y;
   const float obx = cb * odx + sb * ody, oby = cb * ody - sb * odx;
   typedef typename std::conditional<(NA > 4), uint64_t, uint32_t>::type mask_t;
