@@ -2631,18 +2631,20 @@ __global__ void k_bump_episode(int32_t* rec_i, int n) {
 __device__ inline void lidar_bin_alias(float ex, float ey, int& bin, float& alias) {
   const float ax = fabsf(ex), ay = fabsf(ey);
   const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  const float q = mn / mx, z = q * q;
+  // (reciprocal to 1 ulp and fused multiply-adds: ~1e-7 bins on top of the polynomial's 3.5e-7, far inside the
+  // 2e-5-bin band the caller re-checks in fp64; half the instructions of the IEEE division + separate mul / add form)
+  const float q = mn * __builtin_amdgcn_rcpf(mx), z = q * q;
   float t = 2.352551941e-03f;
-  t = t * z + -1.610619163e-02f;
-  t = t * z + 5.173371997e-02f;
-  t = t * z + -1.067070450e-01f;
-  t = t * z + 1.662277135e-01f;
-  t = t * z + -2.217355754e-01f;
-  t = t * z + 2.807958079e-01f;
-  t = t * z + -3.634874369e-01f;
-  t = t * z + 5.092729113e-01f;
-  t = t * z + -8.488255360e-01f;
-  t = t * z + 2.546479081e+00f;
+  t = __builtin_fmaf(t, z, -1.610619163e-02f);
+  t = __builtin_fmaf(t, z, 5.173371997e-02f);
+  t = __builtin_fmaf(t, z, -1.067070450e-01f);
+  t = __builtin_fmaf(t, z, 1.662277135e-01f);
+  t = __builtin_fmaf(t, z, -2.217355754e-01f);
+  t = __builtin_fmaf(t, z, 2.807958079e-01f);
+  t = __builtin_fmaf(t, z, -3.634874369e-01f);
+  t = __builtin_fmaf(t, z, 5.092729113e-01f);
+  t = __builtin_fmaf(t, z, -8.488255360e-01f);
+  t = __builtin_fmaf(t, z, 2.546479081e+00f);
   t *= q;
   int b = t >= 1.0f ? 1 : 0;
   float f = t - (float)b;
@@ -2732,11 +2734,11 @@ __global__ __launch_bounds__(WAVE) void k_lidar_cost(int n, int K, const float* 
       int b = -1;
       if (g >= 1 && g <= 3) {
         const float ex = (float)(W0 * cd + W1 * sd), ey = (float)(W0 * -sd + W1 * cd);
-        const float dist = sqrtf(ex * ex + ey * ey);
-        float alias, sensor = fmaxf(5.0f - dist, 0.0f) / 5.0f;
+        const float dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(ex, ex, ey * ey));   // 1 ulp: feeds the closeness value only
+        float alias, sensor = fmaxf(5.0f - dist, 0.0f) * 0.2f;
         lidar_bin_alias(ex, ey, b, alias);
         const float edge = fminf(alias, 1.0f - alias);
-        if (!(edge * dist >= 2e-5f * dist + 1.5e-6f) || b > 15) {
+        if (!(edge * dist >= __builtin_fmaf(2e-5f, dist, 1.5e-6f)) || b > 15) {
           const LidarHit h = lidar_exact(rxf, ryf, yawf, p.x, p.y);
           b = h.bin; alias = h.alias; sensor = h.sensor;
         }

@@ -18,6 +18,13 @@ def fit(nterms):
   return c, e.max()
 
 
+def fma32(a, b, c):
+  """fp32 fused multiply-add: the product of two fp32 is exact in fp64; one rounding to fp32 (double rounding through
+  fp64 is negligible for an error bound).  The kernels evaluate both polynomials with explicit fmaf since round 2."""
+  return (a.astype(np.float64) * np.float64(b) + np.float64(c)).astype(np.float32) if np.isscalar(b) or np.ndim(b) == 0 \
+      else (a.astype(np.float64) * b.astype(np.float64) + np.float64(c)).astype(np.float32)
+
+
 def angle_bins_f32(ex, ey, c):
   f = np.float32
   c = c.astype(f)
@@ -27,7 +34,7 @@ def angle_bins_f32(ex, ey, c):
   z = (q * q).astype(f)
   t = np.full(len(ex), c[-1], f)
   for k in range(len(c) - 2, -1, -1):
-    t = ((t * z).astype(f) + c[k]).astype(f)
+    t = fma32(t, z, c[k])
   t = (t * q).astype(f)
   t = np.where(ay > ax, (f(4) - t).astype(f), t)
   t = np.where(ex < 0, (f(8) - t).astype(f), t)
@@ -57,11 +64,11 @@ def angle_bin_alias_f32(ex, ey, c):
   c = c.astype(f)
   ax, ay = np.abs(ex), np.abs(ey)
   mx, mn = np.maximum(ax, ay), np.minimum(ax, ay)
-  q = (mn / mx).astype(f)
+  q = (mn * (f(1) / mx).astype(f)).astype(f)   # v_rcp_f32 (1 ulp) + multiply
   z = (q * q).astype(f)
   t = np.full(len(ex), c[-1], f)
   for k in range(len(c) - 2, -1, -1):
-    t = ((t * z).astype(f) + c[k]).astype(f)
+    t = fma32(t, z, c[k])
   t = (t * q).astype(f)
   b = np.minimum(np.floor(t), 1).astype(np.int32)      # t in [0, 2]: bin 0 or 1 (t == 2 -> bin 1, fraction 1)
   fr = (t - b.astype(f)).astype(f)
