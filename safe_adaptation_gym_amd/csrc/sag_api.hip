@@ -408,6 +408,19 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   return 0;
 }
 
+// K <= 21 (the reference's point count): the register-resident kernel at 13 wavefronts per CU; more points per env: the
+// LDS-staged one.  SAG_LIDAR_REG=0 forces the latter (A/B).
+void launch_lidar_cost(sag_ctx* c, int n, int K, const float* d_robot, const float* d_pts, const uint8_t* d_grp, float hazard_size,
+                       float* d_lid, int32_t* d_bins, uint8_t* d_cost) {
+  static const bool use_reg = [] { const char* e = getenv("SAG_LIDAR_REG"); return !e || atoi(e) != 0; }();
+  if (K <= LC_KREG && use_reg)
+    hipLaunchKernelGGL(k_lidar_cost_reg, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts, d_grp,
+                       hazard_size, d_lid, d_bins, d_cost);
+  else
+    hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lidar_cost_lds_bytes(K), c->stream, n, K, d_robot, d_pts,
+                       d_grp, hazard_size, d_lid, d_bins, d_cost);
+}
+
 }  // namespace
 
 extern "C" {
@@ -738,8 +751,7 @@ int sag_lidar_cost(sag_ctx* c, int32_t n, int32_t K, const float* robot, const f
     HIPCHK(c, hipMemcpyAsync(d_pts, points, (size_t)n * K * 2 * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_grp, group, (size_t)n * K, hipMemcpyHostToDevice, c->stream));
   }
-  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lidar_cost_lds_bytes(K), c->stream, n, K, d_robot, d_pts,
-                     d_grp, hazard_size, d_lid, bins ? d_bins : nullptr, d_cost);
+  launch_lidar_cost(c, n, K, d_robot, d_pts, d_grp, hazard_size, d_lid, bins ? d_bins : nullptr, d_cost);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(lidar, d_lid, (size_t)n * 48 * 4, hipMemcpyDeviceToHost, c->stream));
   if (bins && K > 0) HIPCHK(c, hipMemcpyAsync(bins, d_bins, (size_t)n * K * 4, hipMemcpyDeviceToHost, c->stream));
@@ -759,8 +771,7 @@ int sag_lidar_cost_device(sag_ctx* c, int32_t n, int32_t K, const float* d_robot
   if (rc) return rc;
   if (lidar_cost_lds_bytes(K) > 64 * 1024) return fail(c, SAG_ERR_ARG, "K = %d points per env exceed the kernel's LDS staging (K <= 100)", K);
   if (e0) HIPCHK(c, hipEventRecord(e0, c->stream));
-  hipLaunchKernelGGL(k_lidar_cost, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), lidar_cost_lds_bytes(K), c->stream, n, K, d_robot, d_points,
-                     d_group, hazard_size, d_lidar, d_bins, d_cost);
+  launch_lidar_cost(c, n, K, d_robot, d_points, d_group, hazard_size, d_lidar, d_bins, d_cost);
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
   HIPCHK(c, hipGetLastError());
   return SAG_OK;

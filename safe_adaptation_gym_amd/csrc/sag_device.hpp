@@ -2773,6 +2773,119 @@ __global__ __launch_bounds__(WAVE) void k_lidar_cost(int n, int K, const float* 
   if (live) cost[i] = (uint8_t)cst;
 }
 
+// The same for K <= LC_KREG points per env (the reference's 8 hazards + 12 vases / pillars / buttons + the goal = 21):
+// ONE LDS region of 12.25 KB serves three purposes in turn - input staging, the [48][64] accumulation tile, its
+// transpose - because each lane first moves ITS env's points and group bytes from the staging area into registers
+// (42 + 6 VGPRs, the point loop unrolled), and the transpose goes through 48 registers in place.  13 wavefronts per CU
+// instead of 6 (24.8 KB per wavefront): the loop body is a chain of fp64 / fp32 operations, LDS atomics and the
+// occasional fp64 re-evaluation, and hides its latencies only through other wavefronts.  Same arithmetic, point for
+// point, as k_lidar_cost.
+constexpr int LC_KREG = 21;
+constexpr int LC_REG_FLOATS = WAVE * 49;   // >= 48 * WAVE (tile), >= staging of K = 21: 64 * 21 * 2 floats + 64 * 21 bytes
+static_assert((size_t)WAVE * LC_KREG * 2 * 4 + (size_t)WAVE * LC_KREG <= (size_t)LC_REG_FLOATS * 4, "staging fits the tile region");
+__global__ __launch_bounds__(WAVE, 3) void k_lidar_cost_reg(int n, int K, const float* __restrict__ robot,
+                                                            const float* __restrict__ points, const uint8_t* __restrict__ group,
+                                                            float hazard_size, float* __restrict__ lidar,
+                                                            int32_t* __restrict__ bins, uint8_t* __restrict__ cost) {
+  __shared__ float4 lc_reg4[LC_REG_FLOATS / 4];
+  float* tile = reinterpret_cast<float*>(lc_reg4);
+  uint8_t* in_grp = reinterpret_cast<uint8_t*>(tile + (size_t)WAVE * 2 * K);
+  const int lane = threadIdx.x;
+  const size_t e0 = (size_t)blockIdx.x * WAVE;
+  const int nenv = (int)((size_t)n - e0 < (size_t)WAVE ? (size_t)n - e0 : (size_t)WAVE);
+  const size_t i = e0 + lane;
+  const bool live = lane < nenv;
+  // ---- coalesced copy in, then the lane's own env into registers ------------------------------
+  {
+    const float* src = points + e0 * 2 * K;
+    const int nf = nenv * 2 * K;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      for (int q = lane; q < nf / 4; q += WAVE) lc_reg4[q] = s4[q];
+      for (int q = (nf & ~3) + lane; q < nf; q += WAVE) tile[q] = src[q];
+    } else {
+      for (int q = lane; q < nf; q += WAVE) tile[q] = src[q];
+    }
+    const uint8_t* gs = group + e0 * K;
+    const int nb = nenv * K;
+    for (int q = lane; q < nb; q += WAVE) in_grp[q] = gs[q];
+  }
+  __syncthreads();
+  float px[LC_KREG], py[LC_KREG];
+  uint32_t gpk[(LC_KREG + 3) / 4] = {};
+#pragma unroll
+  for (int j = 0; j < LC_KREG; j++) {
+    px[j] = 0.f; py[j] = 0.f;
+    if (j < K && live) {
+      const float2 p = reinterpret_cast<const float2*>(tile)[lane * K + j];
+      px[j] = p.x; py[j] = p.y;
+      gpk[j >> 2] |= (uint32_t)in_grp[lane * K + j] << (8 * (j & 3));
+    }
+  }
+  __syncthreads();   // the staging area becomes the accumulation tile
+#pragma unroll
+  for (int k = 0; k < 48; k++) tile[k * WAVE + lane] = 0.0f;
+  int cst = 0;
+  if (live) {
+    const float rxf = robot[i * 3], ryf = robot[i * 3 + 1], yawf = robot[i * 3 + 2];
+    const double rx = rxf, ry = ryf, cd = cos((double)yawf), sd = sin((double)yawf);
+    const float t2 = hazard_size * hazard_size;
+    int* acc = reinterpret_cast<int*>(tile) + lane;   // (a lane only touches its own column: no barrier before the loop)
+#pragma unroll
+    for (int j = 0; j < LC_KREG; j++) {
+      if (j >= K) continue;   // (K is uniform)
+      const int gg = (int)(gpk[j >> 2] >> (8 * (j & 3)) & 255u), g = gg & 127;
+      const double W0 = (double)px[j] - rx, W1 = (double)py[j] - ry;
+      if (gg & 128) {
+        const float d2 = (float)(W0 * W0 + W1 * W1);
+        bool in = d2 <= t2;
+        if (fabsf(d2 - t2) < 1e-5f) in = dist2d(rx, ry, px[j], py[j]) <= (double)hazard_size;
+        cst |= in;
+      }
+      int b = -1;
+      if (g >= 1 && g <= 3) {
+        const float ex = (float)(W0 * cd + W1 * sd), ey = (float)(W0 * -sd + W1 * cd);
+        const float dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(ex, ex, ey * ey));
+        float alias, sensor = fmaxf(5.0f - dist, 0.0f) * 0.2f;
+        lidar_bin_alias(ex, ey, b, alias);
+        const float edge = fminf(alias, 1.0f - alias);
+        if (!(edge * dist >= __builtin_fmaf(2e-5f, dist, 1.5e-6f)) || b > 15) {
+          const LidarHit h = lidar_exact(rxf, ryf, yawf, px[j], py[j]);
+          b = h.bin; alias = h.alias; sensor = h.sensor;
+        }
+        const int base = (g == 1 ? 0 : (g == 3 ? 16 : 32)) * WAVE;
+        atomicMax(acc + base + b * WAVE, __float_as_int(sensor));
+        atomicMax(acc + base + ((b + 1) & 15) * WAVE, __float_as_int(alias * sensor));
+        atomicMax(acc + base + ((b + 15) & 15) * WAVE, __float_as_int((1.0f - alias) * sensor));
+      }
+      if (bins) bins[i * K + j] = b;
+    }
+  }
+  // ---- transpose [48][64] -> [64][49] in place through registers, leave as one contiguous block ----
+  float col[48];
+#pragma unroll
+  for (int k = 0; k < 48; k++) col[k] = tile[k * WAVE + lane];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 48; k++) tile[lane * 49 + k] = col[k];
+  __syncthreads();
+  {
+    float* dst = lidar + e0 * 48;
+    const int nq = nenv * 12;
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int q = lane; q < nq; q += WAVE) {
+        const int env = (int)(((uint32_t)q * 43691u) >> 19);   // q / 12, exact for q < 768
+        const float* t = tile + env * 49 + 4 * (q - 12 * env);
+        d4[q] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    } else {
+      for (int q = lane; q < nenv * 48; q += WAVE) { const int env = q / 48; dst[q] = tile[env * 49 + (q - 48 * env)]; }
+    }
+  }
+  if (live) cost[i] = (uint8_t)cst;
+}
+
 // synthetic policy: U(-1,1)^nu from Philox stream 2
 __global__ void k_fill_actions(float* actions, const int32_t* I, int N, int nu, uint32_t k0,
                                uint32_t k1, uint32_t step_index) {

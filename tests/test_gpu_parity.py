@@ -50,8 +50,10 @@ def _lidar_inputs(n, K, seed):
   return robot, pts, grp
 
 
-def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle):
-  n, K = 4096, 21
+@pytest.mark.parametrize('K', [21, 13, 30])
+def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle, K):
+  """K <= 21 runs the register-resident kernel (k_lidar_cost_reg), more points per env the LDS-staged one."""
+  n = 4096
   robot, pts, grp = _lidar_inputs(n, K, 1)
   ctx = nat.Context('point', n)
   lidar, bins, cost = ctx.lidar_cost(robot, pts, grp)
