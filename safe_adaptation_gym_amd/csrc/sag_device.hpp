@@ -177,8 +177,10 @@ constexpr int CAR_FRICTION_SWEEPS = 1;   // Gauss-Seidel sweeps over the six flo
 __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
-    uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-    uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    // (one 64-bit product per multiplier - v_mad_u64_u32 - instead of a mul_hi + mul_lo pair: integer multiplies
+    // issue at a quarter of the rate, and this runs for every env-step)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
     c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
