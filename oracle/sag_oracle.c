@@ -443,8 +443,6 @@ static real impedance(real depth) {
  * and only the increment is applied.  With f = 0 this is the specification's one-shot formula
  * d (aref - a) / A, so sweep 0 of the N-sweep mode IS the specification; n = 1 runs the original code. */
 static int g_sweeps = 1;
-static int g_car_sweeps = 1;   /* (study knob: plain Gauss-Seidel sweeps over the car's six floor-friction elements) */
-void sago_set_car_sweeps(int n) { g_car_sweeps = n < 1 ? 1 : n; }
 void sago_set_sweeps(int n) { g_sweeps = n < 1 ? 1 : n; }
 int sago_get_sweeps(void) { return g_sweeps; }
 #define ACC_SLOTS 8192
@@ -603,6 +601,7 @@ typedef struct {
   int nV, nP, nB, box_kind, haul;
   int robot_id;
   real ext[SAG_ROBOT_EXT_FLOATS], ext_acc[5]; /* car: wheel rates L,R; ball rate x,y,z; ball quat w,x,y,z */
+  real ext_acc0[5], car_fa[3];                /* car: spin accelerations without floor friction; the friction's share of the base acceleration (body axes) */
   void* dg;                                   /* doggo: Doggo* articulated state (sag_oracle_doggo.inc) */
 } World;
 
@@ -939,21 +938,24 @@ void sago_car_constants(double out[9]) {
  * spinning part (wheel / ball) through lever `rw` and inertia `Ispin` */
 static real car_friction(Body* r, real dx, real dy, real rx, real ry, real spin_rate, real* spin_acc,
                          real rw, real Ispin, real limit, real bcoef, real* facc) {
+  (void)facc;
   real u[3];
   real A = minv_apply(r, dx, dy, rx * dy - ry * dx, u);
   real slip = (r->vx - r->w * ry) * dx + (r->vy + r->w * rx) * dy + rw * spin_rate;
   real sacc = (r->ax - r->aw * ry) * dx + (r->ay + r->aw * rx) * dy + rw * (spin_acc ? *spin_acc : 0);
   if (spin_acc) A += rw * rw / Ispin;
   real f;
-  if (g_sweeps > 1 || g_car_sweeps > 1)   /* study modes: accumulated force, PGS increment */
-    f = pgs_step(g_sweeps > 1 ? acc_slot() : facc, -bcoef * slip, sacc, A, (real)SOL_D0, -limit, limit);
+  if (g_sweeps > 1)   /* converged reference: accumulated force, PGS increment */
+    f = pgs_step(acc_slot(), -bcoef * slip, sacc, A, (real)SOL_D0, -limit, limit);
   else f = clampr((real)SOL_D0 * (-bcoef * slip - sacc) / A, -limit, limit);
   r->ax += u[0] * f; r->ay += u[1] * f; r->aw += u[2] * f;
   if (spin_acc) *spin_acc += rw * f / Ispin;
   return f;
 }
 
-/* part 1: inverse inertia, centrifugal term, motor / damping of the spinning parts; part 2: floor friction sweep */
+/* part 1: inverse inertia, centrifugal term, motor / damping of the spinning parts; part 2: the six floor-friction
+ * elements as one plain sweep inside the N-sweep reference mode (sago_set_sweeps; the specification itself solves
+ * them with car_floor_friction below) */
 static void car_smooth(World* w, const real ctrl[2], const Sol* sol, int part) {
   Body* r = &w->robot;
   const CarK k = car_constants();
@@ -975,6 +977,8 @@ static void car_smooth(World* w, const real ctrl[2], const Sol* sol, int part) {
   for (int i = 0; i < 2; i++)
     acc[i] = (clampr(ctrl[i], -(real)CAR_FLIM, (real)CAR_FLIM) - (real)CAR_JDAMP * w->ext[i]) / Iw;
   for (int i = 0; i < 3; i++) acc[2 + i] = -(real)CAR_JDAMP * w->ext[2 + i] / Ib;
+  for (int i = 0; i < 5; i++) w->ext_acc0[i] = acc[i];
+  w->car_fa[0] = w->car_fa[1] = w->car_fa[2] = 0;
   }
   if (!(part & 2)) return;
   /* floor friction: left, right (longitudinal = body y, coupled to the wheel; lateral = body x),
@@ -982,7 +986,6 @@ static void car_smooth(World* w, const real ctrl[2], const Sol* sol, int part) {
   static const real PX[3] = {-0.13, 0.13, 0}, PY[3] = {0.1, 0.1, -0.1};
   real xbx = c, xby = s, ybx = -s, yby = c;
   real facc[6] = {0, 0, 0, 0, 0, 0};
-  for (int sw = 0; sw < (g_sweeps > 1 ? 1 : g_car_sweeps); sw++)
   for (int i = 0; i < 3; i++) {
     real rx = c * PX[i] - s * PY[i], ry = s * PX[i] + c * PY[i];
     real lim = (real)FRICTION_MU * k.N[i];
@@ -997,6 +1000,92 @@ static void car_smooth(World* w, const real ctrl[2], const Sol* sol, int part) {
       car_friction(r, ybx, yby, rx, ry, w->ext[2], &acc[2], (real)CAR_RW, Ib, lim, sol->bcoef, &facc[5]);
     }
   }
+}
+
+/* SPECIFICATION (round 3): the car's floor friction solved to convergence in every forward
+ * evaluation instead of one Gauss-Seidel sweep over six elements.
+ *  - FIVE elements in the body frame, where their Jacobians, M^-1 J^T and J M^-1 J^T are constants: rolling
+ *    direction of the left wheel, the two wheels' LATERAL elements merged, rolling direction of the right wheel,
+ *    caster x, caster y.  (The wheels' lateral elements share Jacobian (body x at y = .1, whatever x), bound and
+ *    reference, so they carry equal forces: one element with bound 2 mu N and regulariser R / 2.  As two rows they
+ *    were the sweep's slow mode - factor d0^2 = .81 per sweep.)
+ *  - start: the direct solve with every element unclamped.  Eliminating f_i = (c_i - J_i a) / D_i from
+ *    J_i a + r_i alpha_i + R_i f_i = aref_i (alpha_i = alpha0_i + r_i f_i / I_i the spin acceleration the element drives,
+ *    c_i = aref_i - r_i alpha0_i, D_i = r_i^2 / I_i + R_i) leaves (M + sum_i J_i^T J_i / D_i) a = M a_other + sum_i J_i^T c_i / D_i,
+ *    a constant 3 x 3 matrix (block diagonal {x, yaw} + {y} by the car's symmetry); forces clamped to +-mu N;
+ *  - then CAR_FRICTION_SWEEPS projected Gauss-Seidel sweeps over the five accumulated forces (exact start when
+ *    nothing clamps; 4 sweeps leave 2e-5 m per env-step against the converged solution, one sweep of the six
+ *    elements left 3e-3: profiles/r03_sweep_convergence.txt);
+ *  - solved before the robot's contacts and, when these changed the base acceleration, once more after them
+ *    (`a_other` then includes the contact forces).
+ * R_i = A_ii (1 - d0) / d0 with A_ii = J_i M^-1 J_i^T + r_i^2 / I_i, bounds mu N_i under the static loads: as before. */
+#define CAR_FRICTION_SWEEPS 4
+static void car_floor_friction(World* w, const Sol* sol) {
+  Body* r = &w->robot;
+  const CarK k = car_constants();
+  const real h = sol->h, c = R_COS(r->yaw), s = R_SIN(r->yaw);
+  const real iIw = 1 / (k.Iw + h * (real)CAR_JDAMP), iIb = 1 / (k.Ib + h * (real)CAR_JDAMP), RF = (1 - (real)SOL_D0) / (real)SOL_D0;
+  /* inertia about the base origin, body axes: [[m, 0, ma], [0, m, 0], [ma, 0, I]] (the COM lies on the body y axis) */
+  const real m = k.m, ma = -k.m * k.oy, I = k.Io;
+  const real idm = 1 / (m * I - ma * ma);
+  const real Mi0 = I * idm, Mi2 = -ma * idm, Mi3 = 1 / m, Mi5 = m * idm;          /* M^-1: xx, xw, yy, ww (xy = yw = 0) */
+  /* element: direction (body x or y), J = (dx, dy, jw), spin lever r_i / inverse spin inertia, bound, R scale */
+  static const int ISX[5] = {0, 1, 0, 1, 0};
+  static const real JW[5] = {-0.13, -0.1, 0.13, 0.1, 0};                          /* rx dy - ry dx */
+  const real rw[5] = {(real)CAR_RW, 0, (real)CAR_RW, (real)CAR_RW, (real)CAR_RW};
+  const real iIs[5] = {iIw, 0, iIw, iIb, iIb};
+  const real lim[5] = {(real)FRICTION_MU * k.N[0], 2 * (real)FRICTION_MU * k.N[0], (real)FRICTION_MU * k.N[1],
+                       (real)FRICTION_MU * k.N[2], (real)FRICTION_MU * k.N[2]};
+  static const real RSC[5] = {1, 0.5, 1, 1, 1};
+  const real rate[5] = {w->ext[0], 0, w->ext[1], -w->ext[3], w->ext[2]};           /* caster x slip <-> -ball_y spin */
+  const real al0[5] = {w->ext_acc0[0], 0, w->ext_acc0[1], -w->ext_acc0[3], w->ext_acc0[2]};
+  real U0[5], U1[5], U2[5], Rr[5], iAR[5], wD[5];
+  for (int i = 0; i < 5; i++) {
+    if (ISX[i]) { U0[i] = Mi0 + Mi2 * JW[i]; U1[i] = 0; U2[i] = Mi2 + Mi5 * JW[i]; }
+    else { U0[i] = Mi2 * JW[i]; U1[i] = Mi3; U2[i] = Mi5 * JW[i]; }
+    const real sp = rw[i] * rw[i] * iIs[i];
+    const real A = (ISX[i] ? U0[i] : U1[i]) + JW[i] * U2[i] + sp;
+    Rr[i] = RSC[i] * A * RF;
+    iAR[i] = 1 / (A + Rr[i]);
+    wD[i] = 1 / (sp + Rr[i]);
+  }
+  const real K00 = m + wD[1] + wD[3], K02 = ma + JW[1] * wD[1] + JW[3] * wD[3], K11 = m + wD[0] + wD[2] + wD[4];
+  const real K22 = I + JW[0] * JW[0] * (wD[0] + wD[2]) + JW[1] * JW[1] * wD[1] + JW[3] * JW[3] * wD[3];
+  const real idk = 1 / (K00 * K22 - K02 * K02);
+  /* base velocity, and the base acceleration from everything but the floor friction, in body axes */
+  const real vbx = c * r->vx + s * r->vy, vby = c * r->vy - s * r->vx;
+  real a0 = c * r->ax + s * r->ay - w->car_fa[0], a1 = c * r->ay - s * r->ax - w->car_fa[1], a2 = r->aw - w->car_fa[2];
+  real aref[5], cc[5];
+  for (int i = 0; i < 5; i++) {
+    const real slip = (ISX[i] ? vbx : vby) + JW[i] * r->w + rw[i] * rate[i];
+    aref[i] = -sol->bcoef * slip;
+    cc[i] = aref[i] - rw[i] * al0[i];
+  }
+  const real b0 = m * a0 + ma * a2 + wD[1] * cc[1] + wD[3] * cc[3];
+  const real b1 = m * a1 + wD[0] * cc[0] + wD[2] * cc[2] + wD[4] * cc[4];
+  real b2 = ma * a0 + I * a2;
+  for (int i = 0; i < 5; i++) b2 += wD[i] * cc[i] * JW[i];
+  const real n0 = (K22 * b0 - K02 * b2) * idk, n1 = b1 / K11, n2 = (K00 * b2 - K02 * b0) * idk;
+  real f[5], al[5], fa0 = 0, fa1 = 0, fa2 = 0;
+  for (int i = 0; i < 5; i++) {
+    f[i] = clampr(wD[i] * (cc[i] - ((ISX[i] ? n0 : n1) + JW[i] * n2)), -lim[i], lim[i]);
+    fa0 += U0[i] * f[i]; fa1 += U1[i] * f[i]; fa2 += U2[i] * f[i];
+    al[i] = al0[i] + rw[i] * f[i] * iIs[i];
+  }
+  for (int sw = 0; sw < CAR_FRICTION_SWEEPS; sw++)
+    for (int i = 0; i < 5; i++) {
+      const real sa = (ISX[i] ? a0 + fa0 : a1 + fa1) + JW[i] * (a2 + fa2) + rw[i] * al[i];
+      const real fn = clampr(f[i] + (aref[i] - sa - Rr[i] * f[i]) * iAR[i], -lim[i], lim[i]);
+      const real df = fn - f[i];
+      f[i] = fn;
+      fa0 += U0[i] * df; fa1 += U1[i] * df; fa2 += U2[i] * df;
+      al[i] += rw[i] * df * iIs[i];
+    }
+  a0 += fa0; a1 += fa1; a2 += fa2;
+  w->car_fa[0] = fa0; w->car_fa[1] = fa1; w->car_fa[2] = fa2;
+  r->ax = c * a0 - s * a1; r->ay = s * a0 + c * a1; r->aw = a2;
+  real* acc = w->ext_acc;
+  acc[0] = al[0]; acc[1] = al[2]; acc[3] = -al[3]; acc[2] = al[4]; acc[4] = w->ext_acc0[4];
 }
 
 static void car_integrate_ext(World* w, real h) {
@@ -1046,7 +1135,11 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
   int cc = 0;
   uint32_t mk = 0;
   if (w->robot_id == SAG_ROBOT_DOGGO) goto free_bodies;
-  if (w->robot_id == SAG_ROBOT_CAR) car_smooth(w, ctrl, sol, 2);
+  real car_pre[3] = {0, 0, 0};
+  if (w->robot_id == SAG_ROBOT_CAR) {
+    if (g_sweeps > 1) car_smooth(w, ctrl, sol, 2);   /* converged reference: the six elements inside the N sweeps */
+    else { car_floor_friction(w, sol); car_pre[0] = w->robot.ax; car_pre[1] = w->robot.ay; car_pre[2] = w->robot.aw; }
+  }
   for (int p = 0; p < w->nP; p++)
     cc += collide_pair(&w->robot, &w->pillar[p], w->r_robot, w->r_pillar, sol, 1);
   for (int b = 0; b < w->nB; b++)
@@ -1072,6 +1165,9 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
     }
     if (w->haul) haul_tendon(w, sol);
   }
+  /* the car's floor friction once more when its contacts (or the tether) changed the base acceleration */
+  if (w->robot_id == SAG_ROBOT_CAR && g_sweeps == 1 &&
+      (w->robot.ax != car_pre[0] || w->robot.ay != car_pre[1] || w->robot.aw != car_pre[2])) car_floor_friction(w, sol);
   if (g_sweep == 0) { cost_contacts = cc; mask = mk; }
 free_bodies:
   for (int k = 0; k < w->nV; k++) {
@@ -1140,7 +1236,10 @@ void sago_substeps(OEnv* e, const real ctrl[2], int nstep, double h) { substeps_
 void sago_doggo_substeps(OEnv* e, const double* ctrl12, int nstep, double h) {
   real c[12];
   for (int k = 0; k < 12; k++) c[k] = (real)ctrl12[k];
+  DgWarm dgws; dgws.n = 0; dgws.evals = 0;
+  g_dgws = &dgws;
   substeps_r(e, c, nstep, h, SAG_ROBOT_DOGGO);
+  g_dgws = NULL;
 }
 /* doggo diagnostics for the analytic tests: total energy; mass matrix [19x19], bias [19], sphere
  * centres [17x3], total mass, contact-free qacc [19] at zero control */
@@ -1546,6 +1645,8 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   /* World.set_mocaps (:71): only CatchGoal acts; uses time BEFORE the step */
   double time = (double)e->i[SAG_I_STEP] * NSTEP[robot] * h;
   if (e->i[SAG_I_TASK] == SAG_TASK_CATCH_GOAL) catch_goal_mocap(e, &g, time);
+  DgWarm dgws; dgws.n = 0; dgws.evals = 0;
+  g_dgws = &dgws;   /* doggo: constraint forces carried from one forward evaluation of this env-step to the next */
   substeps_r(e, ctrl, nstep, h, robot);
   e->i[SAG_I_STEP] += 1;
   if (state_bad_r(e, robot)) { /* PhysicsError branch (:73-75) */
@@ -1554,6 +1655,7 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
     else observe(e, robot, z, out->obs);
     out->reward[0] = -10; out->done = 1; out->cost = 0;
     out->tape_used = g.pos;
+    g_dgws = NULL;
     return;
   }
   /* mj_forward at the final state (:76): contacts + qacc */
@@ -1564,6 +1666,7 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   Sol sol = make_sol(h);
   uint32_t mask = 0;
   int cc = world_forward(&w, e, ctrl, &sol, &mask);
+  g_dgws = NULL;
   if (ext_cost_contacts >= 0) { cc = ext_cost_contacts; mask = ext_btn_mask; }
   out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
   if (robot == SAG_ROBOT_DOGGO) {
@@ -1643,12 +1746,15 @@ void sago_step_batch(OEnv* envs, int n, int robot, const float* actions, uint32_
 }
 
 /* lockstep parity driver: explicit noise / tape per env (either may be NULL), all
- * outputs incl. diagnostics.  Serial. */
+ * outputs incl. diagnostics.  Serial unless sago_set_threads(n > 1) (envs are independent). */
+static int g_full_threads = 1;
+void sago_set_threads(int n) { g_full_threads = n < 1 ? 1 : n; }
 void sago_step_batch_full(OEnv* envs, int n, int robot, const float* actions, const float* noise,
                           const uint32_t* tape, int tape_len, uint32_t key0, uint32_t key1,
                           int nstep, float* obs, float* reward, uint8_t* cost, uint8_t* done,
                           uint8_t* goal_met, int32_t* tape_used, double* cost_margin) {
   int nu = NU[robot], od = OBS_DIM[robot];
+#pragma omp parallel for num_threads(g_full_threads) schedule(dynamic, 4)
   for (int i = 0; i < n; i++) {
     OOut o;
     sago_step(&envs[i], robot, actions + (size_t)i * nu, noise ? noise + (size_t)i * nu : NULL,
