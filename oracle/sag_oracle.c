@@ -601,6 +601,7 @@ typedef struct {
   int nV, nP, nB, box_kind, haul;
   int robot_id;
   real ext[SAG_ROBOT_EXT_FLOATS], ext_acc[5]; /* car: wheel rates L,R; ball rate x,y,z; ball quat w,x,y,z */
+  int act_v[SAG_MAX_VASES], act_box;          /* free bodies that take part in this forward evaluation (see world_forward) */
   real ext_acc0[5], car_fa[3];                /* car: spin accelerations without floor friction; the friction's share of the base acceleration (body axes) */
   void* dg;                                   /* doggo: Doggo* articulated state (sag_oracle_doggo.inc) */
 } World;
@@ -721,12 +722,12 @@ static void box_floor_friction(World* w, const Sol* sol) {
  * Sites are the robot origin (z .1) and the box centre (z .2): length L = sqrt(d^2 + .1^2).
  * Beyond the limit it acts as a soft constraint (default solref/solimp) pulling the two
  * together along the tendon; its planar Jacobian is (d/L) times the unit vector. */
-static void haul_tendon(World* w, const Sol* sol) {
+static int haul_tendon(World* w, const Sol* sol) {
   Body* A = &w->robot; Body* B = &w->box;
   real dx = B->x - A->x, dy = B->y - A->y;
   real d = R_SQRT(dx * dx + dy * dy), L = R_SQRT(d * d + (real)0.01);
   real viol = L - (real)0.75;
-  if (viol <= 0 || d < (real)1e-9) return;
+  if (viol <= 0 || d < (real)1e-9) return 0;
   real jx = dx / L, jy = dy / L; /* d(L)/d(pB) ; d(L)/d(pA) = -j */
   /* rate and acceleration of L along the constraint */
   real Ldot = jx * (B->vx - A->vx) + jy * (B->vy - A->vy);
@@ -739,12 +740,13 @@ static void haul_tendon(World* w, const Sol* sol) {
     real f = pgs_step(acc_slot(), -sol->bcoef * Ldot - sol->kcoef * viol, Lacc, Ainv, dimp, -(real)1e30, 0);
     A->ax -= ua[0] * f; A->ay -= ua[1] * f; A->aw -= ua[2] * f;
     B->ax += ub[0] * f; B->ay += ub[1] * f; B->aw += ub[2] * f;
-    return;
+    return 1;
   }
   real f = dimp * ((-sol->bcoef * Ldot - sol->kcoef * viol) - Lacc) / Ainv;
-  if (f >= 0) return; /* a tendon only pulls */
+  if (f >= 0) return 0; /* a tendon only pulls */
   A->ax -= ua[0] * f; A->ay -= ua[1] * f; A->aw -= ua[2] * f;
   B->ax += ub[0] * f; B->ay += ub[1] * f; B->aw += ub[2] * f;
+  return 1;
 }
 
 static void point_minv(Body* b, real damp, real h) {
@@ -1111,6 +1113,14 @@ static void car_integrate_ext(World* w, real h) {
  *   robot-pillars, robot-buttons, robot-vases, robot-box, haul tendon,
  *   vase-pillars/buttons, box-pillars/buttons, free-body pairs (i<j, lexicographic, the task
  *   object counting as the last body), then floor friction of each vase and of the box.
+ * SLEEPING BODIES (specification; the device kernels skip them): a free body takes part in a forward evaluation
+ * only if it is ACTIVE - it has a non-zero velocity component, or a contact with the robot (or the pull of the
+ * tether) was found in this evaluation, or a contact with an active free body was found in the pair walk.  Its
+ * contacts with the static circles are evaluated only if it is active when that phase starts, a pair of free bodies
+ * only if one of the two is active when the pair walk starts.  A body at rest that nothing active touches therefore
+ * stays exactly at rest, also while it still overlaps another resting body by the depth at which the rest capture
+ * caught it (evaluating such pairs made the two creep apart at ~2e-5 m/s).  The N-sweep reference mode
+ * (sago_set_sweeps) evaluates every pair.
  * Returns robot/obstacle penetration count (cost rule, mujoco_bridge.py:177-191
  * with prefixes consts.OBSTACLES; the box is not an obstacle) and the button contact mask. */
 static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* sol,
@@ -1125,6 +1135,8 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
     w->box.minv[3] = s * s * ix + c * c * iy;
   }
   const int has_box = w->box_kind != SAG_BOX_NONE;
+  for (int k = 0; k < w->nV; k++) w->act_v[k] = g_sweeps > 1 || w->vase[k].vx != 0 || w->vase[k].vy != 0 || w->vase[k].w != 0;
+  w->act_box = has_box && (g_sweeps > 1 || w->box.vx != 0 || w->box.vy != 0 || w->box.w != 0);
   int cost_contacts = 0;
   uint32_t mask = 0;
   /* every robot row of the Doggo (limits, floor, pillars, buttons, vases, box, tether) in one PGS of its own */
@@ -1144,8 +1156,11 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
     cc += collide_pair(&w->robot, &w->pillar[p], w->r_robot, w->r_pillar, sol, 1);
   for (int b = 0; b < w->nB; b++)
     if (collide_pair(&w->robot, &w->button[b], w->r_robot, w->r_button, sol, 1)) mk |= 1u << b;
-  for (int k = 0; k < w->nV; k++)
-    cc += collide_pair(&w->robot, &w->vase[k], w->r_robot, w->r_vase, sol, 1);
+  for (int k = 0; k < w->nV; k++) {
+    const int nc = collide_pair(&w->robot, &w->vase[k], w->r_robot, w->r_vase, sol, 1);
+    cc += nc;
+    if (nc) w->act_v[k] = 1;
+  }
   if (has_box) {
     if (w->box_kind == SAG_BOX_BALL) {
       /* the ball's centre is .04 above the robot sphere's: they touch at horizontal distance
@@ -1154,16 +1169,16 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
       sphere.ngeom = 1; arrow.ngeom = 1; arrow.g[0] = w->robot.g[1];
       Body ball = w->box;
       ball.g[0].a = (real)(0.23664319132398464 - 0.1);
-      collide_pair(&sphere, &ball, w->r_robot, w->r_box, sol, 1);
+      if (collide_pair(&sphere, &ball, w->r_robot, w->r_box, sol, 1)) w->act_box = 1;
       w->robot.ax = sphere.ax; w->robot.ay = sphere.ay; w->robot.aw = sphere.aw;
       w->box.ax = ball.ax; w->box.ay = ball.ay; w->box.aw = ball.aw;
       arrow.ax = sphere.ax; arrow.ay = sphere.ay; arrow.aw = sphere.aw;
-      collide_pair(&arrow, &w->box, w->r_robot, w->r_box, sol, 1);
+      if (collide_pair(&arrow, &w->box, w->r_robot, w->r_box, sol, 1)) w->act_box = 1;
       w->robot.ax = arrow.ax; w->robot.ay = arrow.ay; w->robot.aw = arrow.aw;
     } else {
-      collide_pair(&w->robot, &w->box, w->r_robot, w->r_box, sol, 1);
+      if (collide_pair(&w->robot, &w->box, w->r_robot, w->r_box, sol, 1)) w->act_box = 1;
     }
-    if (w->haul) haul_tendon(w, sol);
+    if (w->haul && haul_tendon(w, sol)) w->act_box = 1;
   }
   /* the car's floor friction once more when its contacts (or the tether) changed the base acceleration */
   if (w->robot_id == SAG_ROBOT_CAR && g_sweeps == 1 &&
@@ -1171,23 +1186,32 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
   if (g_sweep == 0) { cost_contacts = cc; mask = mk; }
 free_bodies:
   for (int k = 0; k < w->nV; k++) {
+    if (!w->act_v[k]) continue;
     for (int p = 0; p < w->nP; p++)
       collide_pair(&w->vase[k], &w->pillar[p], w->r_vase, w->r_pillar, sol, 1);
     for (int b = 0; b < w->nB; b++)
       collide_pair(&w->vase[k], &w->button[b], w->r_vase, w->r_button, sol, 1);
   }
-  if (has_box) {
+  if (w->act_box) {
     for (int p = 0; p < w->nP; p++) collide_pair(&w->box, &w->pillar[p], w->r_box, w->r_pillar, sol, 1);
     for (int b = 0; b < w->nB; b++) collide_pair(&w->box, &w->button[b], w->r_box, w->r_button, sol, 1);
   }
-  /* free body pairs in lexicographic order, the task object being the last body */
-  for (int i = 0; i < w->nV; i++) {
-    for (int j = i + 1; j < w->nV; j++)
-      collide_pair(&w->vase[i], &w->vase[j], w->r_vase, w->r_vase, sol, 1);
-    if (has_box) collide_pair(&w->vase[i], &w->box, w->r_vase, w->r_box, sol, 1);
+  /* free body pairs in lexicographic order, the task object being the last body; which pairs are walked is decided
+   * by who is active NOW (a body woken inside the walk was asleep: its other pairs with sleepers stay skipped) */
+  {
+    int was_v[SAG_MAX_VASES], was_box = w->act_box;
+    for (int k = 0; k < w->nV; k++) was_v[k] = w->act_v[k];
+    for (int i = 0; i < w->nV; i++) {
+      for (int j = i + 1; j < w->nV; j++)
+        if ((was_v[i] || was_v[j]) && collide_pair(&w->vase[i], &w->vase[j], w->r_vase, w->r_vase, sol, 1))
+          w->act_v[i] = w->act_v[j] = 1;
+      if (has_box && (was_v[i] || was_box) && collide_pair(&w->vase[i], &w->box, w->r_vase, w->r_box, sol, 1))
+        w->act_v[i] = w->act_box = 1;
+    }
   }
-  for (int k = 0; k < w->nV; k++) floor_friction(&w->vase[k], w->vase_m, w->vase_I, w->vase_reff, sol);
-  if (has_box) box_floor_friction(w, sol);
+  for (int k = 0; k < w->nV; k++)
+    if (w->act_v[k]) floor_friction(&w->vase[k], w->vase_m, w->vase_I, w->vase_reff, sol);
+  if (w->act_box) box_floor_friction(w, sol);
   }
   g_sweep = 0;
   if (btn_mask) *btn_mask = mask;

@@ -171,7 +171,7 @@ constexpr float CAR_IO =
     2 * CAR_MW * ((3 * 0.0025f + 0.0025f) / 12 + 0.13f * 0.13f + 0.01f) + CAR_MBALL * (0.4f * 0.0025f + 0.01f);
 constexpr float CAR_IW = 0.5f * CAR_MW * 0.0025f + 0.00025f;  // axle inertia + armature (car.xml:22,26)
 constexpr float CAR_IB = 0.4f * CAR_MBALL * 0.0025f;
-constexpr int CAR_FRICTION_SWEEPS = 1;   // Gauss-Seidel sweeps over the six floor-friction elements (the specification: one; see DESIGN.md 4 for what more would buy)
+constexpr int CAR_FRICTION_SWEEPS = 4;   // projected Gauss-Seidel sweeps over the five floor-friction elements after their direct solve (oracle car_floor_friction)
 
 // ---- counter-based generator ------------------------------------------------
 __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -1483,24 +1483,93 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       }
     }
   } else {
-  // Car: 1 / inertia of the spinning parts (joint damping implicit: I + h d) and 1 / (J M^-1 J^T) of the friction
-  // elements (body frame: constants up to the h-dependent spin term), once per step
-  float car_iIw = 0, car_iIb = 0, car_iA_wl = 0, car_iA_wt = 0, car_iA_bx = 0, car_iA_by = 0;
-  float car_R_wl = 0, car_R_wt = 0, car_R_bx = 0, car_R_by = 0;
+  // Car: 1 / inertia of the spinning parts (joint damping implicit: I + h d); per floor-friction element (L / R the
+  // wheels' rolling directions, T their merged lateral element, X / Y the caster's: oracle car_floor_friction) the
+  // regulariser R = A (1 - d0) / d0 of A = J M^-1 J^T + r_w^2 / I_spin, 1 / (A + R), the weight 1 / D = 1 / (r_w^2 / I_spin + R)
+  // of the eliminated element, and the friction-augmented inertia K = M + sum J^T J / D of the direct solve.  Body
+  // frame: constants up to the h-dependent spin terms; once per step
+  float car_iIw = 0, car_iIb = 0, car_iA_L = 0, car_iA_T = 0, car_iA_X = 0, car_iA_Y = 0;
+  float car_R_L = 0, car_R_T = 0, car_R_X = 0, car_R_Y = 0, car_w_L = 0, car_w_T = 0, car_w_X = 0, car_w_Y = 0;
+  float car_K00 = 0, car_K02 = 0, car_K22 = 0, car_idk = 0, car_iK11 = 0;
   if constexpr (CAR) {
     constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CRW = 0.05f, AB = -CM * COY;
     constexpr float IDC = 1.0f / (CM * (CM * CIO - AB * AB));
     constexpr float M0 = (CM * CIO) * IDC, M2 = (-AB * CM) * IDC, M3 = (CM * CIO - AB * AB) * IDC, M5 = (CM * CM) * IDC;
     car_iIw = 1.0f / (CAR_IW + h * 0.001f); car_iIb = 1.0f / (CAR_IB + h * 0.001f);
-    // d = body y at lever (rx, .1): rxd = rx -> A = M3 + M5 rx^2;  d = body x at (rx, ry): rxd = -ry -> A = M0 - 2 M2 ry + M5 ry^2
-    // A of an element, then R = A (1 - d0) / d0 and 1 / (A + R) (named iA below)
-    const float A_wl = M3 + M5 * 0.13f * 0.13f + CRW * CRW * car_iIw, A_wt = M0 - 2 * M2 * 0.1f + M5 * 0.1f * 0.1f;
-    const float A_bx = M0 + 2 * M2 * 0.1f + M5 * 0.1f * 0.1f + CRW * CRW * car_iIb, A_by = M3 + CRW * CRW * car_iIb;
+    const float spw = CRW * CRW * car_iIw, spb = CRW * CRW * car_iIb;
+    // d = body y at lever (rx, .): J = (0, 1, rx) -> A = M3 + M5 rx^2;  d = body x at (., ry): J = (1, 0, -ry) -> A = M0 - 2 M2 ry + M5 ry^2
+    const float A_L = M3 + M5 * 0.13f * 0.13f + spw, A_T = M0 - 2 * M2 * 0.1f + M5 * 0.1f * 0.1f;
+    const float A_X = M0 + 2 * M2 * 0.1f + M5 * 0.1f * 0.1f + spb, A_Y = M3 + spb;
     constexpr float RF = (1.0f - SOL_D0) / SOL_D0;
-    car_R_wl = A_wl * RF; car_R_wt = A_wt * RF; car_R_bx = A_bx * RF; car_R_by = A_by * RF;
-    car_iA_wl = 1.0f / (A_wl + car_R_wl); car_iA_wt = 1.0f / (A_wt + car_R_wt);
-    car_iA_bx = 1.0f / (A_bx + car_R_bx); car_iA_by = 1.0f / (A_by + car_R_by);
+    car_R_L = A_L * RF; car_R_T = 0.5f * A_T * RF; car_R_X = A_X * RF; car_R_Y = A_Y * RF;   // T: two equal elements merged
+    car_iA_L = 1.0f / (A_L + car_R_L); car_iA_T = 1.0f / (A_T + car_R_T);
+    car_iA_X = 1.0f / (A_X + car_R_X); car_iA_Y = 1.0f / (A_Y + car_R_Y);
+    car_w_L = 1.0f / (spw + car_R_L); car_w_T = 1.0f / car_R_T; car_w_X = 1.0f / (spb + car_R_X); car_w_Y = 1.0f / (spb + car_R_Y);
+    car_K00 = CM + car_w_T + car_w_X; car_K02 = AB - 0.1f * car_w_T + 0.1f * car_w_X;
+    car_K22 = CIO + 0.13f * 0.13f * (car_w_L + car_w_L) + 0.1f * 0.1f * car_w_T + 0.1f * 0.1f * car_w_X;
+    car_idk = 1.0f / (car_K00 * car_K22 - car_K02 * car_K02);
+    car_iK11 = 1.0f / (CM + car_w_L + car_w_L + car_w_Y);
   }
+  float car_f0 = 0, car_f1 = 0, car_f2 = 0, car_px = 0, car_py = 0, car_pw = 0;   // friction's share of the base acceleration (body axes); R.a after the first solve
+  // Car floor friction solved to convergence (SPECIFICATION: oracle car_floor_friction): given the base
+  // acceleration (a0, a1, a2) from everything else, in body axes, (1) the direct solve with all five elements
+  // unclamped - eliminating f_i = (c_i - J_i a) / D_i leaves K a = M a_other + sum J_i^T c_i / D_i with the constant
+  // K = M + sum J_i^T J_i / D_i, block diagonal {x, yaw} + {y} - and its forces clamped to their bounds, then (2)
+  // CAR_FRICTION_SWEEPS projected Gauss-Seidel sweeps over the accumulated forces (order L, T, R, X, Y).  Writes R.a
+  // (world axes), the spin accelerations eacc and the friction's share car_f* of the base acceleration.
+  auto car_floor = [&](const float a0, const float a1, const float a2) {
+#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
+    constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CJD = 0.001f, CRW = 0.05f, AB = -CM * COY;
+    constexpr float CNL = CM * GRAV * (0.1f + COY) / 0.4f, CNC = CM * GRAV - 2 * CNL;
+    constexpr float IDC = 1.0f / (CM * (CM * CIO - AB * AB));
+    constexpr float M0 = (CM * CIO) * IDC, M2 = (-AB * CM) * IDC, M3 = (CM * CIO - AB * AB) * IDC, M5 = (CM * CM) * IDC;
+    // M^-1 J^T: rolling elements J = (0, 1, -+.13), lateral (1, 0, -.1), caster x (1, 0, .1), caster y (0, 1, 0)
+    constexpr float UL0 = -0.13f * M2, UL2 = -0.13f * M5, UT0 = M0 - 0.1f * M2, UT2 = M2 - 0.1f * M5, UX0 = M0 + 0.1f * M2, UX2 = M2 + 0.1f * M5;
+    constexpr float LIML = MU * CNL, LIMT = 2 * MU * CNL, LIMC = MU * CNC;
+    const float vbx = cy * R.vx + sy * R.vy, vby = cy * R.vy - sy * R.vx, bc = sol0.bcoef;
+    // spin accelerations without floor friction (caster x couples to -ball_y), reference accelerations -b slip
+    const float qL = (clampf(ctrl0, -0.02f, 0.02f) - CJD * ext[0]) * car_iIw, qR = (clampf(ctrl1, -0.02f, 0.02f) - CJD * ext[1]) * car_iIw;
+    const float qX = CJD * ext[3] * car_iIb, qY = -CJD * ext[2] * car_iIb;
+    const float rL = -bc * (vby - 0.13f * R.w + CRW * ext[0]), rT = -bc * (vbx - 0.1f * R.w), rR = -bc * (vby + 0.13f * R.w + CRW * ext[1]);
+    const float rX = -bc * (vbx + 0.1f * R.w - CRW * ext[3]), rY = -bc * (vby + CRW * ext[2]);
+    const float cL = rL - CRW * qL, cR = rR - CRW * qR, cX = rX - CRW * qX, cY = rY - CRW * qY;
+    const float b0 = CM * a0 + AB * a2 + car_w_T * rT + car_w_X * cX;
+    const float b1 = CM * a1 + car_w_L * cL + car_w_L * cR + car_w_Y * cY;
+    const float b2 = AB * a0 + CIO * a2 + (-0.13f * car_w_L) * cL + (-0.1f * car_w_T) * rT + (0.13f * car_w_L) * cR + (0.1f * car_w_X) * cX;
+    const float n0 = (car_K22 * b0 - car_K02 * b2) * car_idk, n1 = b1 * car_iK11, n2 = (car_K00 * b2 - car_K02 * b0) * car_idk;
+    float fL = clampf(car_w_L * (cL - (n1 - 0.13f * n2)), -LIML, LIML), fT = clampf(car_w_T * (rT - (n0 - 0.1f * n2)), -LIMT, LIMT);
+    float fR = clampf(car_w_L * (cR - (n1 + 0.13f * n2)), -LIML, LIML), fX = clampf(car_w_X * (cX - (n0 + 0.1f * n2)), -LIMC, LIMC);
+    float fY = clampf(car_w_Y * (cY - n1), -LIMC, LIMC);
+    float g0 = UL0 * fL + UT0 * fT - UL0 * fR + UX0 * fX, g1 = M3 * fL + M3 * fR + M3 * fY, g2 = UL2 * fL + UT2 * fT - UL2 * fR + UX2 * fX;
+    float sL = qL + CRW * fL * car_iIw, sR = qR + CRW * fR * car_iIw, sX = qX + CRW * fX * car_iIb, sY = qY + CRW * fY * car_iIb;
+#pragma unroll
+    for (int sw = 0; sw < CAR_FRICTION_SWEEPS; sw++) {
+      {
+        const float sa = (a1 + g1) - 0.13f * (a2 + g2) + CRW * sL, fn = clampf(fL + (rL - sa - car_R_L * fL) * car_iA_L, -LIML, LIML), df = fn - fL;
+        fL = fn; g0 += UL0 * df; g1 += M3 * df; g2 += UL2 * df; sL += CRW * df * car_iIw;
+      }
+      {
+        const float sa = (a0 + g0) - 0.1f * (a2 + g2), fn = clampf(fT + (rT - sa - car_R_T * fT) * car_iA_T, -LIMT, LIMT), df = fn - fT;
+        fT = fn; g0 += UT0 * df; g2 += UT2 * df;
+      }
+      {
+        const float sa = (a1 + g1) + 0.13f * (a2 + g2) + CRW * sR, fn = clampf(fR + (rR - sa - car_R_L * fR) * car_iA_L, -LIML, LIML), df = fn - fR;
+        fR = fn; g0 -= UL0 * df; g1 += M3 * df; g2 -= UL2 * df; sR += CRW * df * car_iIw;
+      }
+      {
+        const float sa = (a0 + g0) + 0.1f * (a2 + g2) + CRW * sX, fn = clampf(fX + (rX - sa - car_R_X * fX) * car_iA_X, -LIMC, LIMC), df = fn - fX;
+        fX = fn; g0 += UX0 * df; g2 += UX2 * df; sX += CRW * df * car_iIb;
+      }
+      {
+        const float sa = (a1 + g1) + CRW * sY, fn = clampf(fY + (rY - sa - car_R_Y * fY) * car_iA_Y, -LIMC, LIMC), df = fn - fY;
+        fY = fn; g1 += M3 * df; sY += CRW * df * car_iIb;
+      }
+    }
+    car_f0 = g0; car_f1 = g1; car_f2 = g2;
+    const float t0 = a0 + g0, t1 = a1 + g1;
+    R.ax = cy * t0 - sy * t1; R.ay = sy * t0 + cy * t1; R.aw = a2 + g2;
+    eacc[0] = sL; eacc[1] = sR; eacc[2] = sY; eacc[3] = -sX; eacc[4] = -CJD * ext[4] * car_iIb;
+  };
   // Point: what does not change over the substeps - the inverse inertia's determinant (a^2 + b^2 = mc^2 for any
   // heading), its yaw element, the yaw servo's denominator, the drive force - leaves the loop with its two divisions
   float pt_mIz = 0, pt_id = 0, pt_mid = 0, pt_m5 = 0, pt_iw = 0, pt_c1 = 0, pt_f0 = 0;
@@ -1551,15 +1620,10 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 #pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
       // Car (car.xml; DESIGN.md "Car"): planar base with COM offset, two driven wheels and a
       // rear ball; floor contact = regularised Coulomb friction at the three contact points.
-      // Evaluated in the BODY frame: there the generalised inverse inertia, the six friction directions (body x
-      // and y at the two wheels and the ball) and their levers are constants, so M^-1 J^T and J M^-1 J^T of every
-      // friction element fold at compile time (the world-frame form of the specification spends ~45 instructions
-      // per element on them; this one ~14).  Same sequential sweep: left, right, caster.
-      constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CJD = 0.001f, CRW = 0.05f;
-      constexpr float CNL = CM * GRAV * (0.1f + COY) / 0.4f, CNC = CM * GRAV - 2 * CNL;
-      constexpr float AB = -CM * COY;                                  // body frame: a = -m oy, b = m ox = 0
-      constexpr float IDC = 1.0f / (CM * (CM * CIO - AB * AB));
-      constexpr float M0 = (CM * CIO) * IDC, M2 = (-AB * CM) * IDC, M3 = (CM * CIO - AB * AB) * IDC, M5 = (CM * CM) * IDC;
+      // Evaluated in the BODY frame: there the generalised inverse inertia, the friction directions (body x and y at
+      // the two wheels and the ball) and their levers are constants, so M^-1 J^T and J M^-1 J^T of every friction
+      // element fold at compile time: car_floor above.
+      constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY;
       if constexpr (!QUIET) {
         // contacts of the footprint use the world-frame inverse inertia
         const float ox = -sy * COY, oy = cy * COY;
@@ -1568,51 +1632,15 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         R.m0 = (CM * CIO - b * b) * id; R.m1 = (a * b) * id; R.m2 = (-a * CM) * id;
         R.m3 = (CM * CIO - a * a) * id; R.m4 = (-b * CM) * id; R.m5 = (CM * CM) * id;
       }
-      const float vbx = cy * R.vx + sy * R.vy, vby = cy * R.vy - sy * R.vx;
-      float abx = 0.f, aby = R.w * R.w * COY, aw = 0.f;             // M^-1 (centrifugal force of the offset COM)
-      eacc[0] = (clampf(ctrl0, -0.02f, 0.02f) - CJD * ext[0]) * car_iIw;
-      eacc[1] = (clampf(ctrl1, -0.02f, 0.02f) - CJD * ext[1]) * car_iIw;
-      eacc[2] = -CJD * ext[2] * car_iIb; eacc[3] = -CJD * ext[3] * car_iIb; eacc[4] = -CJD * ext[4] * car_iIb;
-      // one friction direction (dx, dy) in {body x, body y} at the constant lever (rx, ry), optionally coupled to a
-      // spinning part: projected Gauss-Seidel update of its accumulated force,
-      //   f <- clamp(f + (-b slip - a - R f) / (A + R)),  A = J M^-1 J^T [+ r_w^2 / I_spin],  R = A (1 - d0) / d0,
-      // with iAR = 1 / (A + R) = d0 / A and Rr = R from before the substep loop.  The six elements couple through
-      // the rigid base; CAR_FRICTION_SWEEPS sweeps (one leaves 10 % of a step's motion unresolved against the
-      // converged solution, two 2 %: profiles/r02_sweep_convergence.txt; oracle car_smooth)
-      auto fricb = [&](const float dx, const float dy, const float rx, const float ry, float rate, float* sacc,
-                       float iIsp, float iAR, float Rr, float lim, float& facc) {
-#pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
-        const float rxd = rx * dy - ry * dx;
-        const float u0 = M0 * dx + M2 * rxd, u1 = M3 * dy, u2 = M2 * dx + M5 * rxd;
-        const float slip = (vbx - R.w * ry) * dx + (vby + R.w * rx) * dy + (sacc ? CRW * rate : 0.f);
-        const float sa = (abx - aw * ry) * dx + (aby + aw * rx) * dy + (sacc ? CRW * *sacc : 0.f);
-        const float fn = clampf(facc + (-sol0.bcoef * slip - sa - Rr * facc) * iAR, -lim, lim);
-        const float f = fn - facc;
-        facc = fn;
-        abx += u0 * f; aby += u1 * f; aw += u2 * f;
-        if (sacc) *sacc += CRW * f * iIsp;
-      };
-      float fa0 = 0, fa1 = 0, fa2 = 0, fa3 = 0, fa4 = 0, fa5 = 0;
-#pragma unroll
-      for (int sw = 0; sw < CAR_FRICTION_SWEEPS; sw++) {
-        fricb(0.f, 1.f, -0.13f, 0.1f, ext[0], &eacc[0], car_iIw, car_iA_wl, car_R_wl, MU * CNL, fa0);   // left wheel: rolling direction
-        fricb(1.f, 0.f, -0.13f, 0.1f, 0.f, nullptr, 0.f, car_iA_wt, car_R_wt, MU * CNL, fa1);          //             lateral
-        fricb(0.f, 1.f, 0.13f, 0.1f, ext[1], &eacc[1], car_iIw, car_iA_wl, car_R_wl, MU * CNL, fa2);    // right wheel
-        fricb(1.f, 0.f, 0.13f, 0.1f, 0.f, nullptr, 0.f, car_iA_wt, car_R_wt, MU * CNL, fa3);
-        float syacc = -eacc[3];                                                                           // rear ball (0, -.1)
-        fricb(1.f, 0.f, 0.f, -0.1f, -ext[3], &syacc, car_iIb, car_iA_bx, car_R_bx, MU * CNC, fa4);      // x slip <-> -ball_y
-        eacc[3] = -syacc;
-        fricb(0.f, 1.f, 0.f, -0.1f, ext[2], &eacc[2], car_iIb, car_iA_by, car_R_by, MU * CNC, fa5);     // y slip <-> +ball_x
-      }
-      R.ax = cy * abx - sy * aby; R.ay = sy * abx + cy * aby; R.aw = aw;
+      car_floor(0.f, R.w * R.w * COY, 0.f);   // M^-1 (centrifugal force of the offset COM) in body axes
+      car_px = R.ax; car_py = R.ay; car_pw = R.aw;
     }
     CYC(CY_ROBOT);
     cost_contacts = 0; btn_mask = 0;
     if constexpr (!QUIET) {
     // `active` = bodies that can have a non-zero acceleration or velocity this substep.
-    // A sleeping body (v = 0, untouched) overlaps nothing, so every pair test it would take
-    // part in is a no-op and is skipped; the pair ORDER of the specification is kept for the
-    // pairs that run (oracle world_forward tests all of them).
+    // A sleeping body (v = 0, untouched) takes no part: the specification's rule (oracle world_forward, "sleeping
+    // bodies"), which the oracle applies pair by pair in the same order.
     uint32_t active = awake;
     for (uint32_t m = active; m; m &= m - 1) dy.set_acc(__ffs(m) - 1, 0, 0, 0);
     // robot vs static circles (pillars, then buttons)
@@ -1679,6 +1707,12 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         }
       }
     }
+    if constexpr (CAR) {
+      // the floor friction once more when the contacts (or the tether) changed the base acceleration: what they
+      // added now belongs to `everything else`
+      if (R.ax != car_px || R.ay != car_py || R.aw != car_pw)
+        car_floor(cy * R.ax + sy * R.ay - car_f0, cy * R.ay - sy * R.ax - car_f1, R.aw - car_f2);
+    }
     CYC(CY_RV);
     if (sub == nsub) break;  // final forward: robot acceleration + contact flags only
     if (active && !ABL(ABL_NO_ACTIVE)) {
@@ -1716,8 +1750,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       // wavefront instead of the 55 a union over "for a: for b > a" costs once the lanes' active
       // indices differ.  Hits go into a 55-bit pair mask (bit = a (21 - a) / 2 + b - a - 1), walked
       // in ascending order = the specification's pair order.  A body that only becomes active inside
-      // this loop was asleep, i.e. overlapped no other sleeping body, so its remaining pairs with
-      // sleeping bodies are no-ops and need no test.
+      // this loop was asleep: by the specification its other pairs with sleeping bodies stay skipped.
       uint64_t pairs = 0;
       if (!ABL(ABL_NO_VV)) {
         for (uint32_t m = active; m; m &= m - 1) {
@@ -2519,36 +2552,17 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
   const float* rf = rec_f + (size_t)j * SAG_REC_FLOATS;
   const int32_t* ri = rec_i + (size_t)j * SAG_REC_INTS;
   for (int k = 0; k < SAG_REC_FLOATS; k++) S[saddr(k, (size_t)N, (size_t)i)] = rf[k];
-  // derived word: which free bodies must be looked at (moving, or possibly overlapping something,
-  // in which case the first substeps resolve it); the others are asleep and are skipped
+  // derived word: which free bodies are awake = have a non-zero velocity component.  (SPECIFICATION, oracle
+  // world_forward "sleeping bodies": a resting body takes part in a forward evaluation only once something active
+  // touches it - also when it was installed overlapping another resting body, e.g. the HaulBox box spawned over a
+  // vase: the pair is resolved when the tether first pulls the box.)
   uint32_t awake = 0;
   {
-    const int nV = ri[SAG_I_NV], nP = ri[SAG_I_NP], nB = ri[SAG_I_NB], bkind = ri[SAG_I_BOX_KIND];
-    const float vr = rf[SAG_F_VASE_SIZE] * 1.41421356237309504880f;
-    const float br = bkind == SAG_BOX_BOX ? 0.42426406871192851f : (bkind == SAG_BOX_ROD ? 0.31048349392520047f : 0.14f);
-    const int nb = NBODY;
-    for (int a = 0; a < nb; a++) {
+    const int nV = ri[SAG_I_NV], bkind = ri[SAG_I_BOX_KIND];
+    for (int a = 0; a < NBODY; a++) {
       if (a < SAG_MAX_VASES ? a >= nV : bkind == SAG_BOX_NONE) continue;
       const float* va = a < SAG_MAX_VASES ? rf + SAG_F_VASES + 6 * a : rf + SAG_F_BOX;
-      const float ra = a < SAG_MAX_VASES ? vr : br;
       if (va[3] != 0 || va[4] != 0 || va[5] != 0) awake |= 1u << a;
-      for (int b = a + 1; b < nb; b++) {
-        if (b < SAG_MAX_VASES ? b >= nV : bkind == SAG_BOX_NONE) continue;
-        const float* vb = b < SAG_MAX_VASES ? rf + SAG_F_VASES + 6 * b : rf + SAG_F_BOX;
-        const float rs = ra + (b < SAG_MAX_VASES ? vr : br);
-        const float dx = va[0] - vb[0], dy = va[1] - vb[1];
-        if (dx * dx + dy * dy <= rs * rs) awake |= 1u << a | 1u << b;
-      }
-      for (int q = 0; q < nP; q++) {
-        const float dx = va[0] - rf[SAG_F_PILLARS + 2 * q], dy = va[1] - rf[SAG_F_PILLARS + 2 * q + 1];
-        const float rs = ra + rf[SAG_F_PILLAR_SIZE];
-        if (dx * dx + dy * dy <= rs * rs) awake |= 1u << a;
-      }
-      for (int q = 0; q < nB; q++) {
-        const float dx = va[0] - rf[SAG_F_BUTTONS + 2 * q], dy = va[1] - rf[SAG_F_BUTTONS + 2 * q + 1];
-        const float rs = ra + BUTTON_R;
-        if (dx * dx + dy * dy <= rs * rs) awake |= 1u << a;
-      }
     }
   }
   I[iaddr(DI_META, (size_t)N, (size_t)i)] = (int32_t)pack_meta(ri);
