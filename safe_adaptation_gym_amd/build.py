@@ -8,10 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsag.so')
-SOURCES = ['sag_api.hip', 'sag_doggo_lane.hip', 'sag_sampler.cpp']
-# per-source extra flags.  sag_doggo_lane.hip: SGPR spills go to scratch memory, not to VGPR lanes - its one big
-# device function was miscompiled on that path (see the file header and DESIGN.md 3.4)
-EXTRA = {'sag_doggo_lane.hip': ['-mllvm', '-amdgpu-spill-sgpr-to-vgpr=false']}
+SOURCES = ['sag_api.hip', 'sag_sampler.cpp']
+EXTRA = {}   # per-source extra flags
 # every header under csrc/ (sag_device.hpp includes the Doggo, cooperative-Doggo and render headers) + the ABI
 HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, '*.hpp'))) + [
     os.path.join('..', '..', 'include', 'sag.h')]

@@ -27,11 +27,6 @@
 
 using namespace sag;
 
-namespace sag {  // sag_doggo_lane.hip: the lane-per-env Doggo kernel lives in its own translation unit
-hipError_t doggo_lane_upload_model(const DgModel* m);
-void doggo_lane_launch(const StepArgs& a, int blocks, hipStream_t stream);
-}
-
 namespace {
 
 struct RobotInfo { int nu, obs_dim, nstep, nq, nv; double dt; };
@@ -101,11 +96,7 @@ struct sag_ctx {
   int phase_used = 0;  // (the phase of the launch being built)
   int n_cu = 256;      // compute units of the device
   uint8_t* d_rgb = nullptr; size_t rgb_bytes = 0;  // [N][H][W][3] staging of sag_render, grown on demand
-  double* d_dr = nullptr;    // Doggo cooperative form: per-env result block of the physics kernel
-  // Doggo: the wave-cooperative physics kernel (2 envs per wavefront, 4 wavefronts per CU) at every batch size - 3.4 ms
-  // at 4096 envs, 2.15e6 env-steps/s at 131072 against 1.04e6 of the lane-per-env kernel, which stays as the
-  // second implementation the tests cross-check (SAG_DOGGO_COOP=0 selects it).
-  bool doggo_coop = false;
+  double* d_dr = nullptr;    // Doggo: per-env result block of the physics kernel (k_doggo_physics: 2 envs per wavefront)
   int epw_override = 0;  // SAG_EPW (read once at create): envs per wavefront of the single-launch form
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
@@ -389,13 +380,11 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   else if (c->cfg.robot == SAG_ROBOT_CAR) SAG_LAUNCH(SAG_ROBOT_CAR);
 #endif
   else if (c->cfg.robot != SAG_ROBOT_DOGGO) return fail(c, SAG_ERR_UNSUPPORTED, "this build holds the step kernels of robot %d only", SAG_ONLY_ROBOT);
-  else if (c->doggo_coop) {
-    // Doggo, wave-cooperative physics (32 lanes per env) + the generic step without physics
+  else {
+    // Doggo: wave-cooperative physics (32 lanes per env) + the generic step without physics
     a.DR = c->d_dr;
     hipLaunchKernelGGL(k_doggo_physics, dim3((c->N + DC_EPW - 1) / DC_EPW), dim3(32 * DC_EPW), 0, c->stream, a, c->d_dr);
     hipLaunchKernelGGL((k_step_doggo_post<true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
-  } else {  // Doggo, lane-per-env form: one (buttons + task object) instance, single launch
-    doggo_lane_launch(a, (c->N + a.envs_per_wave - 1) / a.envs_per_wave, c->stream);
   }
 #undef SAG_LAUNCH
 #undef SAG_LAUNCH3
@@ -488,8 +477,6 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
   if (const char* e = getenv("SAG_HOT")) c->use_hot = atoi(e) != 0;
   if (const char* e = getenv("SAG_EPW")) c->epw_override = atoi(e);
-  c->doggo_coop = cfg->robot == SAG_ROBOT_DOGGO;
-  if (const char* e = getenv("SAG_DOGGO_COOP")) c->doggo_coop = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -515,12 +502,11 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->d_used, N * sizeof(int32_t)));
   if (c->split && c->use_hot && cfg->robot != SAG_ROBOT_DOGGO)
     CREATE_CHK(hipMalloc(&c->d_hot, N * (HOT_FLOATS + 20) * sizeof(float)));
-  if (c->doggo_coop) CREATE_CHK(hipMalloc(&c->d_dr, N * DR_STRIDE * sizeof(double)));
+  if (cfg->robot == SAG_ROBOT_DOGGO) CREATE_CHK(hipMalloc(&c->d_dr, N * DR_STRIDE * sizeof(double)));
   if (cfg->robot == SAG_ROBOT_DOGGO) {
     DgModel model;
     dg_build_model(model);
     CREATE_CHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dg), &model, sizeof(model)));
-    CREATE_CHK(doggo_lane_upload_model(&model));
   }
   CREATE_CHK(hipMemsetAsync(c->d_cost, 0, N, c->stream));
   CREATE_CHK(hipMemsetAsync(c->d_obs, 0, N * c->rb.obs_dim * sizeof(float), c->stream));

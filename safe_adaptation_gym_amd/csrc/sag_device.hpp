@@ -903,32 +903,15 @@ __device__ inline void lidar_point_tilted(float* lds, int lane, const double* po
 }
 
 // ---------------------------------------------------------------------------
-// Doggo: the substep loop (specification: oracle/sag_oracle_doggo.inc + world_forward order).
-// Robot rows (joint limits, floor, pillars, buttons, vases, task object, HaulBox tether) go through
-// one projected Gauss-Seidel in fp64; the planar free bodies keep the fp32 arithmetic and the pair
-// order of the Point/Car kernels, without the sleeping-body shortcut (every body is processed; a
-// resting body is a fixed point of the update, so the result is the same).
+// Doggo: the physics is k_doggo_physics (sag_doggo_coop.hpp: specification oracle/sag_oracle_doggo.inc +
+// world_forward order); the generic step post-processes its per-env result block (DgResult).
 // ---------------------------------------------------------------------------
-#ifndef SAG_DG_CONST_R
-#define SAG_DG_CONST_R false   // cull of the planar pair tests inside doggo_physics
-#endif
 struct DgResult {
   double qacc_lin[3], touch[8], comvel[4];
   int cost_contacts;
   uint32_t btn_mask;
   int overflow;   // a constraint row did not fit into DG_MAXROWS during this step
 };
-
-#ifdef SAG_DOGGO_LANE_TU
-__device__ inline void dg_body_view(const DgWorld& Wd, int k, BV& V, float& c, float& s) {
-  const float* B = Wd.fb[k];
-  V.x = B[0]; V.y = B[1]; V.vx = B[3]; V.vy = B[4]; V.w = B[5]; V.ax = B[6]; V.ay = B[7]; V.aw = B[8];
-  sincosf(B[2], &s, &c);
-  const float* m = Wd.minv[k];
-  V.m0 = m[0]; V.m1 = m[1]; V.m2 = m[2]; V.m3 = m[3]; V.m4 = m[4]; V.m5 = m[5]; V.dyn = 1;
-}
-
-#endif  // SAG_DOGGO_LANE_TU
 
 // floor friction + semi-implicit Euler + rest capture of one planar free body (the block of
 // step_body, on the [x y yaw vx vy w ax ay aw] layout)
@@ -973,203 +956,6 @@ __device__ __attribute__((noinline)) void dg_free_body_finish(float* B, bool is_
   B[0] += h * vx_; B[1] += h * vy_; B[2] += h * w_;
 }
 
-#ifdef SAG_DOGGO_LANE_TU
-__device__ __attribute__((noinline)) void doggo_physics(
-    DgState& D, DgWorld& Wd, DgResult& out, lds_f64* dgL, const float* ctrl12, int nsub, float hf, const float* stx,
-    const float* sty, int nP, int nB, float psz, float vsz, const BodyK& vk, const BodyK& bk, const Sol& sol0,
-    const Sol& solb, int nV, bool has_box, bool haul) {
-  DgWork K;
-  DgRows R;
-  K.L = dgL; K.xs = dgL + DG_NTRI * WAVE; K.dinv = K.xs + 3 * DG_NV * WAVE;
-  const DgModel& M = g_dg;
-  const double h = (double)hf;
-#ifdef SAG_CYCLES
-  unsigned long long dcy[12] = {}, dct = __builtin_readcyclecounter();
-#define DCY(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); dcy[k] += t_ - dct; dct = t_; } while (0)
-#else
-#define DCY(k) do {} while (0)
-#endif
-  const float vase_r = vk.reff, box_r = shape_bound(bk.sh, vsz, 0);
-  const double top_vase = 2.0 * (double)vsz;
-  const double top_box = bk.sh == SH_ROD ? 0.16 : (bk.sh == SH_BALL ? 0.28 : 0.4);
-  out.cost_contacts = 0; out.btn_mask = 0; out.overflow = 0;
-  R.overflow = 0;
-#pragma unroll 1
-  for (int sub = 0; sub <= nsub; sub++) {
-    for (int k = 0; k < NBODY; k++) { Wd.fb[k][6] = 0; Wd.fb[k][7] = 0; Wd.fb[k][8] = 0; }
-    if (has_box && bk.sh == SH_ROD) {
-      float c, s; sincosf(Wd.fb[BOX_ID][2], &s, &c);
-      const float ix = 1.0f / (1.5f * bk.m), iy = 1.0f / bk.m;
-      Wd.minv[BOX_ID][0] = c * c * ix + s * s * iy; Wd.minv[BOX_ID][1] = c * s * (ix - iy);
-      Wd.minv[BOX_ID][3] = s * s * ix + c * c * iy;
-    }
-    // ---- robot: smooth dynamics -----------------------------------------------------
-    double bias[DG_NV], tau[DG_NV], qd[DG_NV];
-    DCY(7);
-    dg_kinematics(D, K);
-    DCY(0);
-    dg_mass_matrix(K);
-    DCY(1);
-    dg_bias(D, K, bias);
-    DCY(2);
-    dg_qd(D, qd);
-    for (int k = 0; k < DG_NV; k++) tau[k] = 0;
-    for (int j = 0; j < DG_NJ; j++) tau[6 + j] = -DG_STIFF * (D.q[j] - M.springref[j]);
-    for (int k = 0; k < 12; k++) tau[6 + M.act_joint[k]] += DG_GEAR * (double)ctrl12[k];
-    for (int k = 0; k < DG_NV; k++) tau[k] -= bias[k];
-    if (!dg_cholesky(K.L, K.dinv)) {  // not positive definite: the state is already broken (PhysicsError)
-      D.pos[0] = __longlong_as_double(0x7ff8000000000000ll);
-      break;
-    }
-    for (int k = 0; k < DG_NV; k++) K.xs[k * 64] = tau[k];
-    dg_solve_lds<1>(K.L, K.dinv, K.xs);
-    for (int k = 0; k < DG_NV; k++) K.qacc[k] = K.xs[k * 64];
-    DCY(3);
-    for (int k = 0; k < 8; k++) K.touch[k] = 0;
-    R.n = 0;
-    // ---- rows: joint limits, floor, pillars, buttons, vases, task object, tether ----
-    // each lane walks ITS OWN list of violated limits / touching spheres (ascending index = the
-    // specification's row order): the wavefront iterates max-count times, not once per index that
-    // any of its 64 envs needs
-    uint32_t lim_mask = 0;
-    for (int j = 0; j < DG_NJ; j++)
-      if (D.q[j] < M.lo[j] || D.q[j] > M.hi[j]) lim_mask |= 1u << j;
-#pragma unroll 1
-    for (uint32_t lm = lim_mask; lm; lm &= lm - 1) {
-      const int j = __ffs(lm) - 1;
-      double depth = 0, sign = 0;
-      if (D.q[j] < M.lo[j]) { depth = M.lo[j] - D.q[j]; sign = 1; }
-      else if (D.q[j] > M.hi[j]) { depth = D.q[j] - M.hi[j]; sign = -1; }
-      double J[DG_NV];
-      for (int k = 0; k < DG_NV; k++) J[k] = 0;
-      J[6 + j] = 1;
-      DgRow* r = dg_add_row1(R, K, Wd, J, sign, -1, 0, 0, 0, 0);
-      if (!r) break;
-      r->imp = dg_impedance(depth);
-      r->aref = -(double)sol0.bcoef * dg_row_vel(*r, Wd, qd) + (double)sol0.kcoef * depth;
-    }
-    DCY(8);
-    uint32_t floor_mask = 0;
-    for (int s = 0; s < DG_NS; s++)
-      if (M.sph_r[s] - K.sph[s][2] > 0) floor_mask |= 1u << s;
-#pragma unroll 1
-    for (uint32_t fm = floor_mask; fm; fm &= fm - 1) {
-      const int s = __ffs(fm) - 1;
-      const double depth = M.sph_r[s] - K.sph[s][2];
-      const double n[3] = {0, 0, 1}, c[3] = {K.sph[s][0], K.sph[s][1], 0.5 * (K.sph[s][2] - M.sph_r[s])};
-      dg_add_contact(R, D, K, Wd, qd, s, n, c, depth, -1, (double)sol0.bcoef, (double)sol0.kcoef, (double)MU);
-    }
-    DCY(9);
-    int cc = 0;
-    uint32_t mask = 0;
-    // every sphere centre lies within .52 m of the base origin (hip offset .224 + hip link .124 +
-    // shin .168): bodies farther than that plus the radii cannot touch and are skipped outright
-    auto near = [&](float bx, float by, float rb) {
-      const double dx = (double)bx - D.pos[0], dy = (double)by - D.pos[1], rs = 0.6 + (double)rb;
-      return dx * dx + dy * dy <= rs * rs;
-    };
-#pragma unroll 1
-    for (int q = 0; q < nP; q++)
-      if (near(stx[q], sty[q], psz))
-      cc += dg_collide_body(R, D, K, Wd, qd, -1, SH_STATIC, stx[q], sty[q], 0.f, psz, vsz, psz, 1.0,
-                            (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu);
-#pragma unroll 1
-    for (int b = 0; b < nB; b++)
-      if (near(stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], BUTTON_R) &&
-          dg_collide_body(R, D, K, Wd, qd, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f,
-                          BUTTON_R, vsz, BUTTON_R, 0.2, (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu))
-        mask |= 1u << b;
-#pragma unroll 1
-    for (int k = 0; k < nV; k++)
-      if (near(Wd.fb[k][0], Wd.fb[k][1], vase_r))
-      cc += dg_collide_body(R, D, K, Wd, qd, k, SH_VASE, Wd.fb[k][0], Wd.fb[k][1], Wd.fb[k][2], vase_r, vsz, 0.f,
-                            top_vase, (double)sol0.bcoef, (double)sol0.kcoef, (double)sol0.mu);
-    if (has_box) {
-      if (near(Wd.fb[BOX_ID][0], Wd.fb[BOX_ID][1], box_r))
-      dg_collide_body(R, D, K, Wd, qd, BOX_ID, bk.sh, Wd.fb[BOX_ID][0], Wd.fb[BOX_ID][1], Wd.fb[BOX_ID][2], box_r,
-                      vsz, 0.f, top_box, (double)solb.bcoef, (double)solb.kcoef, (double)solb.mu);
-      if (haul) {  // haul_box.py:21-29: tendon base site <-> box site (z .2), range [0, .75]
-        const double dx = (double)Wd.fb[BOX_ID][0] - D.pos[0], dy = (double)Wd.fb[BOX_ID][1] - D.pos[1], dz = 0.2 - D.pos[2];
-        const double d2 = dx * dx + dy * dy, Lt = sqrt(d2 + dz * dz), viol = Lt - 0.75;
-        if (viol > 0 && d2 >= 1e-18) {
-          const double j[3] = {dx / Lt, dy / Lt, dz / Lt};
-          double J[DG_NV];
-          dg_jac(D, K, 0, D.pos, j, J);
-          DgRow* r = dg_add_row1(R, K, Wd, J, 1.0, BOX_ID, -j[0], -j[1], (double)Wd.fb[BOX_ID][0], (double)Wd.fb[BOX_ID][1]);
-          if (r) {
-            r->imp = dg_impedance(viol);
-            r->aref = -(double)sol0.bcoef * dg_row_vel(*r, Wd, qd) + (double)sol0.kcoef * viol;
-          }
-        }
-      }
-    }
-    DCY(4);
-    dg_pgs(R, K, Wd);
-    DCY(5);
-    for (int k = 0; k < R.n; k++)
-      if (R.row[k].touch >= 0 && R.row[k].parent < 0) K.touch[R.row[k].touch] += R.row[k].f;
-    out.cost_contacts = cc; out.btn_mask = mask;
-    if (sub == nsub) break;
-    // ---- planar world: free bodies vs statics, free-body pairs, friction, integration ----
-#pragma unroll 1
-    for (int k = 0; k < NBODY; k++) {
-      const bool isb = k == BOX_ID;
-      if (isb ? !has_box : k >= nV) continue;
-      const float br = isb ? box_r : vase_r;
-#pragma unroll 1
-      for (int q = 0; q < SAG_MAX_PILLARS + nB; q++) {
-        if (q == nP && q < SAG_MAX_PILLARS) q = SAG_MAX_PILLARS;
-        if (q >= SAG_MAX_PILLARS + nB) break;
-        const bool is_p = q < SAG_MAX_PILLARS;
-        const float sr = is_p ? psz : BUTTON_R;
-        const float dx = stx[q] - Wd.fb[k][0], dyy = sty[q] - Wd.fb[k][1], rs = br + sr;
-        if (dx * dx + dyy * dyy > rs * rs) continue;
-        BV V; float cv, sv; dg_body_view(Wd, k, V, cv, sv);
-        BV St; St.x = stx[q]; St.y = sty[q]; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
-        St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
-        collide_shapes<SAG_DG_CONST_R>(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
-        Wd.fb[k][6] = V.ax; Wd.fb[k][7] = V.ay; Wd.fb[k][8] = V.aw;
-      }
-    }
-#pragma unroll 1
-    for (int a = 0; a < nV; a++)
-#pragma unroll 1
-      for (int b = a + 1; b < NBODY; b++) {
-        const bool isb = b == BOX_ID;
-        if (isb ? !has_box : b >= nV) continue;
-        const float dx = Wd.fb[b][0] - Wd.fb[a][0], dyy = Wd.fb[b][1] - Wd.fb[a][1], rs = vase_r + (isb ? box_r : vase_r);
-        if (dx * dx + dyy * dyy > rs * rs) continue;
-        BV A, B; float ca, sa, cb, sb;
-        dg_body_view(Wd, a, A, ca, sa);
-        dg_body_view(Wd, b, B, cb, sb);
-        if (collide_shapes<SAG_DG_CONST_R>(A, SH_VASE, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0)) {
-          Wd.fb[a][6] = A.ax; Wd.fb[a][7] = A.ay; Wd.fb[a][8] = A.aw;
-          Wd.fb[b][6] = B.ax; Wd.fb[b][7] = B.ay; Wd.fb[b][8] = B.aw;
-        }
-      }
-    dg_integrate(D, K.qacc, h);
-#pragma unroll 1
-    for (int k = 0; k < NBODY; k++) {
-      const bool isb = k == BOX_ID;
-      if (isb ? !has_box : k >= nV) continue;
-      dg_free_body_finish(Wd.fb[k], isb, vk, bk, sol0.bcoef, hf);
-    }
-  }
-  DCY(6);
-#ifdef SAG_CYCLES
-  if ((threadIdx.x & 63) == 0) {
-    for (int k = 0; k < 12; k++) atomicAdd(&g_cyc[1][k], dcy[k]);
-    atomicAdd(&g_cyc[1][CY_N], 1ull);
-  }
-#endif
-#undef DCY
-  out.overflow = R.overflow;
-  for (int k = 0; k < 3; k++) out.qacc_lin[k] = K.qacc[k];
-  for (int k = 0; k < 8; k++) out.touch[k] = K.touch[k];
-  dg_com_vel(D, K, out.comvel);
-}
-
-#endif  // SAG_DOGGO_LANE_TU
 
 // MODE_POST: Doggo only - the generic step after the wave-cooperative physics kernel (results in StepArgs::DR):
 // no physics code in the instance at all
@@ -1182,7 +968,7 @@ constexpr uint32_t TS_BUSY_BIT = 1u << 28;
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX, int MODE>
 __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const int lane, const int i,
                                           const bool live, const int base_env, const int nvalid,
-                                          const uint64_t skip_mask, const int* rows, double* dgL = nullptr) {
+                                          const uint64_t skip_mask, const int* rows) {
   constexpr int NSTAT = SAG_MAX_PILLARS + (HAS_BTN ? SAG_MAX_BUTTONS : 0);
   constexpr bool CAR = ROBOT == SAG_ROBOT_CAR, DOGGO = ROBOT == SAG_ROBOT_DOGGO;
   static_assert(!DOGGO || MODE == MODE_ALL || MODE == MODE_POST, "Doggo runs the single-launch form");
@@ -1420,7 +1206,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   float cy = 1, sy = 0, yaw_turn = 0;
 
   CYC(CY_LOAD);
-  // Doggo: its own substep loop (doggo_physics); state in private memory
+  // Doggo: the physics kernel has run; state in private memory for the sensors
   DgState dgs;
   DgResult dgr;
   double dg_rot[DOGGO ? 9 : 1] = {};  // base rotation matrix (lidar, sensors)
@@ -1452,13 +1238,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       for (int k = 0; k < 4; k++) dgr.comvel[k] = dr[11 + k];
       dgr.cost_contacts = (int)dr[15]; dgr.btn_mask = (uint32_t)dr[16]; dgr.overflow = (int)dr[17];
     } else {
-#ifdef SAG_DOGGO_LANE_TU
-      if (live)  // padding lanes of a partly filled wavefront stay out of the divergence union
-        doggo_physics(dgs, Wd, dgr, (lds_f64*)dgL + lane, ctrl12, nsub, h, stx, sty, nP, nB, psz, vsz, vk, bk, sol0, solb, nV,
-                      has_box, HAS_TBOX && task == SAG_TASK_HAUL_BOX);
-#else
-      static_assert(MODE == MODE_POST, "the lane-per-env Doggo kernel is instantiated in sag_doggo_lane.hip only");
-#endif
+      static_assert(post, "the Doggo physics is k_doggo_physics (sag_doggo_coop.hpp); the generic step only post-processes its results");
     }
     cost_contacts = dgr.cost_contacts; btn_mask = dgr.btn_mask;
     if (dgr.overflow) flags |= 4;   // SAG_I_FLAGS bit 2: a Doggo constraint did not fit the row budget
@@ -2393,17 +2173,16 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 
 // ---- the three launch forms ------------------------------------------------------------
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
-__global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_DOGGO ? 1 : SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
+__global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
   __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
-  // Doggo: the Cholesky factor of the mass matrix, [190][64 lanes] fp64 = 95 KB (one wavefront per CU)
-  __shared__ double dgL[ROBOT == SAG_ROBOT_DOGGO ? (DG_NTRI + 4 * DG_NV) * WAVE : 1];  // + 3 solve vectors, 1 / diagonal
-  // small batches (and Doggo, whose wavefronts are long): fewer envs per wavefront (p.envs_per_wave)
+  static_assert(ROBOT != SAG_ROBOT_DOGGO, "Doggo: k_doggo_physics + k_step_doggo_post");
+  // small batches: fewer envs per wavefront (p.envs_per_wave)
   // spread the batch over more CUs and shrink the divergence union; the idle lanes just mirror env N-1
   const int epw = p.envs_per_wave;   // 64 unless the batch is too small to give every CU a wavefront
   const int lane = threadIdx.x, base = blockIdx.x * epw, gi = base + lane;
   const bool live = gi < p.N && lane < epw;
   step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_ALL>(p, lds, lane, live ? gi : p.N - 1, live, base,
-                                                 min(epw, p.N - base), 0ull, nullptr, dgL);
+                                                 min(epw, p.N - base), 0ull, nullptr);
 }
 
 // Doggo, cooperative form: the generic step after k_doggo_physics (p.DR set): no physics, no factor in LDS
@@ -2413,10 +2192,9 @@ __global__ __launch_bounds__(WAVE, 1) void k_step_doggo_post(StepArgs p) {
   const int lane = threadIdx.x, base = blockIdx.x * WAVE, gi = base + lane;
   const bool live = gi < p.N;
   step_body<SAG_ROBOT_DOGGO, HAS_BTN, HAS_TBOX, MODE_POST>(p, lds, lane, live ? gi : p.N - 1, live, base, min(WAVE, p.N - base),
-                                                            0ull, nullptr, nullptr);
+                                                            0ull, nullptr);
 }
 
-#ifndef SAG_DOGGO_LANE_TU   // the rest of the file: kernels of the main translation unit (sag_api.hip)
 #ifndef SAG_QUIET_MIN_WAVES
 #define SAG_QUIET_MIN_WAVES 4   // 128 VGPRs: a busy wavefront (250) and TWO quiet ones share a SIMD's 512 registers; at 3 (136 VGPRs, no
                                // 16-B spill) only one fits beside it: measured 0.88 vs 0.97 ms per Point step at 4 M envs
@@ -2919,6 +2697,3 @@ __global__ void k_fill_actions(float* actions, const int32_t* I, int N, int nu, 
 }  // namespace sag
 #include "sag_render.hpp"
 #include "sag_doggo_coop.hpp"
-#else
-}  // namespace sag
-#endif  // SAG_DOGGO_LANE_TU

@@ -1,18 +1,18 @@
 // Doggo physics, wave-cooperative form: 32 lanes per env (two envs per wavefront), every working
 // array in LDS, the dense linear algebra spread over the lanes.
 //
-// Same specification as sag_doggo.hpp / DESIGN.md §4 "Doggo" (same row order, same PGS sweeps), other
-// mapping onto the machine: the lane-per-env form of sag_doggo.hpp walks every dependent chain
-// (Cholesky, 40+ triangular solves, row construction) through private memory at ~100 clocks per
-// step, 17 ms per step for 4096 envs.  Here lane i owns dof i (row i of the mass matrix, component
-// i of every generalised vector), lane b body b, lane s collision sphere s:
+// Specification: oracle/sag_oracle_doggo.inc / DESIGN.md §4 "Doggo" (same row order, same warm-started PGS).  A
+// lane-per-env kernel would walk every dependent chain (Cholesky, 40+ triangular solves, row construction) through
+// private memory at ~100 clocks per step (round 1: 17 ms per step for 4096 envs).  Here lane i owns dof i (row i of
+// the mass matrix, component i of every generalised vector), lane b body b, lane s collision sphere s:
 //   kinematics / inertias / RNEA   each lane walks its own root-to-body chain (<= 3 joints)
 //   mass matrix                    lane i computes row i from the composite inertias
 //   Cholesky                       right-looking, 19 rank-1 steps, lane i updates row i
 //   M^-1                           19 right-hand sides at once (lane i: component i of each)
 //   constraint rows                the contact's owner lane builds J (sparse) and W = M^-1 J^T;
 //                                  all contacts of a phase in parallel
-//   PGS                            rows in sequence, J.qacc by a 32-lane butterfly reduction
+//   PGS                            one row per lane on the Delassus matrix (fp32), warm-started from the previous
+//                                  forward evaluation of the env-step, DG_PGS_ITERS sweeps (DG_PGS_ITERS0 cold)
 //   planar world                   body k on lane k for statics / friction / integration
 // The generic step kernel then runs with `doggo_post` set: it skips the physics and does reward,
 // cost, lidar and the observation from the stored state and the per-env result block.
@@ -20,11 +20,12 @@
 
 namespace sag {
 
-constexpr int DC_ROWS = DG_MAXROWS;              // max constraint rows per env (same cap as the lane-per-env form)
+constexpr int DC_ROWS = DG_MAXROWS;              // max constraint rows per env
 constexpr int DC_PGS_LANES = 32;                // fast PGS path: one constraint row per lane
 struct DcContact {                              // a contact as its owner lane found it; its three rows are built by all lanes
   double dir[3][3], c[3], depth;                // normal + two tangents, point, penetration
   float bcoef, kcoef, mu;
+  uint32_t key;                                 // identity of the contact's normal row (+1, +2: its tangents): warm start
   short s, other;                               // robot sphere, planar body (-1: static / floor)
 };
 struct DcEnv {                                  // one env's working set in LDS
@@ -59,10 +60,17 @@ struct DcEnv {                                  // one env's working set in LDS
   double touch[8];
   double com[2], mom[2];                        // centre of mass, momentum / mass (outputs; from Ib and M rows 0, 1)
   float rJ[DC_ROWS][DG_NV];
-  double rA[DC_ROWS], rAref[DC_ROWS], rImp[DC_ROWS], rF[DC_ROWS], rMu[DC_ROWS];
+  double rA[DC_ROWS], rAref[DC_ROWS], rF[DC_ROWS];
+  float rImp[DC_ROWS], rMu[DC_ROWS];             // impedance (0.9 .. 0.95), friction coefficient (two wavefronts' envs must fit 40 KB: four per CU)
   double rReg[DC_ROWS], rInv[DC_ROWS];           // A (1 - d) / d and 1 / (A + reg): no division inside the PGS sweeps
   float rOu[DC_ROWS][3], rOd[DC_ROWS][2], rOrx[DC_ROWS], rOry[DC_ROWS];
   short rParent[DC_ROWS], rOther[DC_ROWS], rTouch[DC_ROWS];
+  // warm start (oracle DgWarm): identity of every row (0 = none; key scheme in oracle/sag_oracle_doggo.inc), and the
+  // rows + forces of the previous forward evaluation of this env-step
+  uint32_t rKey[DC_ROWS], wsKey[DC_ROWS];
+  float wsF[DC_ROWS];
+  int wsN;
+  uint32_t act;                                 // planar bodies that take part in this forward evaluation (oracle world_forward, "sleeping bodies")
   float wfb[NBODY][9], wminv[NBODY][6];         // planar free bodies
   int nrows, flag;
 };
@@ -504,7 +512,7 @@ __device__ __attribute__((noinline)) double dc_build_row(int hf, int r, int othe
   double vel = 0;
 #pragma unroll
   for (int k = 0; k < DG_NV; k++) vel += (double)E.rJ[r][k] * E.qdv[k];
-  E.rOther[r] = (short)other; E.rParent[r] = -1; E.rTouch[r] = -1; E.rF[r] = 0; E.rMu[r] = 0;
+  E.rOther[r] = (short)other; E.rParent[r] = -1; E.rTouch[r] = -1; E.rF[r] = 0; E.rMu[r] = 0; E.rKey[r] = 0;
   float ou0 = 0, ou1 = 0, ou2 = 0, od0 = 0, od1 = 0, orx = 0, ory = 0;
   if (other >= 0) {
     const float* m = E.wminv[other];
@@ -564,7 +572,7 @@ __device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nr
 #pragma unroll
     for (int k = 0; k < DG_NV; k++) Arr += Jr[k] * (double)E.rW[rr][k];
     Arr += dc_body_coupling(E, rr, rr);
-    const double imp = E.rImp[rr], reg = Arr * (1 - imp) / imp;
+    const double imp = (double)E.rImp[rr], reg = Arr * (1 - imp) / imp;
     E.rA[rr] = Arr; E.rReg[rr] = reg; E.rInv[rr] = 1.0 / (Arr + reg);
     if (fast) {
 #pragma unroll
@@ -590,6 +598,13 @@ __device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nr
   return a0;
 }
 
+// the same for a float
+__device__ inline float dc_bcastf(float v, int lane_in_half, int half) {
+  const int b = __float_as_int(v);
+  const int v0 = __builtin_amdgcn_readlane(b, lane_in_half);
+  if (DC_EPW == 2) { const int v1 = __builtin_amdgcn_readlane(b, lane_in_half + 32); return __int_as_float(half ? v1 : v0); }
+  return __int_as_float(v0);
+}
 // v of lane `lane_in_half` of this lane's own half, for every lane (lane index uniform across the wavefront)
 __device__ inline double dc_bcast(double v, int lane_in_half, int half) {
   const long long b = __double_as_longlong(v);
@@ -623,7 +638,7 @@ __device__ inline void dc_jac(int hf, int r, int b, const double* c, const doubl
 // three rows - 57 Jacobian entries - are computed by all lanes together in dc_contacts_finish: one lane per contact
 // doing them while the others idle was 17 % of the kernel.
 __device__ inline void dc_contact_add(int hf, int j, int s, const double* n, const double* c, double depth, int other,
-                                      double bcoef, double kcoef, double mu) {
+                                      double bcoef, double kcoef, double mu, uint32_t key) {
   DC_ENV;
   DcContact& C = E.ct[j];
   double dir[3][3];
@@ -635,7 +650,7 @@ __device__ inline void dc_contact_add(int hf, int j, int s, const double* n, con
     for (int a = 0; a < 3; a++) C.dir[k][a] = dir[k][a];
   for (int a = 0; a < 3; a++) C.c[a] = c[a];
   C.depth = depth; C.bcoef = (float)bcoef; C.kcoef = (float)kcoef; C.mu = (float)mu;   // (float-valued: exact)
-  C.s = (short)s; C.other = (short)other;
+  C.s = (short)s; C.other = (short)other; C.key = key;
 }
 
 // rows [r0, r0 + 3 nct) of the nct registered contacts: Jacobians entry by entry across the lanes, then one row per lane
@@ -664,18 +679,20 @@ __device__ __attribute__((noinline)) void dc_contacts_finish(int hf, int u, int 
     const int j = q / 3, k = q - 3 * j, r = r0 + q, base = r0 + 3 * j;
     const DcContact& C = E.ct[j];
     const double vel = dc_build_row(hf, r, C.other, -C.dir[k][0], -C.dir[k][1], C.c[0], C.c[1]);
-    E.rImp[r] = dg_impedance(C.depth);
+    E.rImp[r] = (float)dg_impedance(C.depth);
+    E.rKey[r] = C.key + (uint32_t)k;
     if (k == 0) { E.rAref[r] = -(double)C.bcoef * vel + (double)C.kcoef * C.depth; E.rTouch[r] = (short)g_dc_phys.sph_touch[C.s]; }
-    else { E.rAref[r] = -(double)C.bcoef * vel; E.rParent[r] = (short)base; E.rMu[r] = (double)C.mu; }
+    else { E.rAref[r] = -(double)C.bcoef * vel; E.rParent[r] = (short)base; E.rMu[r] = C.mu; }
   }
 }
 
 // spheres of the robot (one per lane) vs one planar body: appends the contact rows in (sphere, geom)
 // order; returns the number of contacts (uniform in the half)
-__device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, int& nrows, int fbi, int shape, float bx, float by, float byaw,
+__device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, int& nrows, int fbi, int obj, int shape, float bx, float by, float byaw,
                                       float rbound, float vsz, float rstatic, double top, double bcoef, double kcoef, double mu) {
   DC_ENV;
   DgHit hits[5];
+  int hg[5] = {0, 0, 0, 0, 0};   // geom of each hit (row identity)
   int cnt = 0;
   double cz = 0;
   if (u < DG_NS) {
@@ -694,7 +711,7 @@ __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, 
         const Geom ge = shape_geom(shape, g, vsz, rstatic);
         const float gx = bx + cb * ge.ox - sb * ge.oy, gy = by + sb * ge.ox + cb * ge.oy;
         DgHit h;
-        if (dg_circle_geom((float)c[0], (float)c[1], (float)r, ge, gx, gy, cb, sb, h)) hits[cnt++] = h;
+        if (dg_circle_geom((float)c[0], (float)c[1], (float)r, ge, gx, gy, cb, sb, h)) { hits[cnt] = h; hg[cnt] = g; cnt++; }
       }
     }
   }
@@ -707,7 +724,8 @@ __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, 
     const int idx = excl + k;
     if (idx < fit) {
       const double nn[3] = {-(double)hits[k].nx, -(double)hits[k].ny, 0}, pc[3] = {(double)hits[k].px, (double)hits[k].py, cz};
-      dc_contact_add(hf, (nrows - r0) / 3 + idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu);
+      dc_contact_add(hf, (nrows - r0) / 3 + idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu,
+                     0x10000u + 4u * (uint32_t)(32 * (8 * (8 * obj + hg[k])) + u));
     }
   }
   nrows += 3 * fit;
@@ -828,6 +846,9 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
 #pragma unroll 1
   for (int sub = 0; sub <= nsub; sub++) {
     if (u < NBODY) { E.wfb[u][6] = 0; E.wfb[u][7] = 0; E.wfb[u][8] = 0; }
+    // planar bodies that take part in this forward evaluation: the moving ones, + below those the robot touches
+    // (specification: oracle world_forward, "sleeping bodies"); uniform in the half
+    uint32_t act = (uint32_t)(__ballot(u < NBODY && (E.wfb[u][3] != 0 || E.wfb[u][4] != 0 || E.wfb[u][5] != 0)) >> (32 * half)) & ((1u << NBODY) - 1);
     if (u == BOX_ID && W.has_box && W.bk.sh == SH_ROD) {
       float c, s; sincosf(E.wfb[BOX_ID][2], &s, &c);
       const float ix = 1.0f / (1.5f * W.bk.m), iy = 1.0f / W.bk.m;
@@ -866,8 +887,9 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         const int r = nrows + excl;
         for (int k = 0; k < DG_NV; k++) E.rJ[r][k] = k == 6 + u ? (float)sign : 0.f;
         const double vel = dc_build_row(hf, r, -1, 0, 0, 0, 0);
-        E.rImp[r] = dg_impedance(depth);
+        E.rImp[r] = (float)dg_impedance(depth);
         E.rAref[r] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * depth;
+        E.rKey[r] = 0x100u + (uint32_t)(2 * u + (sign < 0 ? 1 : 0));
       }
       nrows += fit;
     }
@@ -882,7 +904,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       if (fit < total && u == 0) E.flag |= 2;
       if (depth > 0 && excl < fit) {
         const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dc_phys.sph_r[u])};
-        dc_contact_add(hf, excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU);
+        dc_contact_add(hf, excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU, 0x1000u + 4u * (uint32_t)u);
       }
       nrows += 3 * fit;
     }
@@ -897,23 +919,27 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
 #pragma unroll 1
     for (int q = 0; q < W.nP; q++)
       if (near(stx[q], sty[q], W.psz))
-        cc += dc_collide_body(hf, u, r0, nrows, -1, SH_STATIC, stx[q], sty[q], 0.f, W.psz, W.vsz, W.psz, 1.0,
+        cc += dc_collide_body(hf, u, r0, nrows, -1, q, SH_STATIC, stx[q], sty[q], 0.f, W.psz, W.vsz, W.psz, 1.0,
                               (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
 #pragma unroll 1
     for (int b = 0; b < W.nB; b++)
       if (near(stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], BUTTON_R) &&
-          dc_collide_body(hf, u, r0, nrows, -1, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f, BUTTON_R, W.vsz,
+          dc_collide_body(hf, u, r0, nrows, -1, SAG_MAX_PILLARS + b, SH_STATIC, stx[SAG_MAX_PILLARS + b], sty[SAG_MAX_PILLARS + b], 0.f, BUTTON_R, W.vsz,
                           BUTTON_R, 0.2, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu))
         mask |= 1u << b;
 #pragma unroll 1
     for (int k = 0; k < W.nV; k++)
-      if (near(E.wfb[k][0], E.wfb[k][1], vase_r))
-        cc += dc_collide_body(hf, u, r0, nrows, k, SH_VASE, E.wfb[k][0], E.wfb[k][1], E.wfb[k][2], vase_r, W.vsz, 0.f, top_vase,
-                              (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
+      if (near(E.wfb[k][0], E.wfb[k][1], vase_r)) {
+        const int nc = dc_collide_body(hf, u, r0, nrows, k, SAG_MAX_PILLARS + SAG_MAX_BUTTONS + k, SH_VASE, E.wfb[k][0], E.wfb[k][1], E.wfb[k][2],
+                                       vase_r, W.vsz, 0.f, top_vase, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)W.sol0.mu);
+        cc += nc;
+        if (nc) act |= 1u << k;   // a body the robot touches takes part in this evaluation
+      }
     if (W.has_box) {
-      if (near(E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], box_r))
-        dc_collide_body(hf, u, r0, nrows, BOX_ID, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], E.wfb[BOX_ID][2], box_r, W.vsz, 0.f,
-                        top_box, (double)W.solb.bcoef, (double)W.solb.kcoef, (double)W.solb.mu);
+      if (near(E.wfb[BOX_ID][0], E.wfb[BOX_ID][1], box_r) &&
+          dc_collide_body(hf, u, r0, nrows, BOX_ID, SAG_MAX_PILLARS + SAG_MAX_BUTTONS + SAG_MAX_VASES, W.bk.sh, E.wfb[BOX_ID][0], E.wfb[BOX_ID][1],
+                          E.wfb[BOX_ID][2], box_r, W.vsz, 0.f, top_box, (double)W.solb.bcoef, (double)W.solb.kcoef, (double)W.solb.mu))
+        act |= 1u << BOX_ID;
     }
     dc_contacts_finish(hf, u, r0, (nrows - r0) / 3);
     if (W.has_box) {
@@ -926,10 +952,12 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
             const double j[3] = {dx / Lt, dy / Lt, dz / Lt};
             dc_jac(hf, nrows, 0, E.pos, j);
             const double vel = dc_build_row(hf, nrows, BOX_ID, -j[0], -j[1], (double)E.wfb[BOX_ID][0], (double)E.wfb[BOX_ID][1]);
-            E.rImp[nrows] = dg_impedance(viol);
+            E.rImp[nrows] = (float)dg_impedance(viol);
             E.rAref[nrows] = -(double)W.sol0.bcoef * vel + (double)W.sol0.kcoef * viol;
+            E.rKey[nrows] = 0x80u;
           }
           nrows += 1;
+          act |= 1u << BOX_ID;
         }
       }
     }
@@ -943,37 +971,59 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     const bool fast = nmax <= DC_PGS_LANES;
     const double a0 = dc_rows_finish(hf, u, nrows, fast);
     DCC(DCY_FINISH);
+    const int iters = sub == 0 ? DG_PGS_ITERS0 : DG_PGS_ITERS;   // the first forward evaluation of an env-step starts cold
     if (fast) {
       // ---- projected Gauss-Seidel on the Delassus matrix: lane r owns row r (its accumulated force f and its
       //      constraint acceleration acc = J_r qacc + planar-body term).  Updating row r changes every row's acc by
       //      A[.][r] df: one broadcast (v_readlane: r is uniform) and one multiply-add per lane, no barrier, no
-      //      19-term dot product.  Same sweep order, bounds and arithmetic as the row-by-row form (A in fp32).
+      //      19-term dot product.  fp32 like A (round 2 ran these sweeps in fp64: 4 of them; the specification now runs
+      //      24, and a sweep is a contraction, so rounding does not accumulate).  Same sweep order and bounds as the oracle.
       const bool mine = u < nrows;
       const int ur = mine ? u : 0;
       float Ar[DC_PGS_LANES];         // the lane's row of A in registers (A[r][u] = A[u][r]: consecutive words across lanes)
 #pragma unroll
       for (int r = 0; r < DC_PGS_LANES; r++) Ar[r] = r < nrows ? E.A[r * DC_PGS_LANES + ur] : 0.f;
-      double acc = a0, f = 0, fn_contact = 0;
-      const double aref = E.rAref[ur], reg = E.rReg[ur], inv = E.rInv[ur], mu = E.rMu[ur];
+      const float aref = (float)E.rAref[ur], reg = (float)E.rReg[ur], inv = (float)E.rInv[ur], mu = E.rMu[ur];
       const int parent = E.rParent[ur];
       const bool okA = mine && E.rA[ur] > 0, isfric = parent >= 0;
+      // warm start: the force this row had in the previous forward evaluation (matched by identity), inside its bounds
+      float f = 0.f;
+      if (sub > 0) {
+        const uint32_t key = E.rKey[ur];
+        const int nprev = E.wsN;
+        float raw = 0.f;
 #pragma unroll 1
-      for (int it = 0; it < DG_PGS_ITERS; it++)
+        for (int q = 0; q < nprev; q++) raw = E.wsKey[q] == key ? E.wsF[q] : raw;   // (same address in every lane: LDS broadcast)
+        if (!okA || key == 0) raw = 0.f;
+        const float fn0 = fmaxf(raw, 0.f);                       // a normal / limit row: [0, inf)
+        const float fpar = __shfl(fn0, isfric ? parent : 0, 32);  // a friction row: +-mu x its normal row's force
+        f = isfric ? fminf(fmaxf(raw, -mu * fpar), mu * fpar) : fn0;
+      }
+      const float fpar0 = __shfl(f, isfric ? parent : 0, 32);   // (every lane takes part in the exchange)
+      float fn_contact = isfric ? fpar0 : 0.f;
+      float acc = (float)a0;
+      if (sub > 0) {
+#pragma unroll
+        for (int r = 0; r < DC_PGS_LANES; r++) {
+          if (r >= nmax) break;
+          acc += Ar[r] * dc_bcastf(f, r, half);
+        }
+      }
+#pragma unroll 1
+      for (int it = 0; it < iters; it++)
 #pragma unroll
         for (int r = 0; r < DC_PGS_LANES; r++) {   // unrolled: lane index and register index of the row are constants
           if (r >= nmax) break;
-          double fnew = f + (aref - acc - reg * f) * inv;
-          const double lo = isfric ? -mu * fn_contact : 0.0, hi = isfric ? mu * fn_contact : 1e30;
-          if (fnew < lo) fnew = lo;
-          if (fnew > hi) fnew = hi;
-          const double df_mine = (u == r && okA) ? fnew - f : 0.0;
-          const double df = dc_bcast(df_mine, r, half);
-          if (u == r) f += df;
-          // a friction row tracks its contact's normal force by the same increments (f starts at 0 in both lanes)
+          const float hi = isfric ? mu * fn_contact : 3.0e38f, lo = isfric ? -hi : 0.f;
+          const float fnew = fminf(fmaxf(f + (aref - acc - reg * f) * inv, lo), hi);
+          const float df_mine = (u == r && okA) ? fnew - f : 0.f;
+          const float df = dc_bcastf(df_mine, r, half);
+          f += df_mine;
+          // a friction row tracks its contact's normal force by the same increments
           if (r == parent) fn_contact += df;
-          acc += (double)Ar[r] * df;
+          acc += Ar[r] * df;
         }
-      if (mine) E.rF[u] = f;
+      if (mine) E.rF[u] = (double)f;
       __syncthreads();
       DCC(DCY_PGS);
       if (u < DG_NV) {
@@ -994,8 +1044,47 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       __syncthreads();
     } else {
     // ---- projected Gauss-Seidel, row by row (an env with more than 32 rows): the dot product J.qacc across the lanes ---
+    if (sub > 0) {
+      // warm start: normal / limit rows first, then the friction rows inside +-mu x their normal row's force
+      float raw[2] = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int r = u + 32 * t;
+        if (r < nrows && E.rA[r] > 0 && E.rKey[r] != 0) {
+          const uint32_t key = E.rKey[r];
+          for (int q = 0; q < E.wsN; q++) raw[t] = E.wsKey[q] == key ? E.wsF[q] : raw[t];
+        }
+        if (r < nrows && E.rParent[r] < 0) E.rF[r] = (double)fmaxf(raw[t], 0.f);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int r = u + 32 * t;
+        if (r < nrows && E.rParent[r] >= 0) {
+          const float b = E.rMu[r] * (float)E.rF[E.rParent[r]];
+          E.rF[r] = (double)fminf(fmaxf(raw[t], -b), b);
+        }
+      }
+      __syncthreads();
+      if (u < DG_NV) {
+        double q = qacc_u;
 #pragma unroll 1
-    for (int it = 0; it < DG_PGS_ITERS; it++)
+        for (int r = 0; r < nrows; r++) q += (double)E.rW[r][u] * E.rF[r];
+        qacc_u = q;
+      }
+      if (u < NBODY) {
+        float b6 = E.wfb[u][6], b7 = E.wfb[u][7], b8 = E.wfb[u][8];
+        for (int r = 0; r < nrows; r++)
+          if (E.rOther[r] == u) {
+            const double fr = E.rF[r];
+            b6 += (float)((double)E.rOu[r][0] * fr); b7 += (float)((double)E.rOu[r][1] * fr); b8 += (float)((double)E.rOu[r][2] * fr);
+          }
+        E.wfb[u][6] = b6; E.wfb[u][7] = b7; E.wfb[u][8] = b8;
+      }
+      __syncthreads();
+    }
+#pragma unroll 1
+    for (int it = 0; it < iters; it++)
 #pragma unroll 1
       for (int r = 0; r < nmax; r++) {
         const bool on = r < nrows;
@@ -1018,7 +1107,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
           double fnew = f + (E.rAref[rr] - acc - E.rReg[rr] * f) * E.rInv[rr];
           double lo = 0, hi = 1e30;
           const int par = E.rParent[rr];
-          if (par >= 0) { const double fn = E.rF[par]; lo = -E.rMu[rr] * fn; hi = E.rMu[rr] * fn; }
+          if (par >= 0) { const double fn = E.rF[par]; lo = -(double)E.rMu[rr] * fn; hi = (double)E.rMu[rr] * fn; }
           if (fnew < lo) fnew = lo;
           if (fnew > hi) fnew = hi;
           df = fnew - f;
@@ -1044,15 +1133,23 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
         if (E.rTouch[r] == u && E.rParent[r] < 0) t += E.rF[r];
       E.touch[u] = t;
     }
+    // this evaluation's rows and forces for the next one's warm start
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int r = u + 32 * t;
+      if (r < nrows) { E.wsKey[r] = E.rKey[r]; E.wsF[r] = (float)E.rF[r]; }
+    }
+    if (u == 0) E.wsN = nrows;
     cost_contacts = cc; btn_mask = mask;
     __syncthreads();
     DCC(DCY_AFTER);
     if (sub == nsub) break;
     // ---- planar world: body k on lane k vs the statics; pairs on lane 0; friction + integration --
+    //      (active bodies only: the moving ones and those the robot touched in this evaluation)
     if (u < NBODY) {
       const int k = u;
       const bool isb = k == BOX_ID;
-      if (isb ? W.has_box : k < W.nV) {
+      if ((isb ? W.has_box : k < W.nV) && (act >> k & 1u)) {
         const float br = isb ? box_r : vase_r;
         for (int q = 0; q < SAG_MAX_PILLARS + W.nB; q++) {
           if (q == W.nP && q < SAG_MAX_PILLARS) q = SAG_MAX_PILLARS;
@@ -1082,15 +1179,18 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       for (int b = u + 1; b < NBODY; b++) {
         const bool isb = b == BOX_ID;
         if (isb ? !W.has_box : b >= W.nV) continue;
+        if (!((act >> u | act >> b) & 1u)) continue;   // two sleeping bodies: the pair is not evaluated
         const float dx = E.wfb[b][0] - E.wfb[u][0], dyy = E.wfb[b][1] - E.wfb[u][1], rs = vase_r + (isb ? box_r : vase_r);
         pair_near |= !(dx * dx + dyy * dyy > rs * rs);
       }
     const unsigned long long near_lanes = __ballot(pair_near);
     if (u == 0 && (near_lanes >> (32 * half) & 0xffffffffull)) {
+      // (which pairs are walked is decided by who was active when the walk started: `act` is not updated inside it)
       for (int a = 0; a < W.nV; a++)
         for (int b = a + 1; b < NBODY; b++) {
           const bool isb = b == BOX_ID;
           if (isb ? !W.has_box : b >= W.nV) continue;
+          if (!((act >> a | act >> b) & 1u)) continue;
           const float dx = E.wfb[b][0] - E.wfb[a][0], dyy = E.wfb[b][1] - E.wfb[a][1], rs = vase_r + (isb ? box_r : vase_r);
           if (dx * dx + dyy * dyy > rs * rs) continue;
           BV A, B; float ca, sa, cb, sb;

@@ -270,11 +270,10 @@ __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S,
       r_rod(ob, n, R, p, .105, .1, -.05, .155, .1, -.05, 0.05, false, 1, 0, 0, 1.0);     // right wheel
       r_obj(ob, n, 2, p[0] + R[1] * -.1, p[1] + R[4] * -.1, p[2] - .05, 0.05, 0, 0, 0.0, 1, 0, 0, 1.0);   // rear ball
     } else {                                 // doggo.xml: two torso cylinders, twelve capsules (ankles blue / green)
-      DgWork K;
-      K.L = nullptr; K.xs = nullptr; K.dinv = nullptr;
+      struct { double R[DG_NB][9], p[DG_NB][3]; } K;
       DgState D;
       dg_load(D, S, (size_t)N, i);
-      dg_kinematics(D, K);
+      dg_frames(D, K.R, K.p);
       for (int g = 0; g < DG_NGEOM; g++) {
         const int b = g_dg.geom_body[g];
         const bool ankle = g_dg.geom_ankle[g] != 0, front = g_dg.geom_ankle[g] == 1;

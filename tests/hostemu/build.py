@@ -39,8 +39,7 @@ def build(cc='gcc', pattern=False, san=True, extra=(), force=False, verbose=Fals
   if pattern:
     assert cc == 'clang', '--pattern needs clang'
     cmd += ['-ftrivial-auto-var-init=pattern']
-  cmd += list(extra) + ['-x', 'c++', os.path.join(CSRC, 'sag_api.hip'), os.path.join(CSRC, 'sag_doggo_lane.hip'),
-                         os.path.join(CSRC, 'sag_sampler.cpp'), '-o', lib]
+  cmd += list(extra) + ['-x', 'c++', os.path.join(CSRC, 'sag_api.hip'), os.path.join(CSRC, 'sag_sampler.cpp'), '-o', lib]
   if verbose:
     print(' '.join(cmd))
   subprocess.check_call(cmd)

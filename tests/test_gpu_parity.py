@@ -697,12 +697,10 @@ def test_car_env_api(nat):
 # Doggo (3-D articulated; fp64 robot solve on the device, fp32 planar world)
 # ----------------------------------------------------------------------------------
 DOGGO_TASKS = ['go_to_goal', 'push_box', 'press_buttons', 'haul_box', 'unsupervised', 'collect', MIXED]
-# two device forms of the Doggo physics: wave-cooperative (the default) and lane-per-env (SAG_DOGGO_COOP=0)
-DOGGO_CASES = [(t, '1') for t in DOGGO_TASKS] + [('go_to_goal', '0'), ('haul_box', '0'), (MIXED, '0')]
 
 
-@pytest.mark.parametrize('task,coop', DOGGO_CASES)
-def test_doggo_lockstep_vs_oracle(nat, oracle, task, coop, monkeypatch):
+@pytest.mark.parametrize('task', DOGGO_TASKS)
+def test_doggo_lockstep_vs_oracle(nat, oracle, task):
   """Same protocol as test_step_lockstep_vs_oracle for the Doggo robot (BASELINE config 4 shape
   for 'multitask').  Stated tolerance after one step (12 substeps) from identical fp32 state:
   robot qpos within 2e-5, qvel within 2e-3 abs + 2e-3 rel of the fp64 oracle (the device solves the
@@ -710,7 +708,6 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task, coop, monkeypatch):
   soft-contact dynamics amplify that rounding), free bodies within the planar STATE_TOL;
   threshold events (a sphere's penetration changing sign with the rounding) are counted and
   bounded.  goal_met / done / task ints / RNG words exact on rows inside the tolerance."""
-  monkeypatch.setenv('SAG_DOGGO_COOP', coop)
   n, T = 64, 30
   from safe_adaptation_gym_amd import benchmark
   if task == MIXED:
