@@ -13,6 +13,12 @@ A "step" = one sag_step_device() over the whole shard: action noise + clip, nste
 physics substeps with contact, reward (+ goal resampling), cost, 3x16 lidar, sensors,
 observation write.  Inputs (layouts, actions) are resident in HBM before timing.
 Prints ONE JSON line on rank 0.
+
+Every `roofline` block names its kernels and is checked against the committed rocprofv3 summary of the SAME device
+sources (profiles/kernels.json, written by tools/prof_summary.py, keyed by `src_sha16`): if that summary is of these
+sources and does not contain one of the block's kernels, the block is REFUSED (replaced by the reason) - a bench
+figure nobody can recompute from profiles/ is not printed.  A summary of other sources is reported as such
+(`profile: null`): re-run tools/gpu_final.sh.
 """
 import argparse
 import json
@@ -35,10 +41,20 @@ ALG_BYTES_PER_ENV_STEP = 892
 ALG_BYTES = {'point': 892, 'car': 804, 'lidar_cost': 376, 'render': 64 * 64 * 3 + 736}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector (non-matrix) peak
-# fp64 flops of one Doggo env-step in the wave-cooperative kernel, counted by rocprofv3
-# (SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes, FMA = 2: issued lane-operations), profiles/r02_doggo_flops.txt
-DOGGO_FP64_FLOPS_PER_ENV_STEP = 2.56e6
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak
 N_ACTION_BUFS = 8
+# per robot: substeps of one env-step (safe_adaptation_gym.py:15-19), the kernels of one step() in the split form and
+# in the single-launch form (below SAG_SPLIT_MIN_ENVS), algorithmic bytes per env-step (None: not HBM-bound)
+ROBOT_LINE = {
+    'point': {'substeps': 5, 'alg': 892, 'split_min': 262144, 'split': ['k_compact', 'k_step_quiet<0', 'k_step_busy<0'], 'single': ['k_step<0']},
+    'car': {'substeps': 10, 'alg': 804, 'split_min': 393216, 'split': ['k_compact', 'k_step_quiet<1', 'k_step_busy<1'], 'single': ['k_step<1']},
+    'doggo': {'substeps': 12, 'alg': None, 'split_min': 1 << 62, 'split': [], 'single': ['k_doggo_physics', 'k_step_doggo_post']},
+}
+
+
+def step_kernels(robot, envs):
+  r = ROBOT_LINE[robot]
+  return r['split'] if envs >= r['split_min'] else r['single']
 
 
 def source_sha16():
@@ -95,10 +111,15 @@ class DeviceRun:
     self.t = 0
 
   def burn_in(self, steps):
-    """Untimed ageing: the cost of a step depends on how many vases the robots have set in
-    motion; ~150 steps after reset the population is stationary (profiles/steptime)."""
+    """Untimed ageing: the cost of a step depends on the state's age (how many vases the robots have set in motion:
+    the busy fraction keeps drifting - 0.11 at step 225, 0.08 at step 420 of the headline run), so the line states
+    the burn-in and the busy fraction at its first and last timed step instead of calling the load stationary."""
     self.run(steps)
     self.ctx.wait()
+
+  def busy_fraction(self):
+    self.ctx.wait()
+    return self.ctx.busy_count() / self.envs
 
   def step(self):
     c = self.ctx
@@ -136,12 +157,66 @@ def timed(run, steps, warmup, barrier):
   """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides."""
   run.run(warmup)
   run.wait()
+  if hasattr(run, 'busy_fraction'):
+    run.busy_first = run.busy_fraction()   # load at the first timed step (untimed read-back)
   barrier()
   t0 = time.perf_counter()
   run.run(steps)
   run.wait()
   barrier()
   return time.perf_counter() - t0
+
+
+_PROFILE = None
+
+
+def profile_kernels():
+  """profiles/kernels.json: {src_sha16, summary, kernels: {name: {calls, avg_us}}, doggo_flops_per_env_step: {...}}."""
+  global _PROFILE
+  if _PROFILE is None:
+    try:
+      _PROFILE = json.load(open(os.path.join(ROOT, 'profiles', 'kernels.json')))
+    except (OSError, ValueError):
+      _PROFILE = {}
+  return _PROFILE
+
+
+def checked(block, kernels):
+  """Attach the committed profile's figures for the block's kernels; refuse the block if the profile is of these
+  sources and lacks one of them (see the module docstring)."""
+  prof = profile_kernels()
+  if prof.get('src_sha16') != source_sha16():
+    block['profile'] = None
+    block['profile_note'] = 'profiles/kernels.json was measured on other device sources (or is absent): nothing to check this block against'
+    return block
+  found = {}
+  for k in kernels:
+    hit = [n for n in prof.get('kernels', {}) if k in n]
+    if not hit:
+      return {'refused': f'kernel {k!r} is not in {prof.get("summary")} (src_sha16 {prof.get("src_sha16")}): this block cannot be recomputed from profiles/',
+              'kernel': block.get('kernel')}
+    found[k] = {n: prof['kernels'][n] for n in hit}
+  block['profile'] = {'summary': prof.get('summary'), 'src_sha16': prof.get('src_sha16'), 'kernels': found}
+  return block
+
+
+def doggo_roofline(ms, envs):
+  """Doggo: not an HBM kernel.  Vector-ALU utilisation from the issued lane-operations per env-step that rocprofv3 counted
+  on these sources (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 / _F32 x 64 lanes, FMA = 2; profiles/kernels.json):
+  time the fp64 operations need at the 78.6 TFLOP/s fp64 vector peak + time the fp32 ones need at 157.3, over the step time."""
+  fl = profile_kernels().get('doggo_flops_per_env_step') if profile_kernels().get('src_sha16') == source_sha16() else None
+  blk = {'bound': 'vector-alu (fp64 + fp32)', 'kernel': 'sag::k_doggo_physics + k_step_doggo_post', 'kernel_ms': ms, 'traffic': None,
+         'units_per_launch': envs,
+         'note': 'chains of dependent fp64 (kinematics, mass matrix, Cholesky, rows) and fp32 (projected Gauss-Seidel) operations on 2 envs per '
+                 'wavefront, one wavefront per SIMD: latency-bound, far from any roofline'}
+  if fl:
+    t64, t32 = fl['fp64'] * envs / (FP64_VECTOR_PEAK_TFLOPS * 1e12), fl['fp32'] * envs / (FP32_VECTOR_PEAK_TFLOPS * 1e12)
+    blk.update({'achieved': (fl['fp64'] + fl['fp32']) * envs / (ms * 1e-3) / 1e12, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': (t64 + t32) / (ms * 1e-3), 'flops_per_env_step': fl})
+  else:
+    blk.update({'achieved': None, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': None,
+                'flops_per_env_step': None, 'profile_note': 'no operation counts for these sources in profiles/kernels.json'})
+  return checked(blk, ['k_doggo_physics', 'k_step_doggo_post'])
 
 
 def traffic_per_launch(envs, key='point'):
@@ -158,11 +233,12 @@ def traffic_per_launch(envs, key='point'):
     return None
 
 
-def roofline_block(alg_bytes, envs, kernel_ms, kernel, key=None, launches=None):
+def roofline_block(alg_bytes, envs, kernel_ms, kernels, key=None, launches=None):
+  """kernels: the names (substrings of the profile's kernel names) whose launches make up one timed unit."""
   achieved = alg_bytes * envs / (kernel_ms * 1e-3) / 1e9
-  return {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-          'traffic': traffic_per_launch(envs, key) if key else None, 'kernel': kernel, 'kernel_ms': kernel_ms,
-          'launches_timed': launches, 'alg_bytes_per_unit': alg_bytes, 'units_per_launch': envs}
+  return checked({'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                  'traffic': traffic_per_launch(envs, key) if key else None, 'kernel': ' + '.join('sag::' + k for k in kernels),
+                  'kernel_ms': kernel_ms, 'launches_timed': launches, 'alg_bytes_per_unit': alg_bytes, 'units_per_launch': envs}, kernels)
 
 
 def cpu_baseline(task, seconds=12.0):
@@ -213,7 +289,10 @@ def main(argv=None, run_factory=None, emit=print):
   ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (stationary contact load)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='CPU time spent on the cpu_baseline sample')
-  ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line')
+  ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line and the other single-GPU config lines')
+  ap.add_argument('--no-c4', action='store_true', help='skip the sharded Doggo / multitask line (BASELINE config 4)')
+  ap.add_argument('--c4-envs', type=int, default=4096, help='Doggo envs per GPU of the config-4 line')
+  ap.add_argument('--c4-steps', type=int, default=30)
   args = ap.parse_args(argv)
 
   rank = int(os.environ.get('RANK', '0'))
@@ -277,8 +356,17 @@ def main(argv=None, run_factory=None, emit=print):
   cost_rate, n_done, finite = run.stats()
   total_env_steps = world * args.envs * args.steps
   value = total_env_steps / elapsed
-  alg = ALG_BYTES.get(args.robot, ALG_BYTES_PER_ENV_STEP)
-  achieved = alg * args.envs / (k_ms * 1e-3) / 1e9
+  line = ROBOT_LINE[args.robot]
+  kernels = step_kernels(args.robot, args.envs)
+  if line['alg'] is None:   # Doggo: no HBM fraction is quoted for a kernel that is not memory-bound
+    roof = doggo_roofline(k_ms, args.envs)
+  else:
+    roof = roofline_block(line['alg'], args.envs, k_ms, kernels, args.robot if args.envs >= line['split_min'] else None, k_n)
+    if 'refused' not in roof:
+      roof['kernel'] += ' (one step() = these launches)'
+      roof['alg_bytes_per_env_step'] = line['alg']
+  roof['kernel_ms_per_rank'] = k_ms_per_rank
+  roof['src_sha16'] = source_sha16()
   res = {
       'metric': 'env-steps/sec (batched) Point/GoToGoal' if args.robot == 'point' else f'env-steps/sec (batched) {args.robot}/{args.task}',
       'value': value,
@@ -293,33 +381,43 @@ def main(argv=None, run_factory=None, emit=print):
       'dtype': 'f32',
       'data': 'synthetic',
       'config': {
-          'workload': f'{args.robot}/{args.task} full step() (5 substeps + contact + reward + cost + lidar + obs), '
+          'workload': f'{args.robot}/{args.task} full step() ({line["substeps"]} substeps + contact + reward + cost + lidar + obs), '
                       f'one layout per env from the reference sampler semantics (env i <- RandomState(666 + i)), '
-                      f'{args.envs} envs per GPU, counter-based actions U(-1,1) and noise 0.01 on device',
+                      f'{args.envs} envs per GPU, counter-based actions U(-1,1) and noise 0.01 on device; '
+                      f'{args.burn_in} untimed burn-in steps + {args.warmup} warmup steps before the timed region',
+          'burn_in': args.burn_in,
           'envs_per_gpu': args.envs,
           'global_envs': world * args.envs,
           'env_id_ranges_per_rank': [[r * args.envs, (r + 1) * args.envs] for r in range(world)],
           'parallelism': f'env-sharded x{world}, no collective',
       },
-      'roofline': {
-          'bound': 'hbm',
-          'achieved': achieved,
-          'peak': HBM_PEAK_GBS,
-          'unit': 'GB/s',
-          'frac': achieved / HBM_PEAK_GBS,
-          'traffic': traffic_per_launch(args.envs, args.robot),
-          'kernel': 'sag::k_compact + k_step_quiet + k_step_busy (one step() = the three launches)',
-          'kernel_ms': k_ms,
-          'kernel_ms_per_rank': k_ms_per_rank,
-          'launches_timed': k_n,
-          'alg_bytes_per_env_step': alg,
-          'src_sha16': source_sha16(),
-      },
+      'roofline': roof,
       'checks': {'cost_rate_last_step': cost_rate, 'done_envs': n_done, 'obs_finite': finite,
                  'goal_met_rate_last_step': getattr(run, 'met_rate', None),
-                 'busy_env_fraction_last_step': getattr(run, 'busy_frac', None)},
+                 'busy_env_fraction_first_timed_step': getattr(run, 'busy_first', None),
+                 'busy_env_fraction_last_step': getattr(run, 'busy_frac', None),
+                 'state_age_steps': [args.burn_in + args.warmup, args.burn_in + args.warmup + args.steps]},
   }
   run.close()
+
+  # BASELINE config 4 as it is stated: Doggo, multitask sampler, 4096 envs PER GPU, sharded by env index over the
+  # ranks (8 x 4096 = 32768 on a node) - emitted at every world size; max over ranks like the headline
+  if not args.no_c4:
+    n4, k4, w4 = args.c4_envs, args.c4_steps, 5
+    r4 = run_factory('multitask', n4, device, rank, robot='doggo')
+    r4.burn_in(20)
+    r4.timing(True)
+    t4 = max_over_ranks(timed(r4, k4, w4, barrier))
+    ms4_rank, _ = r4.kernel_time_ms()
+    ms4 = max_over_ranks(ms4_rank)
+    res['c4_doggo_multitask'] = {
+        'value': world * n4 * k4 / t4, 'unit': 'env-steps/s', 'n_gpus': world, 'envs_per_gpu': n4, 'global_envs': world * n4,
+        'env_id_ranges_per_rank': [[r * n4, (r + 1) * n4] for r in range(world)], 'steps': k4, 'warmup': w4, 'burn_in': 20,
+        'ms_per_step': t4 / k4 * 1e3, 'kernel_ms': ms4, 'kernel_ms_per_rank': gather_ranks(ms4_rank), 'scaling': 'weak',
+        'note': 'BASELINE config 4: task of global env g from the benchmark TaskSampler order; whole-job env-steps over the max-over-ranks '
+                'time; 12 substeps, warm-started PGS 24 sweeps (48 cold)',
+        'roofline': doggo_roofline(ms4, n4)}
+    r4.close()
 
   if rank == 0 and world == 1 and run_factory is DeviceRun:
     if not args.no_c2:
@@ -333,6 +431,7 @@ def main(argv=None, run_factory=None, emit=print):
           'unit': 'env-steps/s',
           'ms_per_step': t / max(args.steps, 200) * 1e3,
           'kernel_ms': ms,
+          'roofline': roofline_block(ALG_BYTES['point'], 4096, ms, step_kernels('point', 4096)),
           'note': 'BASELINE config-2 batch size (4096 envs on one GPU): latency bound, 16 envs per wavefront x 256 wavefronts'
       }
       # the lidar + hazard-cost kernel alone on explicit poses (BASELINE config 2 "lidar + cost only"), device
@@ -362,7 +461,7 @@ def main(argv=None, run_factory=None, emit=print):
         t_lc = (time.perf_counter() - t0) / reps
         ms, cnt = cx.kernel_time_ms(reset=True)
         lc[str(n_lc)] = {'value': n_lc / t_lc, 'unit': 'env-evaluations/s', 'ms_per_call': t_lc * 1e3,
-                         'roofline': roofline_block(ALG_BYTES['lidar_cost'], n_lc, ms, 'sag::k_lidar_cost_reg', 'lidar_cost', cnt)}
+                         'roofline': roofline_block(ALG_BYTES['lidar_cost'], n_lc, ms, ['k_lidar_cost_reg'], 'lidar_cost', cnt)}
         cx.close()
       lc['note'] = ('sag_lidar_cost_device (k_lidar_cost_reg: one 12-KB LDS region as staging area, [bin][lane] ds_max tile and transpose buffer; bit-exact bins and '
                     'cost flags vs the reference fixtures) on n poses x 21 points resident in HBM, kernel-only time')
@@ -379,27 +478,10 @@ def main(argv=None, run_factory=None, emit=print):
         t = timed(r3, k3, 10, lambda: None)
         ms, cnt = r3.kernel_time_ms()
         c3[str(n_c3)] = {'value': n_c3 * k3 / t, 'unit': 'env-steps/s', 'ms_per_step': t / k3 * 1e3,
-                         'roofline': roofline_block(ALG_BYTES['car'], n_c3, ms, 'sag::k_compact + k_step_quiet<1> + k_step_busy<1>'
-                                                    if n_c3 > 393216 else 'sag::k_step<1>', 'car' if n_c3 > 393216 else None, cnt)}
+                         'roofline': roofline_block(ALG_BYTES['car'], n_c3, ms, step_kernels('car', n_c3),
+                                                    'car' if n_c3 >= ROBOT_LINE['car']['split_min'] else None, cnt)}
         r3.close()
       res['c3_car_push_box'] = c3
-      # BASELINE config 4 shape on one GPU: Doggo, multitask sampler, 4096 envs (x 8 GPUs = 32768)
-      r4 = DeviceRun('multitask', 4096, device, 0, robot='doggo')
-      r4.burn_in(20)
-      r4.timing(True)
-      t = timed(r4, 30, 5, lambda: None)
-      ms, _ = r4.kernel_time_ms()
-      c4 = {'value': 4096 * 30 / t, 'unit': 'env-steps/s', 'kernel_ms': ms,
-            'note': 'per GPU; wave-cooperative fp64 articulated solve (32 lanes per env), 12 substeps'}
-      if DOGGO_FP64_FLOPS_PER_ENV_STEP:
-        tf = DOGGO_FP64_FLOPS_PER_ENV_STEP * 4096 / (ms * 1e-3) / 1e12
-        c4['roofline'] = {'bound': 'fp64-vector', 'achieved': tf, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                          'frac': tf / FP64_VECTOR_PEAK_TFLOPS, 'traffic': None, 'kernel': 'sag::k_doggo_physics + k_step_doggo_post',
-                          'kernel_ms': ms, 'flops_per_env_step': DOGGO_FP64_FLOPS_PER_ENV_STEP,
-                          'note': 'a chain of dependent fp64 operations and LDS round trips on 2 envs per wavefront: latency-bound, '
-                                  'far from either roofline'}
-      res['c4_doggo_multitask_4096'] = c4
-      r4.close()
       # BASELINE config 5 (stretch): Doggo / haul_box with rgb_observation: step + 64x64x3 render per env
       r5 = DeviceRun('haul_box', 4096, device, 0, robot='doggo')
       d_img = r5.ctx.dev_alloc(4096 * 64 * 64 * 3)
@@ -414,7 +496,7 @@ def main(argv=None, run_factory=None, emit=print):
       t = timed(r5, 20, 2, lambda: None)
       res['c5_doggo_haul_box_rgb_4096'] = {'render_ms': t_render * 1e3, 'step_ms': t / 20 * 1e3,
                                            'value': 4096 / (t / 20 + t_render), 'unit': 'env-steps/s',
-                                           'roofline_render': roofline_block(ALG_BYTES['render'], 4096, t_render * 1e3, 'sag::k_render_rgb'),
+                                           'roofline_render': roofline_block(ALG_BYTES['render'], 4096, t_render * 1e3, ['k_render_rgb']),
                                            'note': 'per GPU: one step + one 64x64x3 uint8 first-person image per env; the ray caster '
                                                    'is fp64 compute per pixel (a hard decision like a lidar bin), not memory-bound'}
       r5.close()

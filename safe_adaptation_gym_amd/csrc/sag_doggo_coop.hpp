@@ -732,6 +732,73 @@ __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, 
   return total;
 }
 
+// Projected Gauss-Seidel of ONE env on all 64 lanes of the wavefront (an env with more than 32 rows; the other env
+// of the wavefront waits its turn): lane r owns row r as in the 32-lane form of k_doggo_physics, but computes its row
+// of the Delassus matrix A[r][s] = J_r W_s^T (+ the coupling through a shared planar body) straight into registers.
+// Needs W, rA / rReg / rInv (dc_rows_finish) and qacc0 in E.qacc; leaves the forces in E.rF.
+__device__ __attribute__((noinline)) void dc_pgs_wide(const int e, const int lane, const int nrows, const int iters, const bool warm) {
+  DcEnv& E = g_dc_env[e];
+  const bool mine = lane < nrows;
+  const int ur = mine ? lane : 0;
+  float Ar[DC_ROWS];
+  float acc;
+  {
+    double Jr[DG_NV], a0 = 0;
+#pragma unroll
+    for (int k = 0; k < DG_NV; k++) { Jr[k] = (double)E.rJ[ur][k]; a0 += Jr[k] * E.qacc[k]; }
+    acc = (float)a0;
+#pragma unroll
+    for (int s = 0; s < DC_ROWS; s++) {
+      float av = 0.f;
+      if (s < nrows) {   // (uniform)
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < DG_NV; k++) v += Jr[k] * (double)E.rW[s][k];
+        av = (float)(v + dc_body_coupling(E, ur, s));
+      }
+      Ar[s] = av;
+    }
+  }
+  const float aref = (float)E.rAref[ur], reg = (float)E.rReg[ur], inv = (float)E.rInv[ur], mu = E.rMu[ur];
+  const int parent = E.rParent[ur];
+  const bool okA = mine && E.rA[ur] > 0, isfric = parent >= 0;
+  float f = 0.f;
+  if (warm) {
+    const uint32_t key = E.rKey[ur];
+    const int nprev = E.wsN;
+    float raw = 0.f;
+#pragma unroll 1
+    for (int q = 0; q < nprev; q++) raw = E.wsKey[q] == key ? E.wsF[q] : raw;
+    if (!okA || key == 0) raw = 0.f;
+    const float fn0 = fmaxf(raw, 0.f);
+    const float fpar = __shfl(fn0, isfric ? parent : 0, 64);
+    f = isfric ? fminf(fmaxf(raw, -mu * fpar), mu * fpar) : fn0;
+  }
+  const float fpar0 = __shfl(f, isfric ? parent : 0, 64);
+  float fn_contact = isfric ? fpar0 : 0.f;
+  if (warm) {
+#pragma unroll
+    for (int r = 0; r < DC_ROWS; r++) {
+      if (r >= nrows) break;
+      acc += Ar[r] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), r));
+    }
+  }
+#pragma unroll 1
+  for (int it = 0; it < iters; it++)
+#pragma unroll
+    for (int r = 0; r < DC_ROWS; r++) {
+      if (r >= nrows) break;
+      const float hi = isfric ? mu * fn_contact : 3.0e38f, lo = isfric ? -hi : 0.f;
+      const float fnew = fminf(fmaxf(f + (aref - acc - reg * f) * inv, lo), hi);
+      const float df_mine = (lane == r && okA) ? fnew - f : 0.f;
+      const float df = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(df_mine), r));
+      f += df_mine;
+      if (r == parent) fn_contact += df;
+      acc += Ar[r] * df;
+    }
+  if (mine) E.rF[lane] = (double)f;
+}
+
 // inputs of the planar world shared by the lanes of a half
 struct DcWorldK {
   int nV, nP, nB, task;
@@ -964,11 +1031,14 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     if (u < DG_NV) E.qacc[u] = qacc_u;   // qacc0 for the rows' initial constraint accelerations
     __syncthreads();
     DCC(DCY_ROWS_WORLD);
-    // both envs of the wavefront take the same path: every row on its own lane (<= 32 rows: the usual case), or
-    // the row-by-row loop
+    // both envs of the wavefront take the same path: every row on its own lane of the env's half (<= 32 rows: the
+    // usual case), or one env after the other on all 64 lanes
     const int nother = DC_EPW == 2 ? __shfl(nrows, (lane + 32) & 63) : nrows;
     const int nmax = max(nrows, nother);
-    const bool fast = nmax <= DC_PGS_LANES;
+#ifndef SAG_DC_FAST_ROWS
+#define SAG_DC_FAST_ROWS DC_PGS_LANES   // (test builds lower it so that the 64-lane path runs on ordinary states)
+#endif
+    const bool fast = nmax <= SAG_DC_FAST_ROWS;
     const double a0 = dc_rows_finish(hf, u, nrows, fast);
     DCC(DCY_FINISH);
     const int iters = sub == 0 ? DG_PGS_ITERS0 : DG_PGS_ITERS;   // the first forward evaluation of an env-step starts cold
@@ -1024,108 +1094,31 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
           acc += Ar[r] * df;
         }
       if (mine) E.rF[u] = (double)f;
-      __syncthreads();
-      DCC(DCY_PGS);
-      if (u < DG_NV) {
-        double q = qacc_u;
-#pragma unroll 1
-        for (int r = 0; r < nrows; r++) q += (double)E.rW[r][u] * E.rF[r];
-        qacc_u = q;
-      }
-      if (u < NBODY) {   // planar bodies: accelerations from the rows that act on them
-        float b6 = E.wfb[u][6], b7 = E.wfb[u][7], b8 = E.wfb[u][8];
-        for (int r = 0; r < nrows; r++)
-          if (E.rOther[r] == u) {
-            const double fr = E.rF[r];
-            b6 += (float)((double)E.rOu[r][0] * fr); b7 += (float)((double)E.rOu[r][1] * fr); b8 += (float)((double)E.rOu[r][2] * fr);
-          }
-        E.wfb[u][6] = b6; E.wfb[u][7] = b7; E.wfb[u][8] = b8;
-      }
-      __syncthreads();
     } else {
-    // ---- projected Gauss-Seidel, row by row (an env with more than 32 rows): the dot product J.qacc across the lanes ---
-    if (sub > 0) {
-      // warm start: normal / limit rows first, then the friction rows inside +-mu x their normal row's force
-      float raw[2] = {0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int r = u + 32 * t;
-        if (r < nrows && E.rA[r] > 0 && E.rKey[r] != 0) {
-          const uint32_t key = E.rKey[r];
-          for (int q = 0; q < E.wsN; q++) raw[t] = E.wsKey[q] == key ? E.wsF[q] : raw[t];
-        }
-        if (r < nrows && E.rParent[r] < 0) E.rF[r] = (double)fmaxf(raw[t], 0.f);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        const int r = u + 32 * t;
-        if (r < nrows && E.rParent[r] >= 0) {
-          const float b = E.rMu[r] * (float)E.rF[E.rParent[r]];
-          E.rF[r] = (double)fminf(fmaxf(raw[t], -b), b);
-        }
-      }
-      __syncthreads();
-      if (u < DG_NV) {
-        double q = qacc_u;
-#pragma unroll 1
-        for (int r = 0; r < nrows; r++) q += (double)E.rW[r][u] * E.rF[r];
-        qacc_u = q;
-      }
-      if (u < NBODY) {
-        float b6 = E.wfb[u][6], b7 = E.wfb[u][7], b8 = E.wfb[u][8];
-        for (int r = 0; r < nrows; r++)
-          if (E.rOther[r] == u) {
-            const double fr = E.rF[r];
-            b6 += (float)((double)E.rOu[r][0] * fr); b7 += (float)((double)E.rOu[r][1] * fr); b8 += (float)((double)E.rOu[r][2] * fr);
-          }
-        E.wfb[u][6] = b6; E.wfb[u][7] = b7; E.wfb[u][8] = b8;
-      }
-      __syncthreads();
+      // an env with more than 32 rows (rare: a body deep inside the task box touches several of its geoms): the two envs
+      // take turns on all 64 lanes.  Three barriers per row update made such a wavefront the kernel's tail (13 ms).
+      const int n0 = __shfl(nrows, 0), n1 = DC_EPW == 2 ? __shfl(nrows, 32) : 0;
+      dc_pgs_wide(0, lane, n0, iters, sub > 0);
+      if (DC_EPW == 2) dc_pgs_wide(1, lane, n1, iters, sub > 0);
     }
+    __syncthreads();
+    DCC(DCY_PGS);
+    if (u < DG_NV) {
+      double q = qacc_u;
 #pragma unroll 1
-    for (int it = 0; it < iters; it++)
-#pragma unroll 1
-      for (int r = 0; r < nmax; r++) {
-        const bool on = r < nrows;
-        const int rr = on ? r : 0;
-        // J.qacc: partial products to LDS, every lane sums the 19 (reads issued together; a 5-step
-        // butterfly of cross-lane permutes costs three times the latency)
-        if (u < DG_NV) E.col[u] = on ? (double)E.rJ[rr][u] * qacc_u : 0.0;
-        __syncthreads();
-        double acc = 0;
-#pragma unroll
-        for (int k = 0; k < DG_NV; k++) acc += E.col[k];
-        const int other = on ? (int)E.rOther[rr] : -1;
-        if (other >= 0) {
-          const float* B = E.wfb[other];
-          acc += (double)((B[6] - B[8] * E.rOry[rr]) * E.rOd[rr][0] + (B[7] + B[8] * E.rOrx[rr]) * E.rOd[rr][1]);
-        }
-        const double A = E.rA[rr], f = E.rF[rr];
-        double df = 0;
-        if (on && A > 0) {
-          double fnew = f + (E.rAref[rr] - acc - E.rReg[rr] * f) * E.rInv[rr];
-          double lo = 0, hi = 1e30;
-          const int par = E.rParent[rr];
-          if (par >= 0) { const double fn = E.rF[par]; lo = -(double)E.rMu[rr] * fn; hi = (double)E.rMu[rr] * fn; }
-          if (fnew < lo) fnew = lo;
-          if (fnew > hi) fnew = hi;
-          df = fnew - f;
-        }
-        __syncthreads();   // every lane has read f / the body accelerations of this row
-        if (df != 0) {
-          if (u < DG_NV) qacc_u += (double)E.rW[rr][u] * df;
-          if (u == 0) {
-            E.rF[rr] = f + df;
-            if (other >= 0) {
-              float* B = E.wfb[other];
-              B[6] += (float)((double)E.rOu[rr][0] * df); B[7] += (float)((double)E.rOu[rr][1] * df); B[8] += (float)((double)E.rOu[rr][2] * df);
-            }
-          }
-        }
-        __syncthreads();
-      }
+      for (int r = 0; r < nrows; r++) q += (double)E.rW[r][u] * E.rF[r];
+      qacc_u = q;
     }
+    if (u < NBODY) {   // planar bodies: accelerations from the rows that act on them
+      float b6 = E.wfb[u][6], b7 = E.wfb[u][7], b8 = E.wfb[u][8];
+      for (int r = 0; r < nrows; r++)
+        if (E.rOther[r] == u) {
+          const double fr = E.rF[r];
+          b6 += (float)((double)E.rOu[r][0] * fr); b7 += (float)((double)E.rOu[r][1] * fr); b8 += (float)((double)E.rOu[r][2] * fr);
+        }
+      E.wfb[u][6] = b6; E.wfb[u][7] = b7; E.wfb[u][8] = b8;
+    }
+    __syncthreads();
     if (u < DG_NV) E.qacc[u] = qacc_u;
     if (u < 8) {
       double t = 0;

@@ -22,19 +22,22 @@ from oracle_lib import Oracle
 
 class OracleRun:
   """CPU stand-in with DeviceRun's interface."""
-  def __init__(self, task, envs, device, rank):
+  def __init__(self, task, envs, device, rank, robot='point'):
     self.o = Oracle()
-    rf, ri = bench.build_records(task, envs, rank)
+    rf, ri = bench.build_records(task, envs, rank, robot=robot)
+    self.rid, self.nu, self.od = {'point': (0, 2, 60), 'car': (1, 2, 72), 'doggo': (2, 12, 104)}[robot]
+    self.robot = robot
     self.ids = ri[:, 12].copy()
+    self.tasks = sorted(set(int(x) for x in ri[:, 0]))
     self.arr = self.o.make_batch(rf, ri)
     self.envs, self.t, self.rank = envs, 0, rank
-    self.acts = np.stack([[self.o.actions((666, 0), int(i), s, 2) for i in self.ids] for s in range(2)])
+    self.acts = np.stack([[self.o.actions((666, 0), int(i), s, self.nu) for i in self.ids] for s in range(2)])
     self.ms, self.n = 0.0, 0
   def burn_in(self, steps): self.run(steps)
   def run(self, steps):
     for _ in range(steps):
       t0 = time.perf_counter()
-      self.out = self.o.step_batch(self.arr, 0, self.acts[self.t %% 2], key=(666, 0))
+      self.out = self.o.step_batch(self.arr, self.rid, self.acts[self.t %% 2], key=(666, 0), obs_dim=self.od)
       self.ms += (time.perf_counter() - t0) * 1e3; self.n += 1; self.t += 1
       if self.rank == 1: time.sleep(0.002)   # a slower rank: the max over ranks must see it
   def wait(self): pass
@@ -42,12 +45,12 @@ class OracleRun:
   def kernel_time_ms(self): return (self.ms / max(self.n, 1), self.n)
   def stats(self): return float(self.out[2].mean()), int(self.out[3].sum()), bool(np.isfinite(self.out[0]).all())
   def close(self):
-    json.dump({'rank': self.rank, 'ids': [int(self.ids[0]), int(self.ids[-1])], 'steps': self.t},
-              open(os.path.join(%(out)r, 'rank%%d.json' %% self.rank), 'w'))
+    json.dump({'rank': self.rank, 'ids': [int(self.ids[0]), int(self.ids[-1])], 'steps': self.t, 'tasks': self.tasks},
+              open(os.path.join(%(out)r, 'rank%%d_%%s.json' %% (self.rank, self.robot)), 'w'))
 
 lines = []
 bench.main(['--gpus', '2', '--steps', '6', '--warmup', '2', '--burn-in', '1', '--envs', '48',
-            '--no-cpu-baseline', '--no-c2'], run_factory=OracleRun, emit=lines.append)
+            '--no-cpu-baseline', '--no-c2', '--c4-envs', '12', '--c4-steps', '2'], run_factory=OracleRun, emit=lines.append)
 if int(os.environ['RANK']) == 0:
   open(os.path.join(%(out)r, 'line.json'), 'w').write('\n'.join(lines))
 else:
@@ -85,10 +88,19 @@ def test_two_rank_gloo_bench(tmp_path):
     assert k in res
   assert set(res['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
   # shards are disjoint contiguous env-id ranges and every rank ran burn-in + warmup + K steps
-  r0 = json.loads((tmp_path / 'rank0.json').read_text())
-  r1 = json.loads((tmp_path / 'rank1.json').read_text())
+  r0 = json.loads((tmp_path / 'rank0_point.json').read_text())
+  r1 = json.loads((tmp_path / 'rank1_point.json').read_text())
   assert r0['ids'] == [0, 47] and r1['ids'] == [48, 95]
   assert r0['steps'] == r1['steps'] == 1 + 2 + 6
+  # BASELINE config 4 is the config that names 8 GPUs: the sharded Doggo / multitask line is part of every --gpus N run
+  c4 = res['c4_doggo_multitask']
+  assert c4['n_gpus'] == 2 and c4['envs_per_gpu'] == 12 and c4['global_envs'] == 24 and c4['scaling'] == 'weak'
+  assert c4['env_id_ranges_per_rank'] == [[0, 12], [12, 24]] and len(c4['kernel_ms_per_rank']) == 2
+  assert abs(c4['value'] - 24 * 2 / (c4['ms_per_step'] * 2e-3)) < 1e-6 * c4['value'] and c4['ms_per_step'] >= 2.0
+  d0 = json.loads((tmp_path / 'rank0_doggo.json').read_text())
+  d1 = json.loads((tmp_path / 'rank1_doggo.json').read_text())
+  assert d0['ids'] == [0, 11] and d1['ids'] == [12, 23] and d0['steps'] == d1['steps'] == 20 + 5 + 2
+  assert len(set(d0['tasks']) | set(d1['tasks'])) >= 5, 'the multitask sampler mixes the tasks over the shards'
 
 
 def test_shard_ranges():
