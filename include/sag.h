@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAG_ABI_VERSION 3
+#define SAG_ABI_VERSION 4
 
 /* ---- capacities (maxima over the reference's task set: Task.obstacles) ---- */
 #define SAG_MAX_HAZARDS 9  /* tasks/go_to_goal.py:83-84  [9,10,0,1]          */
@@ -205,6 +205,14 @@ int sag_step(sag_ctx* ctx, const float* actions, const float* noise,
              const uint32_t* tape, int32_t tape_len, int32_t nstep, float* obs,
              float* reward, uint8_t* cost, uint8_t* done, uint8_t* goal_met,
              int32_t* tape_used);
+
+/* External contact results for the NEXT step with nstep == 0 (one-shot; replay of recorded episodes: the caller sets
+ * the poses with sag_set_state and supplies what the physics would have reported).  Replaces, per env, the outcome of
+ * MujocoBridge.robot_contacts on the final state (mujoco_bridge.py:177-191): cost_contacts[i] = number of contacts
+ * robot geom <-> obstacle geom (world.py:146; -1 = keep the device's own geometric result for this env),
+ * btn_mask[i] = buttons the robot touches (tasks/press_buttons.py:51, tasks/collect.py:32).  Host arrays [n_envs];
+ * NULL, NULL clears a pending set.  A step with nstep != 0 ignores and clears it. */
+int sag_set_ext_contacts(sag_ctx* ctx, const int32_t* cost_contacts, const uint32_t* btn_mask);
 
 /* Device-buffer step for learners that live on the GPU: same semantics, all
  * pointers are device pointers on ctx's device (or NULL as above), enqueued on

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SAG_LIB overrides the library file (A/B builds of the same ABI during kernel tuning)
 LIB_PATH = os.environ.get('SAG_LIB') or os.path.join(_HERE, 'libsag.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_HAZARDS, MAX_VASES, MAX_PILLARS, MAX_BUTTONS, MAX_NU = 9, 10, 2, 6, 12
 REC_FLOATS, REC_INTS = 184, 16
 
@@ -30,7 +30,7 @@ ROBOT_IDS = {'point': 0, 'car': 1, 'doggo': 2}
 EXPORTS = [
     'sag_robot_info', 'sag_create', 'sag_destroy', 'sag_last_error', 'sag_set_layout',
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
-    'sag_observe', 'sag_lidar_cost', 'sag_lidar_cost_device', 'sag_set_seed', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
+    'sag_observe', 'sag_set_ext_contacts', 'sag_lidar_cost', 'sag_lidar_cost_device', 'sag_set_seed', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
     'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device', 'sag_render', 'sag_render_device', 'sag_debug_doggo_coop',
     'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts'
 ]
@@ -83,6 +83,7 @@ def load():
   lib.sag_step_device.argtypes = [vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
   lib.sag_wait.argtypes = [vp]
   lib.sag_observe.argtypes = [vp, fp]
+  lib.sag_set_ext_contacts.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
   lib.sag_lidar_cost.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, bp, C.c_float, fp, ip, bp]
   lib.sag_lidar_cost_device.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_float, vp, vp, vp]
   lib.sag_set_seed.argtypes = [vp, C.c_uint64]
@@ -263,6 +264,17 @@ class Context:
   def observe(self):
     self._check(self.lib.sag_observe(self.h, _ptr(self._obs, C.c_float)), 'sag_observe')
     return self._obs.copy()
+
+  def set_ext_contacts(self, cost_contacts, btn_mask):
+    """Contact results of the final state for the next step(nstep=0) (replayed episodes): per env the number of
+    robot <-> obstacle contacts (-1: keep the device's own) and the mask of touched buttons
+    (mujoco_bridge.py:177-191).  None, None clears a pending set."""
+    if cost_contacts is None and btn_mask is None:
+      self._check(self.lib.sag_set_ext_contacts(self.h, None, None), 'sag_set_ext_contacts')
+      return
+    cc = np.ascontiguousarray(cost_contacts, np.int32).reshape(self.n_envs)
+    bm = np.ascontiguousarray(btn_mask, np.uint32).reshape(self.n_envs)
+    self._check(self.lib.sag_set_ext_contacts(self.h, _ptr(cc, C.c_int32), _ptr(bm, C.c_uint32)), 'sag_set_ext_contacts')
 
   def lidar_cost(self, robot, points, group, hazard_size=0.2, want_bins=True):
     robot = np.ascontiguousarray(robot, np.float32).reshape(-1, 3)

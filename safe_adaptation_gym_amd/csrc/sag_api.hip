@@ -84,6 +84,7 @@ struct sag_ctx {
   float* d_act = nullptr; float* d_noise = nullptr; uint32_t* d_tape = nullptr; size_t tape_cap = 0;
   float* d_obs = nullptr; float* d_rew = nullptr; uint8_t* d_cost = nullptr; uint8_t* d_done = nullptr;
   uint8_t* d_met = nullptr; int32_t* d_used = nullptr;
+  int32_t* d_ext_cc = nullptr; uint32_t* d_ext_btn = nullptr; bool ext_pending = false;   // sag_set_ext_contacts
   // generic buffers for sag_lidar_cost
   void* scratch = nullptr; size_t scratch_bytes = 0;
   bool have_layout = false;
@@ -275,6 +276,10 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
   a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr;
   a.hot = nullptr; a.hot_haz = nullptr;
+  // external contact results: for the one step with nstep == 0 that follows sag_set_ext_contacts
+  const bool use_ext = c->ext_pending && !observe_only && a.nstep == 0;
+  a.ext_cc = use_ext ? c->d_ext_cc : nullptr; a.ext_btn = use_ext ? c->d_ext_btn : nullptr;
+  if (!observe_only) c->ext_pending = false;
   {
     // single-launch form: aim for four wavefronts per CU (Doggo: one - only one fits its LDS working
     // set), down to 16 (Doggo 8) envs per wavefront (tools/epw_sweep.py: Car 4096 envs 0.58 -> 0.48 ms)
@@ -524,7 +529,8 @@ int sag_destroy(sag_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
-                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr, c->d_hot};
+                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr, c->d_hot,
+                  c->d_ext_cc, c->d_ext_btn};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);
   if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -699,6 +705,23 @@ int sag_step(sag_ctx* c, const float* actions, const float* noise, const uint32_
   if (goal_met) HIPCHK(c, hipMemcpyAsync(goal_met, c->d_met, N, hipMemcpyDeviceToHost, c->stream));
   if (tape_used) HIPCHK(c, hipMemcpyAsync(tape_used, c->d_used, N * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SAG_OK;
+}
+
+int sag_set_ext_contacts(sag_ctx* c, const int32_t* cost_contacts, const uint32_t* btn_mask) {
+  if (!c) return SAG_ERR_ARG;
+  if (!cost_contacts && !btn_mask) { c->ext_pending = false; return SAG_OK; }
+  if (!cost_contacts || !btn_mask) return fail(c, SAG_ERR_ARG, "sag_set_ext_contacts: both arrays or neither");
+  const size_t N = (size_t)c->N;
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  if (!c->d_ext_cc) {
+    HIPCHK(c, hipMalloc(&c->d_ext_cc, N * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->d_ext_btn, N * sizeof(uint32_t)));
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_ext_cc, cost_contacts, N * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_ext_btn, btn_mask, N * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the host arrays are the caller's: do not keep reading them
+  c->ext_pending = true;
   return SAG_OK;
 }
 

@@ -125,6 +125,8 @@ struct StepArgs {
   int32_t* count_next;    //   (nullptr: not built; the host then runs k_compact)
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
   int32_t observe_only;   // 1: sag_observe (no noise/physics/reward/cost)
+  const int32_t* ext_cc;  // sag_set_ext_contacts: [N] contact counts (>= 0: replaces the geometric result) or nullptr
+  const uint32_t* ext_btn;  // [N] touched-button masks
   float* hot;             // split form: [N][HOT_FLOATS] env-major copy of what the busy prologue reads, or nullptr
   const float* hot_haz;   // [N][20]: the five hazard groups env-major (static: written by k_hot_refresh only)
   double* DR;             // Doggo, cooperative form: per-env result block of k_doggo_physics [N][DR_STRIDE]
@@ -1651,6 +1653,10 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   }
 
   }  // !DOGGO
+  if (p.ext_cc) {   // replayed episode: the contact results of the final state come from the caller (sag_set_ext_contacts)
+    const int32_t v = p.ext_cc[i];
+    if (v >= 0) { cost_contacts = v; btn_mask = p.ext_btn[i]; }
+  }
   CYC(CY_ROBOT);
   // ---- write back dynamic state -------------------------------------------------
   const float boxx = LP(LS_X, BOX_ID), boxy = LP(LS_Y, BOX_ID);

@@ -343,7 +343,7 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
 # ----------------------------------------------------------------------------------
 # free-running comparison: no resynchronisation, the drift is observed and bounded
 # ----------------------------------------------------------------------------------
-DRIFT_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r02_free_running_drift.txt')
+DRIFT_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r03_free_running_drift.txt')
 
 
 @pytest.mark.parametrize('robot,task', [('point', 'go_to_goal'), ('car', 'push_box'), ('doggo', 'go_to_goal')])
@@ -358,7 +358,10 @@ def test_free_running_drift(nat, oracle, robot, task):
   stay statistically identical (cost-flag and goal-met agreement).  Figures go to gpurun_out/ and DESIGN.md."""
   rid = {'point': 0, 'car': 1, 'doggo': 2}[robot]
   nu, od = gu.ROBOT_NU[robot], gu.ROBOT_OBS[robot]
-  n, T = (64 if robot == 'doggo' else 192), 200
+  # Doggo: 2048 envs (VERDICT r2: at 64 envs the standard error of the cost rate was half the rate); the oracle
+  # legs run on the host's cores (envs are independent)
+  n, T = (2048 if robot == 'doggo' else 192), 200
+  oracle.lib.sago_set_threads(min(16, len(os.sched_getaffinity(0))))
   rf, ri = bu.sample_records_native(robot, task, n, seed=4242)
   ctx = nat.Context(robot, n, seed=99)
   ctx.set_layout(rf, ri)
@@ -415,9 +418,13 @@ def test_free_running_drift(nat, oracle, robot, task):
   assert q(199)[0] <= 3 * np.median(rpos[-1]) + 1e-3, 'drift beyond what fp32 state storage alone causes in the oracle'
   if robot != 'doggo':
     assert q(199)[0] < 1e-3, 'the median env should not separate from its oracle twin'
-  assert cost_agree > (0.93 if robot == 'doggo' else 0.99)
-  assert abs(per_env.mean()) < max(0.01, 4 * cost_se + 0.002), 'cost rates differ beyond the env-to-env scatter'
+  assert cost_agree > (0.97 if robot == 'doggo' else 0.99)
+  if robot == 'doggo':
+    assert abs(per_env.mean()) < 3 * cost_se, f'cost rates differ by {per_env.mean():.5f}: more than 3 standard errors ({cost_se:.5f}) of the env-to-env scatter'
+  else:
+    assert abs(per_env.mean()) < max(0.01, 4 * cost_se + 0.002), 'cost rates differ beyond the env-to-env scatter'
   assert met_agree > 0.995
+  oracle.lib.sago_set_threads(1)
   ctx.close()
 
 
@@ -428,70 +435,66 @@ GOAL_FAMILY = ['go_to_goal', 'go_to_goal_scarce', 'go_to_goal_motor', 'go_to_goa
                'catch_goal', 'unsupervised']
 
 
-# Car / Doggo reference episodes (oracle/gen_golden.py:729-732): the goal-family ones replay like the Point ones;
-# push_box (car) and press_buttons (doggo) depend on contacts for more than `cost`, so there the device is
-# checked on everything that does not (lidar with the reference's grouping, sensor columns, RNG position)
-DEVICE_EPISODES = [('point', t) for t in GOAL_FAMILY] + [('car', 'go_to_goal'), ('car', 'push_box'),
-                                                         ('doggo', 'catch_goal'), ('doggo', 'press_buttons')]
+# Car / Doggo reference episodes (oracle/gen_golden.py:729-732).  push_box (car) and press_buttons (doggo) depend on
+# contacts for more than `cost` (button presses): the reference's own contact list of every step goes in through
+# sag_set_ext_contacts, so reward, goal-met, button state machine and RNG position are all checked against the
+# reference (round 2 copied the task state from the fixture and skipped those).
+DEVICE_EPISODES = gu.episode_keys()   # all 18: the 14 Point tasks, car go_to_goal / push_box, doggo catch_goal / press_buttons
 
 
 @pytest.mark.parametrize('robot,task', DEVICE_EPISODES, ids=lambda v: v)
 def test_golden_episode_on_device(nat, robot, task):
-  """Reference-generated episodes replayed on the device with the physics off (nstep = 0): the poses are the
-  fixture's, everything else is computed by the kernels.  For the goal family nothing but `cost` depends on
-  contacts, so reward, lidar, goal resampling and RNG consumption are checked against the reference
-  directly; for every robot the observation pins the reference's column order (60 / 72 / 104,
-  safe_adaptation_gym.py:225-237)."""
+  """Reference-generated episodes replayed on the device with the physics off (nstep = 0): the poses and the
+  contact list of every step are the fixture's (sag_set_state, sag_set_ext_contacts: what MuJoCo computed in the
+  reference), everything else is computed by the kernels and checked against the reference directly: reward, cost,
+  goal-met, lidar (with the reference's grouping), goal resampling, button / collect state, RNG consumption; for every
+  robot the observation pins the reference's column order (60 / 72 / 104, safe_adaptation_gym.py:225-237)."""
   from oracle_lib import F_GOAL, F_LAST
   ep = [e for e in gu.load_json_gz('episodes.json.gz') if e['robot'] == robot and e['task'] == task][0]
   names = ep['names']
   nu, od = gu.ROBOT_NU[robot], gu.ROBOT_OBS[robot]
   cols, icols = gu.PINNED_SENSOR_COLS[robot], gu.INIT_PINNED_COLS[robot]
-  goal_family = task in GOAL_FAMILY
   rf, ri = gu.episode_init_record(ep)
   ctx = nat.Context(robot, 1)
   ctx.set_state(rf[None].astype(np.float32), ri[None])
   rs = gu.rs_from_dump(ep['rs_state'])
-  n_lidar_checked = 0
   obs0 = ctx.observe()[0]
   assert obs0.shape == (od,) and len(ep['init_obs']) == od
   np.testing.assert_allclose(obs0[:48], ep['init_obs'][:48], rtol=0, atol=OBS_TOL)
   np.testing.assert_allclose(obs0[icols], np.array(ep['init_obs'])[icols], rtol=0, atol=1e-6)
+  n_met = n_cost = 0
   for t, st in enumerate(ep['steps']):
     noise = rs.normal(size=nu)
     tape = gu.rs_words(gu.rs_copy(rs), 4096)
     rf, ri = ctx.get_state()
     rf = rf[0].astype(np.float64)
-    gu.set_poses(rf, names, st['pos'], yaw=st['robot_yaw'], v0=st['robot_v0'], wz=st['sensors']['gyro'][2])
+    # poses only: the task state (goal, last distances, button state, timers) stays the device's own
+    gu.set_poses(rf, names, st['pos'], yaw=st['robot_yaw'], v0=st['robot_v0'], wz=st["sensors"]["gyro"][2])
     gu.set_robot_planar(rf, robot, st['robot_yaw'], st['sensors']['gyro'][2])
-    if not goal_family:
-      # task state that the reference derives from ITS contact list is taken from the fixture (the device's
-      # own contacts are geometric); the lidar grouping that follows from it is what is under test
-      gu.set_task_state(rf, ri[0], ep['steps'][t - 1]['task_state'] if t else ep['init']['task_state'])
-      if 'goal' in names:
-        rf[F_GOAL:F_GOAL + 2] = (ep['steps'][t - 1]['pos'] if t else [ep['init']['body_pos'][k] for k in names])[names.index('goal')][:2]
-    # (goal family: the goal is task state - keep the device's own, resampled, goal, not the fixture's)
     ctx.set_state(rf[None].astype(np.float32), ri)
+    cc, mask = gu.contact_inputs(robot, st['contacts'])
+    ctx.set_ext_contacts([cc], [mask])
     obs, rew, cost, done, met, used = ctx.step(np.array([st['action']], np.float32), noise[None], tape[None], nstep=0)
-    np.testing.assert_allclose(obs[0, cols], np.array(st['obs'])[cols], rtol=0, atol=1e-5, err_msg=f'step {t}')
-    if not goal_family:
-      # the step's own reward / goal-met follow the device's (geometric) contacts, so only steps on which the
-      # reference had no task event compare further: the lidar, with the grouping the fixture's task state implies
-      if not (st['reward'][0] > 0.5 or met[0]):   # (+1 = box on goal / button pressed)
-        np.testing.assert_allclose(obs[0, :48], st['obs'][:48], rtol=0, atol=OBS_TOL, err_msg=f'step {t}')
-        n_lidar_checked += 1
-      continue
     gu.rs_words(rs, int(used[0]))
     assert gu.rs_probe(rs) == st['rs_probe'], f'RNG position diverged at step {t}'
     nr = len(st['reward'])
-    np.testing.assert_allclose(rew[0, :nr], st['reward'], rtol=0, atol=3e-6, err_msg=f'step {t}')
-    np.testing.assert_allclose(obs[0, :48], st['obs'][:48], rtol=0, atol=OBS_TOL, err_msg=f'step {t}')
-    rf2, _ = ctx.get_state()
-    g = st['pos'][names.index('goal')]
-    np.testing.assert_allclose(rf2[0, F_GOAL:F_GOAL + 2], g[:2], rtol=0, atol=1e-6)
-    np.testing.assert_allclose(rf2[0, F_LAST], st['task_state']['_last_goal_distance'], rtol=0, atol=1e-6)
-  if not goal_family:
-    assert n_lidar_checked >= 10
+    np.testing.assert_allclose(rew[0, :nr], st['reward'], rtol=0, atol=3e-6, err_msg=f'reward step {t}')
+    assert int(cost[0]) == int(st['cost']), f'cost step {t}'
+    assert int(done[0]) == int(st['done'])
+    np.testing.assert_allclose(obs[0, :48], st['obs'][:48], rtol=0, atol=OBS_TOL, err_msg=f'lidar step {t}')
+    np.testing.assert_allclose(obs[0, cols], np.array(st['obs'])[cols], rtol=0, atol=1e-5, err_msg=f'sensors step {t}')
+    # task state after the step = the reference's
+    rf2, ri2 = ctx.get_state()
+    ts = st['task_state']
+    exp_f, exp_i = rf2[0].astype(np.float64).copy(), ri2[0].copy()
+    gu.set_task_state(exp_f, exp_i, ts)
+    np.testing.assert_array_equal(ri2[0], exp_i, err_msg=f'task ints step {t}')
+    np.testing.assert_allclose(rf2[0], exp_f, rtol=0, atol=2e-6, err_msg=f'task floats step {t}')
+    if 'goal' in names:
+      g = st['pos'][names.index('goal')]
+      np.testing.assert_allclose(rf2[0, F_GOAL:F_GOAL + 2], g[:2], rtol=0, atol=1e-6, err_msg=f'goal step {t}')
+    n_met += int(met[0]); n_cost += int(cost[0])
+  assert n_met > 0, 'the fixture should exercise goal-met events'
   ctx.close()
 
 

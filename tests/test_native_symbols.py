@@ -64,7 +64,9 @@ def test_product_never_imports_the_oracle():
     for f in files:
       if f.endswith(('.py', '.hip', '.hpp', '.h', '.cpp')):
         txt = open(os.path.join(dp, f)).read()
-        assert 'oracle' not in txt.lower() or f in ('sag_device.hpp',), f'{f} mentions the oracle'
+        if not f.endswith('.py'):   # device / host C++: comments may cite the specification's file, code may not
+          txt = re.sub(r'//[^\n]*', '', re.sub(r'/\*.*?\*/', '', txt, flags=re.S))
+        assert 'oracle' not in txt.lower(), f'{f} references the oracle outside a comment'
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

@@ -15,5 +15,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- python3 $ARGS > /
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- python3 $ARGS > /dev/null 2> $OUT/pmc4.err || true
 # fp64 operation counts (Doggo: flops per env-step for the fp64-vector roofline)
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 --output-format csv -d $OUT/pmc5 -- python3 $ARGS > /dev/null 2> $OUT/pmc5.err || true
-python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 --output-format csv -d $OUT/pmc6 -- python3 $ARGS > /dev/null 2> $OUT/pmc6.err || true
+# FULL=1 also writes profiles/kernels.json (what bench.py checks its roofline blocks against) for summary file $SUMMARY
+python3 tools/prof_summary.py $OUT ${FULL:+--json ${SUMMARY:-profiles/${TAG}_summary.txt}} > $OUT/summary.txt 2>&1 || true
 cat $OUT/summary.txt
