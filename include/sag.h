@@ -303,6 +303,30 @@ typedef struct sag_world_config {
 } sag_world_config;
 void sag_world_config_default(sag_world_config* cfg);
 
+/* What the sampler needs to know about a Task object (tasks/task.py:14-97): the host mirror builds one from the
+ * Task's own `obstacles`, `placement_extents`, `setup_placements()` and attributes (safe_adaptation_gym_amd/tasks), so a
+ * subclass that overrides them changes the layouts; `task_id` selects the device-side per-step logic (compute_reward /
+ * set_mocaps / on-goal reset), which cannot be overridden from Python.  Rectangles are (xmin, ymin, xmax, ymax). */
+typedef struct sag_task_desc {
+  int32_t task_id;                       /* enum sag_task */
+  int32_t n_hazards, n_vases, n_pillars; /* Task.obstacles = [hazards, vases, gremlins (always 0), pillars] */
+  int32_t has_goal;                      /* a 'goal' placement, re-drawn by GoToGoal.reset (go_to_goal.py:50-80) */
+  int32_t box_kind;                      /* enum sag_box_kind; SAG_BOX_NONE: no task object */
+  int32_t box_yaw;                       /* build_world_config draws a yaw for it (push_box.py; not roll_rod / dribble_ball) */
+  int32_t box_at_robot;                  /* haul_box.py:17-18: after sampling the object sits at robot + (box_offset, 0) */
+  int32_t n_buttons;
+  int32_t button_reset;                  /* task.reset: 0 none, 1 rs.choice(n_buttons) + timer (press_buttons.py:71-77), 2 all active (collect.py) */
+  int32_t button_timer;                  /* BUTTON_TICKING_DELAY */
+  int32_t reserved;
+  double extents[4];                     /* Task.placement_extents */
+  double goal_keepout, box_keepout, button_keepout, box_offset;
+  double box_rect[4];                    /* all zero: the extents (placement None) */
+  double button_rect[4];
+  double gear, damping;                  /* point.xml variants (go_to_goal_motor.py, go_to_goal_damping.py) */
+} sag_task_desc;
+/* the descriptor of one of the reference's 14 tasks; returns SAG_ERR_ARG for an unknown id */
+int sag_task_desc_default(int32_t task_id, sag_task_desc* out);
+
 /* Replaces World.__init__ + sample_layout + _build_world_config + World.reset's host draws
  * (world.py:36-137,172-217; tasks' setup_placements/build_world_config/reset) for n envs on the
  * host cores.  Env j owns np.random.RandomState(seeds[j]) (exact legacy MT19937 stream, the
@@ -316,6 +340,13 @@ int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const in
                        const sag_world_config* cfg, int32_t first_episode, int32_t env_id0,
                        float* rec_f, int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos,
                        int32_t* mt_has_gauss, double* mt_gauss, int32_t* status, int32_t nthreads);
+/* The same with explicit task descriptors: env j uses descs[desc_of_env[j]] (n_descs of them).  sag_sample_layouts is
+ * this call with the 14 default descriptors and desc_of_env = task_ids.  SAG_ERR_ARG if a descriptor exceeds the
+ * record's capacity (SAG_MAX_HAZARDS / VASES / PILLARS / BUTTONS) or is inconsistent. */
+int sag_sample_layouts_desc(int32_t robot, int32_t n, const uint32_t* seeds, const sag_task_desc* descs, int32_t n_descs,
+                            const int32_t* desc_of_env, const sag_world_config* cfg, int32_t first_episode, int32_t env_id0,
+                            float* rec_f, int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos,
+                            int32_t* mt_has_gauss, double* mt_gauss, int32_t* status, int32_t nthreads);
 
 #ifdef __cplusplus
 }

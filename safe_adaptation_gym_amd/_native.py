@@ -32,7 +32,7 @@ EXPORTS = [
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
     'sag_observe', 'sag_set_ext_contacts', 'sag_lidar_cost', 'sag_lidar_cost_device', 'sag_set_seed', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
     'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device', 'sag_render', 'sag_render_device', 'sag_debug_doggo_coop',
-    'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts'
+    'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts', 'sag_sample_layouts_desc', 'sag_task_desc_default'
 ]
 
 
@@ -119,10 +119,45 @@ def robot_info(robot):
   return dict(nu=out[0], obs_dim=out[1], nstep=out[2], nq=out[3], nv=out[4], dt=dt.value)
 
 
+class TaskDesc(C.Structure):
+  """sag_task_desc (include/sag.h)."""
+  _fields_ = [(k, C.c_int32) for k in ('task_id', 'n_hazards', 'n_vases', 'n_pillars', 'has_goal', 'box_kind', 'box_yaw',
+                                        'box_at_robot', 'n_buttons', 'button_reset', 'button_timer', 'reserved')] + [
+      ('extents', C.c_double * 4), ('goal_keepout', C.c_double), ('box_keepout', C.c_double), ('button_keepout', C.c_double),
+      ('box_offset', C.c_double), ('box_rect', C.c_double * 4), ('button_rect', C.c_double * 4), ('gear', C.c_double),
+      ('damping', C.c_double)]
+
+  @classmethod
+  def from_dict(cls, d):
+    t = cls()
+    for k, v in d.items():
+      if isinstance(v, (list, tuple)):
+        setattr(t, k, (C.c_double * 4)(*v))
+      else:
+        setattr(t, k, v)
+    return t
+
+  def to_dict(self):
+    return {k: (list(getattr(self, k)) if k in ('extents', 'box_rect', 'button_rect') else getattr(self, k))
+            for k, _ in self._fields_ if k != 'reserved'}
+
+
+def task_desc_default(task_id):
+  """The descriptor the library holds for one of the reference's 14 tasks (what the Python Task classes are tested against)."""
+  lib = load()
+  lib.sag_task_desc_default.argtypes = [C.c_int32, C.POINTER(TaskDesc)]
+  t = TaskDesc()
+  if lib.sag_task_desc_default(int(task_id), C.byref(t)) != 0:
+    raise SagError(f'no task {task_id}')
+  return t.to_dict()
+
+
 def sample_layouts(robot, seeds, task_ids, config=None, first_episode=True, env_id0=0,
-                   want_rng=False, nthreads=None):
+                   want_rng=False, nthreads=None, descs=None):
   """Native reset path: records for len(seeds) envs, env j drawn with
   np.random.RandomState(seeds[j]) semantics.  config: dict over World.DEFAULT keys.
+  task_ids: one of the 14 reference tasks per env - or, with `descs` (a list of Task.descriptor() dicts), the index of
+  env j's descriptor in that list.
   Returns (rec_f, rec_i, status[, rng states as numpy RandomState set_state tuples])."""
   lib = load()
   seeds = np.ascontiguousarray(np.asarray(seeds, np.int64) % 2**32, np.uint32)
@@ -145,13 +180,16 @@ def sample_layouts(robot, seeds, task_ids, config=None, first_episode=True, env_
   g = np.zeros(n, np.float64) if want_rng else None
   if nthreads is None:
     nthreads = min(len(os.sched_getaffinity(0)), 16)
-  rc = lib.sag_sample_layouts(ROBOT_IDS[robot] if isinstance(robot, str) else robot, n,
-                              _ptr(seeds, C.c_uint32), _ptr(tids, C.c_int32), C.byref(cfg),
-                              int(first_episode), env_id0, _ptr(rf, C.c_float), _ptr(ri, C.c_int32),
-                              _ptr(key, C.c_uint32), _ptr(pos, C.c_int32), _ptr(hg, C.c_int32),
-                              _ptr(g, C.c_double), _ptr(status, C.c_int32), nthreads)
+  rid = ROBOT_IDS[robot] if isinstance(robot, str) else robot
+  tail = (C.byref(cfg), int(first_episode), env_id0, _ptr(rf, C.c_float), _ptr(ri, C.c_int32), _ptr(key, C.c_uint32),
+          _ptr(pos, C.c_int32), _ptr(hg, C.c_int32), _ptr(g, C.c_double), _ptr(status, C.c_int32), nthreads)
+  if descs is None:
+    rc = lib.sag_sample_layouts(rid, n, _ptr(seeds, C.c_uint32), _ptr(tids, C.c_int32), *tail)
+  else:
+    arr = (TaskDesc * len(descs))(*[TaskDesc.from_dict(d) for d in descs])
+    rc = lib.sag_sample_layouts_desc(rid, n, _ptr(seeds, C.c_uint32), arr, len(descs), _ptr(tids, C.c_int32), *tail)
   if rc < 0:
-    raise SagError(f'sag_sample_layouts failed ({rc})')
+    raise SagError(f'sag_sample_layouts failed ({rc}): a task descriptor exceeds the record capacity or is inconsistent')
   if want_rng:
     states = [('MT19937', key[j], int(pos[j]), int(hg[j]), float(g[j])) for j in range(n)]
     return rf, ri, status, states

@@ -86,7 +86,9 @@ struct MT {
   }
 };
 
-// ---- task tables (tasks/*.py: obstacles, placement_extents, setup_placements) ----------------
+// ---- the reference's 14 tasks as descriptors (tasks/*.py: obstacles, placement_extents, setup_placements,
+//      build_world_config, reset).  The Python host builds descriptors from its Task objects; this table serves callers
+//      that only have task ids (sag_sample_layouts) and is what the Python classes are tested against. ----------------
 struct TaskDef {
   int nH, nV, nP;
   double ext;        // placement_extents = (-ext, -ext, ext, ext)
@@ -122,24 +124,25 @@ constexpr int MAX_ITEMS = 1 + SAG_MAX_HAZARDS + SAG_MAX_VASES + SAG_MAX_PILLARS 
 
 struct Item {
   double x, y, keepout;
-  double rect;   // > 0: own rectangle +-rect; 0: the task extents
-  int kind;      // 0 robot 1 hazard 2 vase 3 pillar 4 goal 5 box 6 button
+  double rect[4];   // own rectangle; all zero: the task extents
+  int kind;         // 0 robot 1 hazard 2 vase 3 pillar 4 goal 5 box 6 button
 };
 
-// utils.draw_placement with one rectangle (no task has several): two uniforms
-inline void draw_xy(MT& rs, double half, double keepout, double& x, double& y) {
-  const double lo = -half + keepout, hi = half - keepout;
-  x = rs.uniform(lo, hi);
-  y = rs.uniform(lo, hi);
+inline bool no_rect(const double* r) { return r[0] == 0 && r[1] == 0 && r[2] == 0 && r[3] == 0; }
+
+// utils.draw_placement with one rectangle (no task has several): two uniforms over the rectangle shrunk by the keepout
+inline void draw_xy(MT& rs, const double* rect, double keepout, double& x, double& y) {
+  x = rs.uniform(rect[0] + keepout, rect[2] - keepout);
+  y = rs.uniform(rect[1] + keepout, rect[3] - keepout);
 }
 
 // World._sample_layout (world.py:191-217)
-bool try_layout(MT& rs, Item* it, int n, double ext, double margin) {
+bool try_layout(MT& rs, Item* it, int n, const double* ext, double margin) {
   for (int k = 0; k < n; k++) {
     bool placed = false;
     for (int t = 0; t < 1000 && !placed; t++) {
       double x, y;
-      draw_xy(rs, it[k].rect > 0 ? it[k].rect : ext, it[k].keepout, x, y);
+      draw_xy(rs, no_rect(it[k].rect) ? ext : it[k].rect, it[k].keepout, x, y);
       bool ok = true;
       for (int j = 0; j < k && ok; j++) {
         const double dx = x - it[j].x, dy = y - it[j].y;
@@ -152,9 +155,9 @@ bool try_layout(MT& rs, Item* it, int n, double ext, double margin) {
   return true;
 }
 
-int sample_one(int robot, int task_id, uint32_t seed, const sag_world_config& cfg, int first_episode,
+int sample_one(int robot, const sag_task_desc& T, uint32_t seed, const sag_world_config& cfg, int first_episode,
                int env_id, float* rf, int32_t* ri, MT& rs) {
-  const TaskDef& T = TASKS[task_id];
+  const int task_id = T.task_id;
   const int nu = robot == SAG_ROBOT_DOGGO ? 12 : 2;
   rs.seed(seed);
   // World.__init__ (world.py:72-76): Cauchy ctrl scale, once per Task instance
@@ -172,16 +175,22 @@ int sample_one(int robot, int task_id, uint32_t seed, const sag_world_config& cf
   // placements in the reference's dict order: robot, hazards, vases, pillars, task bodies
   Item it[MAX_ITEMS];
   int n = 0;
-  it[n++] = {0, 0, cfg.robot_keepout, 0, 0};
-  for (int k = 0; k < T.nH; k++) it[n++] = {0, 0, k_haz, 0, 1};
-  for (int k = 0; k < T.nV; k++) it[n++] = {0, 0, k_vase, 0, 2};
-  for (int k = 0; k < T.nP; k++) it[n++] = {0, 0, k_pil, 0, 3};
+  auto add = [&](double keepout, const double* rect, int kind) {
+    Item& I = it[n++];
+    I.x = I.y = 0; I.keepout = keepout; I.kind = kind;
+    for (int q = 0; q < 4; q++) I.rect[q] = rect ? rect[q] : 0.0;
+  };
+  const double goal_rect[4] = {-GOAL_RECT, -GOAL_RECT, GOAL_RECT, GOAL_RECT};
+  add(cfg.robot_keepout, nullptr, 0);
+  for (int k = 0; k < T.n_hazards; k++) add(k_haz, nullptr, 1);
+  for (int k = 0; k < T.n_vases; k++) add(k_vase, nullptr, 2);
+  for (int k = 0; k < T.n_pillars; k++) add(k_pil, nullptr, 3);
   int i_goal = -1, i_box = -1, i_btn = -1;
-  if (T.goal) { i_goal = n; it[n++] = {0, 0, GOAL_KEEPOUT, GOAL_RECT, 4}; }
-  if (T.box_kind) { i_box = n; it[n++] = {0, 0, T.box_keepout, T.box_rect, 5}; }
-  if (T.nB) { i_btn = n; for (int k = 0; k < T.nB; k++) it[n++] = {0, 0, BUTTONS_KEEPOUT, T.btn_rect, 6}; }
+  if (T.has_goal) { i_goal = n; add(T.goal_keepout, goal_rect, 4); }
+  if (T.box_kind) { i_box = n; add(T.box_keepout, T.box_rect, 5); }
+  if (T.n_buttons) { i_btn = n; for (int k = 0; k < T.n_buttons; k++) add(T.button_keepout, T.button_rect, 6); }
   bool ok = false;
-  for (int a = 0; a < 10000 && !ok; a++) ok = try_layout(rs, it, n, T.ext, margin);
+  for (int a = 0; a < 10000 && !ok; a++) ok = try_layout(rs, it, n, T.extents, margin);
   if (!ok) return -1;  // ResamplingError
   // _build_world_config (world.py:108-137): yaw draws
   const double two_pi = 2 * 3.14159265358979323846;
@@ -190,49 +199,49 @@ int sample_one(int robot, int task_id, uint32_t seed, const sag_world_config& cf
   for (int k = 0; k < n; k++) yaw[k] = 0;
   for (int k = 1; k < n; k++)
     if (it[k].kind >= 1 && it[k].kind <= 3) yaw[k] = rs.uniform(0, two_pi);
-  if (task_id == SAG_TASK_HAUL_BOX) {  // haul_box.py:17-18: box 3 box sizes ahead (world +x)
-    it[i_box].x = it[0].x + 0.2 * 3.0;
+  if (i_box >= 0 && T.box_at_robot) {  // haul_box.py:17-18: box 3 box sizes ahead (world +x)
+    it[i_box].x = it[0].x + T.box_offset;
     it[i_box].y = it[0].y;
   }
   if (i_goal >= 0) yaw[i_goal] = rs.uniform(0, two_pi);
   if (i_box >= 0 && T.box_yaw) yaw[i_box] = rs.uniform(0, two_pi);
-  for (int k = 0; k < T.nB; k++) yaw[i_btn + k] = rs.uniform(0, two_pi);
+  for (int k = 0; k < T.n_buttons; k++) yaw[i_btn + k] = rs.uniform(0, two_pi);
   // task.reset (App. B.5)
   int goal_button = 0, btn_timer = 0;
   uint32_t active_mask = 0;
   if (i_goal >= 0) {  // GoToGoal._resample_goal_position (go_to_goal.py:59-80)
-    double half = GOAL_RECT;
+    double rect[4] = {-GOAL_RECT, -GOAL_RECT, GOAL_RECT, GOAL_RECT};
     bool found = false;
     for (int t = 0; t < 10000 && !found; t++) {
       double gx, gy;
-      draw_xy(rs, half, GOAL_KEEPOUT, gx, gy);
+      draw_xy(rs, rect, T.goal_keepout, gx, gy);
       bool good = true;
       for (int j = 0; j < n && good; j++) {
         if (j == i_goal) continue;
         const double dx = gx - it[j].x, dy = gy - it[j].y;
-        if (std::sqrt(dx * dx + dy * dy) < it[j].keepout + GOAL_KEEPOUT) good = false;
+        if (std::sqrt(dx * dx + dy * dy) < it[j].keepout + T.goal_keepout) good = false;
       }
       if (good) { it[i_goal].x = gx; it[i_goal].y = gy; found = true; }
-      else half *= 1.01;
+      else for (int q = 0; q < 4; q++) rect[q] *= 1.01;   // utils.increase_extents
     }
     if (!found) return -2;
   }
-  if (task_id == SAG_TASK_PRESS_BUTTONS || task_id == SAG_TASK_PRESS_BUTTONS_SCARCE) {
-    goal_button = (int)rs.bounded(3);  // rs.choice(4)
-    btn_timer = 5;
+  if (T.button_reset == 1) {
+    goal_button = (int)rs.bounded((uint32_t)T.n_buttons - 1);  // rs.choice(n_buttons)
+    btn_timer = T.button_timer;
   }
-  if (task_id == SAG_TASK_COLLECT) active_mask = (1u << T.nB) - 1;
+  if (T.button_reset == 2) active_mask = (1u << T.n_buttons) - 1;
   // ---- record (same as World.record) -------------------------------------------------------
   for (int k = 0; k < SAG_REC_FLOATS; k++) rf[k] = 0.f;
   for (int k = 0; k < SAG_REC_INTS; k++) ri[k] = 0;
-  ri[SAG_I_TASK] = task_id; ri[SAG_I_NH] = T.nH; ri[SAG_I_NV] = T.nV; ri[SAG_I_NP] = T.nP;
-  ri[SAG_I_NB] = T.nB; ri[SAG_I_BOX_KIND] = T.box_kind; ri[SAG_I_ENV_ID] = env_id;
+  ri[SAG_I_TASK] = task_id; ri[SAG_I_NH] = T.n_hazards; ri[SAG_I_NV] = T.n_vases; ri[SAG_I_NP] = T.n_pillars;
+  ri[SAG_I_NB] = T.n_buttons; ri[SAG_I_BOX_KIND] = T.box_kind; ri[SAG_I_ENV_ID] = env_id;
   ri[SAG_I_GOAL_BUTTON] = goal_button; ri[SAG_I_BTN_STATE] = 1; ri[SAG_I_BTN_TIMER] = btn_timer;
   ri[SAG_I_ACTIVE_MASK] = (int32_t)active_mask;
   rf[SAG_F_ROBOT] = (float)it[0].x; rf[SAG_F_ROBOT + 1] = (float)it[0].y; rf[SAG_F_ROBOT + 2] = (float)robot_rot;
   for (int k = 0; k < 3; k++) rf[SAG_F_ROBOT0 + k] = rf[SAG_F_ROBOT + k];
   if (robot == SAG_ROBOT_CAR) rf[SAG_F_ROBOT_EXT + 5] = 1.0f;  // rear ball quaternion w; doggo: all zero = reset pose
-  rf[SAG_F_GEAR] = (float)T.gear; rf[SAG_F_DAMP] = (float)T.damp;
+  rf[SAG_F_GEAR] = (float)T.gear; rf[SAG_F_DAMP] = (float)T.damping;
   rf[SAG_F_ACTION_NOISE] = (float)cfg.action_noise;
   for (int k = 0; k < SAG_MAX_NU; k++) rf[SAG_F_CTRL_SCALE + k] = (float)ctrl_scale[k];
   rf[SAG_F_HAZARD_SIZE] = (float)cfg.hazards_size; rf[SAG_F_VASE_SIZE] = (float)cfg.vases_size;
@@ -272,13 +281,39 @@ void sag_world_config_default(sag_world_config* c) {
   c->reserved = 0;
 }
 
-int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const int32_t* task_ids,
-                       const sag_world_config* cfg, int32_t first_episode, int32_t env_id0, float* rec_f,
-                       int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos, int32_t* mt_has_gauss,
-                       double* mt_gauss, int32_t* status, int32_t nthreads) {
-  if (robot < 0 || robot > 2 || n <= 0 || !seeds || !task_ids || !rec_f || !rec_i) return SAG_ERR_ARG;
+int sag_task_desc_default(int32_t task_id, sag_task_desc* d) {
+  if (task_id < 0 || task_id >= SAG_NUM_TASKS || !d) return SAG_ERR_ARG;
+  const TaskDef& T = TASKS[task_id];
+  std::memset(d, 0, sizeof(*d));
+  d->task_id = task_id; d->n_hazards = T.nH; d->n_vases = T.nV; d->n_pillars = T.nP;
+  d->has_goal = T.goal; d->box_kind = T.box_kind; d->box_yaw = T.box_yaw;
+  d->box_at_robot = task_id == SAG_TASK_HAUL_BOX; d->box_offset = d->box_at_robot ? 0.2 * 3.0 : 0.0;   // haul_box.py:17-18: 3 box sizes
+  d->n_buttons = T.nB;
+  d->button_reset = task_id == SAG_TASK_COLLECT ? 2 : (T.nB ? 1 : 0);
+  d->button_timer = 5;
+  d->extents[0] = d->extents[1] = -T.ext; d->extents[2] = d->extents[3] = T.ext;
+  d->goal_keepout = GOAL_KEEPOUT; d->box_keepout = T.box_keepout; d->button_keepout = T.nB ? BUTTONS_KEEPOUT : 0.0;
+  if (T.box_rect > 0) { d->box_rect[0] = d->box_rect[1] = -T.box_rect; d->box_rect[2] = d->box_rect[3] = T.box_rect; }
+  if (T.nB) { d->button_rect[0] = d->button_rect[1] = -T.btn_rect; d->button_rect[2] = d->button_rect[3] = T.btn_rect; }
+  d->gear = T.gear; d->damping = T.damp;
+  return SAG_OK;
+}
+
+int sag_sample_layouts_desc(int32_t robot, int32_t n, const uint32_t* seeds, const sag_task_desc* descs, int32_t n_descs,
+                            const int32_t* desc_of_env, const sag_world_config* cfg, int32_t first_episode, int32_t env_id0,
+                            float* rec_f, int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos, int32_t* mt_has_gauss,
+                            double* mt_gauss, int32_t* status, int32_t nthreads) {
+  if (robot < 0 || robot > 2 || n <= 0 || !seeds || !descs || n_descs <= 0 || !desc_of_env || !rec_f || !rec_i) return SAG_ERR_ARG;
+  for (int k = 0; k < n_descs; k++) {
+    const sag_task_desc& d = descs[k];
+    if (d.task_id < 0 || d.task_id >= SAG_NUM_TASKS || d.n_hazards < 0 || d.n_hazards > SAG_MAX_HAZARDS || d.n_vases < 0 ||
+        d.n_vases > SAG_MAX_VASES || d.n_pillars < 0 || d.n_pillars > SAG_MAX_PILLARS || d.n_buttons < 0 ||
+        d.n_buttons > SAG_MAX_BUTTONS || d.box_kind < 0 || d.box_kind > SAG_BOX_BALL || !(d.extents[0] < d.extents[2]) ||
+        !(d.extents[1] < d.extents[3]) || (d.button_reset && !d.n_buttons) || (d.box_at_robot && !d.box_kind))
+      return SAG_ERR_ARG;
+  }
   for (int i = 0; i < n; i++)
-    if (task_ids[i] < 0 || task_ids[i] >= SAG_NUM_TASKS) return SAG_ERR_ARG;
+    if (desc_of_env[i] < 0 || desc_of_env[i] >= n_descs) return SAG_ERR_ARG;
   sag_world_config c;
   if (cfg) c = *cfg; else sag_world_config_default(&c);
   if (nthreads < 1) nthreads = 1;
@@ -287,7 +322,7 @@ int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const in
   auto work = [&](int t) {
     MT rs;
     for (int i = t; i < n; i += nthreads) {
-      int rc = sample_one(robot, task_ids[i], seeds[i], c, first_episode, env_id0 + i,
+      int rc = sample_one(robot, descs[desc_of_env[i]], seeds[i], c, first_episode, env_id0 + i,
                           rec_f + (size_t)i * SAG_REC_FLOATS, rec_i + (size_t)i * SAG_REC_INTS, rs);
       if (status) status[i] = rc;
       if (rc) fails[t]++;
@@ -304,6 +339,17 @@ int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const in
   int nf = 0;
   for (int f : fails) nf += f;
   return nf;  // number of envs whose sampling failed (ResamplingError), 0 = all good
+}
+
+int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const int32_t* task_ids,
+                       const sag_world_config* cfg, int32_t first_episode, int32_t env_id0, float* rec_f,
+                       int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos, int32_t* mt_has_gauss,
+                       double* mt_gauss, int32_t* status, int32_t nthreads) {
+  if (!task_ids) return SAG_ERR_ARG;
+  sag_task_desc descs[SAG_NUM_TASKS];
+  for (int k = 0; k < SAG_NUM_TASKS; k++) sag_task_desc_default(k, &descs[k]);
+  return sag_sample_layouts_desc(robot, n, seeds, descs, SAG_NUM_TASKS, task_ids, cfg, first_episode, env_id0, rec_f, rec_i, mt_key,
+                                 mt_pos, mt_has_gauss, mt_gauss, status, nthreads);
 }
 
 }  // extern "C"

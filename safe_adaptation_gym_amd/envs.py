@@ -127,6 +127,16 @@ class BatchedSafeAdaptationGym:
     unknown = set(self.base_config or {}) - set(consts.WORLD_DEFAULT)   # the reference accepts anything (world.py:43-44)
     if unknown:
       raise KeyError(f'unknown world config keys: {sorted(unknown)}')
+    # the native sampler draws from what the Task objects say about themselves (tasks/task.py: obstacles,
+    # placement_extents, setup_placements(), attributes), deduplicated: env j uses descriptor _desc_of_env[j]
+    self._descs, self._desc_of_env, seen = [], np.zeros(self.n_envs, np.int32), {}
+    for j, t in enumerate(self._tasks):
+      d = t.descriptor()
+      key = repr(sorted(d.items()))
+      if key not in seen:
+        seen[key] = len(self._descs)
+        self._descs.append(d)
+      self._desc_of_env[j] = seen[key]
     self._task_ids = np.array([t.TASK_ID for t in self._tasks], np.int32)
     self._reward_dim = max(t.REWARD_DIM for t in self._tasks)
     self._persist = None  # task attributes that outlive an episode (filled by _pull_task_state)
@@ -228,8 +238,8 @@ class BatchedSafeAdaptationGym:
   def _build_world(self, first_episode):
     """World.sample_layout + World.reset for every env (safe_adaptation_gym.py:170-172) on the
     native sampler: env i draws from RandomState(seed_i) in the reference's order."""
-    out = nat.sample_layouts(self.robot.name, self._seeds, self._task_ids, config=self.base_config,
-                             first_episode=first_episode, want_rng=self.parity_rng)
+    out = nat.sample_layouts(self.robot.name, self._seeds, self._desc_of_env, config=self.base_config,
+                             first_episode=first_episode, want_rng=self.parity_rng, descs=self._descs)
     rf, ri, status = out[:3]
     states = out[3] if self.parity_rng else None
     if status.any():

@@ -1,41 +1,15 @@
-import numpy as np
-
-from safe_adaptation_gym_amd import utils
-from safe_adaptation_gym_amd.tasks.task import Task
-
-_GOAL_PLACEMENT = [(-1.5, -1.5, 1.5, 1.5)]
+from safe_adaptation_gym_amd.tasks.task import GOAL_KEEPOUT, GOAL_PLACEMENT, Task
 
 
 class GoToGoal(Task):
-  """Reference tasks/go_to_goal.py.  Device side: 3-D progress reward, goal-met
-  resample (sag_device.hpp, task switch)."""
+  """Reference tasks/go_to_goal.py.  Device side: 3-D progress reward, goal-met resample (sag_device.hpp, task
+  switch); the goal's yaw draw and the reset-time resample (go_to_goal.py:50-80) are the native sampler's."""
   NAME, TASK_ID, HAS_GOAL = 'go_to_goal', 3, True
   GOAL_SIZE = 0.3
-  GOAL_KEEPOUT = 0.4
+  GOAL_KEEPOUT = GOAL_KEEPOUT
 
   def setup_placements(self):
-    return {'goal': (_GOAL_PLACEMENT, self.GOAL_KEEPOUT)}
-
-  def draw_world_config(self, layout, rs):
-    return {'goal': utils.random_rot(rs)}
-
-  def reset(self, layout, placements, rs, state):
-    layout['goal'] = self.resample_goal_position(layout, placements, rs)
-
-  def resample_goal_position(self, layout, placements, rs):
-    """tasks/go_to_goal.py:59-80: rejection sampling against every other layout
-    entry with keepout_other + GOAL_KEEPOUT; each rejected draw grows the goal
-    rectangle by 1 %."""
-    layout.pop('goal')
-    rect = _GOAL_PLACEMENT
-    for i in range(50):
-      for _ in range(10000):
-        xy = utils.draw_placement(rs, rect, self.placement_extents, self.GOAL_KEEPOUT)
-        if all(np.linalg.norm(xy - o) >= placements[n][1] + self.GOAL_KEEPOUT
-               for n, o in layout.items()):
-          return xy
-        rect = None if i == 48 else [utils.grow(rect[0])]
-    raise utils.ResamplingError('Failed to generate goal')
+    return {'goal': (GOAL_PLACEMENT, self.GOAL_KEEPOUT)}
 
   @property
   def obstacles(self):
@@ -66,14 +40,10 @@ class GoToGoalDamping(GoToGoal):
 
 
 class CatchGoal(GoToGoal):
-  """tasks/catch_goal.py: the goal orbits its origin; radii/timer live in the
+  """tasks/catch_goal.py: the goal orbits its origin (= the goal position after reset); radii / timer live in the
   device task state."""
   NAME, TASK_ID = 'catch_goal', 0
   MIN_RADIUS, MAX_RADIUS, SAMPLE_POINTS = 0.2, 1.0, 10
-
-  def reset(self, layout, placements, rs, state):
-    super().reset(layout, placements, rs, state)
-    state['catch_origin'] = np.array(layout['goal'], float)
 
 
 class Unsupervised(GoToGoal):

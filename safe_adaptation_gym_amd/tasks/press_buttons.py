@@ -1,12 +1,12 @@
-from safe_adaptation_gym_amd import utils
 from safe_adaptation_gym_amd.tasks.task import Task
 
 
 class PressButtons(Task):
-  """Reference tasks/press_buttons.py.  The NORMAL/BUTTON_CHANGE state machine and
-  the 5-tick timer run on the device; the host draws the first goal button."""
+  """Reference tasks/press_buttons.py.  The NORMAL / BUTTON_CHANGE state machine and the 5-tick timer run on the
+  device; the first goal button is the sampler's rs.choice (press_buttons.py:71-77)."""
   NAME, TASK_ID = 'press_buttons', 8
   NUM_BUTTONS = 4
+  BUTTON_RESET = 1
   BUTTONS_KEEPOUT = 0.2
   BUTTON_SIZE = 0.1
   BUTTON_TICKING_DELAY = 5
@@ -14,15 +14,6 @@ class PressButtons(Task):
 
   def setup_placements(self):
     return {f'buttons{i}': ([self._RECT], self.BUTTONS_KEEPOUT) for i in range(self.NUM_BUTTONS)}
-
-  def draw_world_config(self, layout, rs):
-    return {n: utils.random_rot(rs) for n in layout if 'buttons' in n}
-
-  def reset(self, layout, placements, rs, state):
-    # _sample_goal_button (press_buttons.py:71-77): rs.choice, timer reset;
-    # `_state` (NORMAL/BUTTON_CHANGE) persists on the Task object across resets.
-    state['goal_button'] = int(rs.choice(self.NUM_BUTTONS))
-    state['btn_timer'] = self.BUTTON_TICKING_DELAY
 
   @property
   def obstacles(self):
@@ -36,13 +27,11 @@ class PressButtonsScarce(PressButtons):
 
 
 class Collect(PressButtons):
-  """tasks/collect.py: six goal buttons, each collected once; no host draws."""
+  """tasks/collect.py: six goal buttons, each collected once; no host draws at reset."""
   NAME, TASK_ID = 'collect', 1
   NUM_BUTTONS = 6
+  BUTTON_RESET = 2
   _RECT = (-1.5, -1.5, 1.5, 1.5)
-
-  def reset(self, layout, placements, rs, state):
-    state['active_mask'] = (1 << self.NUM_BUTTONS) - 1
 
   @property
   def placement_extents(self):

@@ -1,10 +1,9 @@
-from safe_adaptation_gym_amd import utils
 from safe_adaptation_gym_amd.tasks.go_to_goal import GoToGoal
 
 
 class PushBox(GoToGoal):
-  """Reference tasks/push_box.py."""
-  NAME, TASK_ID, BOX_KIND = 'push_box', 10, 1
+  """Reference tasks/push_box.py: a free box (main body + four corner columns) to be pushed onto the goal."""
+  NAME, TASK_ID, BOX_KIND, BOX_YAW = 'push_box', 10, 1, True
   BOX_SIZE = 0.2
   BOX_KEEPOUT = 0.5
   BOX_DENSITY = 0.001
@@ -13,11 +12,6 @@ class PushBox(GoToGoal):
     placements = super().setup_placements()
     placements.update({'box': (None, self.BOX_KEEPOUT)})
     return placements
-
-  def draw_world_config(self, layout, rs):
-    rots = super().draw_world_config(layout, rs)
-    rots['box'] = utils.random_rot(rs)
-    return rots
 
   @property
   def obstacles(self):
@@ -39,25 +33,18 @@ class PushBoxScarce(PushBox):
 
 
 class HaulBox(PushBox):
-  """tasks/haul_box.py: box spawned 3 box sizes ahead of the robot (world +x) and
-  tied to it by a length-limited tendon."""
+  """tasks/haul_box.py: box spawned 3 box sizes ahead of the robot (world +x, haul_box.py:17-18) and tied to it by a
+  length-limited tendon."""
   NAME, TASK_ID = 'haul_box', 7
-
-  def draw_world_config(self, layout, rs):
-    layout['box'] = layout['robot'].copy()
-    layout['box'][0] += self.BOX_SIZE * 3.
-    return super().draw_world_config(layout, rs)
+  BOX_AT_ROBOT = PushBox.BOX_SIZE * 3.
 
 
 class RollRod(PushBox):
   """tasks/roll_rod.py: the object is a cylinder lying on its side; no yaw draw."""
-  NAME, TASK_ID, BOX_KIND = 'roll_rod', 12, 2
+  NAME, TASK_ID, BOX_KIND, BOX_YAW = 'roll_rod', 12, 2, False
   ROD_LENGTH, ROD_RADIUS = 0.3, 0.08
   BOX_KEEPOUT = 0.7
   BOX_SIZE = 0.25
-
-  def draw_world_config(self, layout, rs):
-    return GoToGoal.draw_world_config(self, layout, rs)
 
   @property
   def placement_extents(self):
@@ -66,13 +53,10 @@ class RollRod(PushBox):
 
 class DribbleBall(PushBox):
   """tasks/dribble_ball.py: the object is a sphere; no yaw draw."""
-  NAME, TASK_ID, BOX_KIND = 'dribble_ball', 2, 3
+  NAME, TASK_ID, BOX_KIND, BOX_YAW = 'dribble_ball', 2, 3, False
   SPHERE_RADIUS = 0.14
   BOX_KEEPOUT = 0.2
   BOX_SIZE = SPHERE_RADIUS
-
-  def draw_world_config(self, layout, rs):
-    return GoToGoal.draw_world_config(self, layout, rs)
 
   @property
   def placement_extents(self):

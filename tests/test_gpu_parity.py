@@ -599,6 +599,21 @@ def test_env_api_shapes_and_reference_surface(nat):
   for name, task in bm.train_tasks:
     obs = env.reset(options={'task': task})
     assert obs.shape == (100, 60)
+  # the tasks/* plugin surface: a subclass that overrides `obstacles` changes the worlds the env builds
+  class Sparse(sag.tasks.GoToGoal):
+    @property
+    def obstacles(self):
+      return [3, 3, 0, 0]
+  env.set_task(Sparse)
+  rf, ri = env.get_state()
+  assert (ri[:, nat.I_NH] == 3).all() and (ri[:, nat.I_NV] == 3).all() and (ri[:, nat.I_NP] == 0).all()
+  obs, reward, done, info = env.step(a)
+  assert np.isfinite(obs).all() and (obs[:, 16:32] == 0).all(), 'no task object: the middle lidar stays empty'
+  class OwnReward(sag.tasks.GoToGoal):
+    def compute_reward(self, *args):
+      return 0.
+  with pytest.raises(NotImplementedError):
+    env.set_task(OwnReward)
   env.close()
 
 

@@ -52,6 +52,9 @@ def test_native_sampler_matches_reference(rec):
   tid = gu.TASK_ID[rec['task']]
   rf, ri, st, states = nat.sample_layouts(rec['robot'], [rec['seed']], tid, want_rng=True)
   assert st[0] == 0
+  # the product path: the descriptor comes from the Python Task object (envs.py), not from the library's table
+  rf_d, ri_d, st_d = nat.sample_layouts(rec['robot'], [rec['seed']], 0, descs=[benchmark.TASKS[rec['task']]().descriptor()])
+  np.testing.assert_array_equal(rf_d, rf); np.testing.assert_array_equal(ri_d, ri)
   _check(rf[0], ri[0], states[0], rec['first'], rec['rots'], rec['robot_rot'], rec['task'])
   assert list(ri[0, 1:6]) == [rec['obstacles'][0], rec['obstacles'][1], rec['obstacles'][3],
                               benchmark.TASKS[rec['task']].NUM_BUTTONS, benchmark.TASKS[rec['task']].BOX_KIND]
@@ -95,3 +98,83 @@ def test_native_sampler_config_and_cauchy_scale():
 def test_native_sampler_impossible_layout_reports_failure():
   rf, ri, st = nat.sample_layouts('doggo', [0], 3, config={'hazards_size': 2.0, 'vases_size': 2.0, 'pillars_size': 2.0})
   assert st[0] < 0
+
+
+# ---- the tasks/* plugin surface (tasks/task.py:14-97) reaches the sampler ----------------------------------------
+@pytest.mark.parametrize('name', sorted(benchmark.TASKS))
+def test_task_class_descriptor_equals_library_table(name):
+  """What each of the 14 Python Task classes says about itself (obstacles, placement_extents, setup_placements(),
+  attributes) is exactly the library's own descriptor for that task id."""
+  t = benchmark.TASKS[name]()
+  assert t.descriptor() == nat.task_desc_default(t.TASK_ID)
+
+
+def test_task_subclass_changes_the_layouts():
+  """a subclass that overrides the reference's Task surface changes the worlds."""
+  from safe_adaptation_gym_amd.tasks.go_to_goal import GoToGoal
+  from safe_adaptation_gym_amd.tasks.push_box import PushBox
+
+  class Sparse(GoToGoal):
+    @property
+    def obstacles(self):
+      return [3, 3, 0, 0]
+
+    @property
+    def placement_extents(self):
+      return [-1.0, -1.5, 2.5, 1.5]
+
+  rf, ri, st = nat.sample_layouts('point', 100 + np.arange(32), 0, descs=[Sparse().descriptor()])
+  assert not st.any()
+  assert (ri[:, nat.I_NH] == 3).all() and (ri[:, nat.I_NV] == 3).all() and (ri[:, nat.I_NP] == 0).all()
+  assert (ri[:, nat.I_TASK] == GoToGoal.TASK_ID).all()
+  hz = rf[:, nat.F_HAZARDS:nat.F_HAZARDS + 6].reshape(-1, 3, 2)
+  assert hz[..., 0].min() >= -1.0 + 0.2 - 1e-6 and hz[..., 0].max() <= 2.5 - 0.2 + 1e-6 and hz[..., 0].max() > 2.0
+  assert np.abs(hz[..., 1]).max() <= 1.5 - 0.2 + 1e-6
+  assert (rf[:, nat.F_HAZARDS + 6:nat.F_HAZARDS + 18] == 0).all(), 'unused hazard slots stay empty'
+
+  class FarBox(PushBox):
+    BOX_KEEPOUT = 0.3
+
+    def setup_placements(self):
+      p = super().setup_placements()
+      p['box'] = ([(1.0, -0.5, 1.6, 0.5)], self.BOX_KEEPOUT)
+      return p
+
+  rf, ri, st = nat.sample_layouts('car', 7 + np.arange(16), 0, descs=[FarBox().descriptor()])
+  assert not st.any()
+  assert (rf[:, nat.F_BOX] >= 1.3 - 1e-6).all() and (np.abs(rf[:, nat.F_BOX + 1]) <= 0.2 + 1e-6).all()
+  assert np.allclose(rf[:, nat.F_KEEPOUT + 4], 0.3)
+
+
+def test_task_surface_limits_raise():
+  from safe_adaptation_gym_amd.tasks.go_to_goal import GoToGoal
+  from safe_adaptation_gym_amd.tasks.task import Task
+
+  class NoId(Task):
+    def setup_placements(self):
+      return {}
+
+  with pytest.raises(TypeError, match='TASK_ID'):
+    NoId().descriptor()
+
+  class OwnReward(GoToGoal):
+    def compute_reward(self, *a):
+      return 0.
+
+  with pytest.raises(NotImplementedError, match='runs on the device'):
+    OwnReward().descriptor()
+
+  class TooMany(GoToGoal):
+    @property
+    def obstacles(self):
+      return [12, 3, 0, 1]
+
+  with pytest.raises(ValueError, match='hazards'):
+    TooMany().descriptor()
+
+  class MovedGoal(GoToGoal):
+    def setup_placements(self):
+      return {'goal': ([(-1, -1, 1, 1)], 0.4)}
+
+  with pytest.raises(NotImplementedError, match='goal placement'):
+    MovedGoal().descriptor()
