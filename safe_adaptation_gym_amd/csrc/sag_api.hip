@@ -541,6 +541,12 @@ int sag_destroy(sag_ctx* c) {
   return SAG_OK;
 }
 
+// a new episode starts without a cost flag: sag_render's cost overlay reads d_cost of the last host-buffer step
+__global__ void k_clear_cost(uint8_t* cost, const int32_t* ids, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) cost[ids ? ids[j] : j] = 0;
+}
+
 static int upload_records(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* rec_f,
                           const int32_t* rec_i) {
   if (n <= 0 || n > c->N || !rec_f || !rec_i) return fail(c, SAG_ERR_ARG, "bad record batch (n=%d)", n);
@@ -555,7 +561,8 @@ static int upload_records(sag_ctx* c, const int32_t* env_ids, int32_t n, const f
         ri[SAG_I_NB] > c->cfg.max_buttons || ri[SAG_I_BOX_KIND] < 0 || ri[SAG_I_BOX_KIND] > 3 ||
         (ri[SAG_I_BOX_KIND] != 0 && !c->cfg.has_box) || ri[SAG_I_GOAL_BUTTON] < 0 ||
         ri[SAG_I_GOAL_BUTTON] >= SAG_MAX_BUTTONS || ri[SAG_I_BTN_TIMER] < 0 || ri[SAG_I_BTN_TIMER] > 5 ||
-        ri[SAG_I_CATCH_TIMER] < 0 || ri[SAG_I_CATCH_TIMER] > 10)
+        ri[SAG_I_CATCH_TIMER] < 0 || ri[SAG_I_CATCH_TIMER] > 10 ||
+        ri[SAG_I_EPISODE] < 0 || ri[SAG_I_EPISODE] > 0xffffff)   // the nonce is 24 bits of the flags word: no silent truncation
       return fail(c, SAG_ERR_ARG, "record %d exceeds the context's capacities or has a bad field", k);
   }
   HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -573,6 +580,7 @@ int sag_set_layout(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* r
   hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 1);
   c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
+  hipLaunchKernelGGL(k_clear_cost, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_cost, env_ids ? c->st_ids : nullptr, n);
   // keep a copy for sag_reset: read the installed state back into the AoS layout store
   hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i);
@@ -644,6 +652,7 @@ int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
     hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                        c->st_ids, n, c->st_f, c->st_i, 0);
   }
+  hipLaunchKernelGGL(k_clear_cost, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_cost, env_ids ? c->st_ids : nullptr, n);
   c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -774,11 +783,13 @@ int sag_lidar_cost_device(sag_ctx* c, int32_t n, int32_t K, const float* d_robot
   if (!c) return SAG_ERR_ARG;
   if (n <= 0 || K < 0 || !d_robot || (K > 0 && (!d_points || !d_group)) || !d_lidar || !d_cost)
     return fail(c, SAG_ERR_ARG, "bad sag_lidar_cost_device arguments");
+  // (every argument is checked BEFORE a timing-event pair is reserved: a pair that is counted but never recorded would
+  //  add an earlier launch's timestamps to the kernel-time mean)
+  if (lidar_cost_lds_bytes(K) > 64 * 1024) return fail(c, SAG_ERR_ARG, "K = %d points per env exceed the kernel's LDS staging (K <= 100)", K);
   HIPCHK(c, hipSetDevice(c->cfg.device));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int rc = timing_events(c, &e0, &e1);
   if (rc) return rc;
-  if (lidar_cost_lds_bytes(K) > 64 * 1024) return fail(c, SAG_ERR_ARG, "K = %d points per env exceed the kernel's LDS staging (K <= 100)", K);
   if (e0) HIPCHK(c, hipEventRecord(e0, c->stream));
   launch_lidar_cost(c, n, K, d_robot, d_points, d_group, hazard_size, d_lidar, d_bins, d_cost);
   if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));

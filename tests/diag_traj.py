@@ -1,6 +1,8 @@
 """Free-running trajectory dump for comparing library builds bit for bit (a refactor that must not change
 results; a code-shape change that should not: DESIGN.md 3.4):
-  SAG_LIB=... [SAG_DOGGO_COOP=0] python tests/diag_traj.py out.npz [robot=doggo] [task=go_to_goal] [n=64] [T=30]
+  SAG_LIB=... python tests/diag_traj.py out.npz [robot=doggo] [task=go_to_goal] [n=64] [T=30] [--replay base.npz]
+--replay: every step starts from the state base.npz had there (one-step comparison of builds whose arithmetic differs
+by rounding, e.g. the 64-lane PGS path forced by -DSAG_DC_FAST_ROWS=8: tests/test_hostemu_variants.py).
 Doggo: random torques (the scenario of test_doggo_lockstep_vs_oracle); Point / Car: pursuit actions so that goals,
 vases and the box are actually hit.  `python tests/diag_traj.py --cmp a.npz b.npz` prints the first difference.
 Uses no oracle."""
@@ -26,6 +28,11 @@ if sys.argv[1] == '--cmp':
   print('bit-identical' if same else 'DIFFERENT')
   sys.exit(0 if same else 1)
 
+replay = None
+if '--replay' in sys.argv:
+  k = sys.argv.index('--replay')
+  replay = np.load(sys.argv[k + 1])
+  del sys.argv[k:k + 2]
 out = sys.argv[1]
 robot = sys.argv[2] if len(sys.argv) > 2 else 'doggo'
 task = sys.argv[3] if len(sys.argv) > 3 else 'go_to_goal'
@@ -36,8 +43,10 @@ rf, ri = bu.sample_records_native(robot, task, n, seed=666)
 ctx = nat.Context(robot, n, seed=4321)
 ctx.set_layout(rf, ri)
 mt, rng = np.random.RandomState(5), np.random.RandomState(6)
-states, outs = [], []
+states, ints, outs = [], [], []
 for t in range(T):
+  if replay is not None and t > 0:
+    ctx.set_state(replay['states'][t - 1], replay['ints'][t - 1])
   if robot == 'doggo':
     act = mt.uniform(-1, 1, size=(n, nu)).astype(np.float32)
     if t < 3:
@@ -49,9 +58,10 @@ for t in range(T):
   o = ctx.step(act, noise, tape)
   s = ctx.get_state()
   states.append(s[0].copy())
+  ints.append(s[1].copy())
   outs.append(np.concatenate([o[0], o[1], o[2][:, None], o[3][:, None], o[4][:, None]], 1))
   bad = np.flatnonzero(~np.isfinite(s[0]).all(1))
   if len(bad):
     print(f'step {t}: non-finite envs {bad.tolist()}', flush=True)
-np.savez_compressed(out, states=np.stack(states), outs=np.stack(outs), rec0=rf, reci0=ri)
+np.savez_compressed(out, states=np.stack(states), ints=np.stack(ints), outs=np.stack(outs), rec0=rf, reci0=ri)
 print('saved', out, 'cost rate', float(np.mean([o[:, -3].mean() for o in outs])), 'goals met', int(sum(o[:, -1].sum() for o in outs)))

@@ -1,5 +1,6 @@
 """HIP path (libsag.so through the C ABI) vs the CPU oracle and the golden fixtures.
 Run on an MI355X: python -m pytest tests -m gpu."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -62,6 +63,42 @@ def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle, K):
   np.testing.assert_array_equal(cost, o_cost)          # bit-exact cost flags
   assert 0.05 < cost.mean() < 0.95
   np.testing.assert_allclose(lidar, o_lidar, rtol=0, atol=1e-6)
+  ctx.close()
+
+
+@pytest.mark.parametrize('K', [21, 30])
+def test_lidar_cost_device_entry_partial_block_and_unaligned_buffers(nat, K):
+  """sag_lidar_cost_device (the entry bench.py times): n not a multiple of the 64-env block and buffers that start 4
+  bytes into their allocation (the kernels' linear 16-byte copies need their unaligned branch) give the same bins,
+  values and flags as the host-buffer entry; one timed launch is reported as one launch; a rejected call (K beyond the
+  LDS staging) reserves no timing slot."""
+  n = 1000 + 37
+  robot, pts, grp = _lidar_inputs(n, K, 3)
+  ctx = nat.Context('point', 64)
+  lidar0, bins0, cost0 = ctx.lidar_cost(robot, pts, grp)
+  off = 4
+  bufs = {}
+  for name, arr in (('robot', robot.astype(np.float32)), ('pts', pts.astype(np.float32)), ('grp', grp.astype(np.uint8))):
+    d = ctx.dev_alloc(arr.nbytes + 64)
+    ctx.dev_upload(C.c_void_p(d.value + off), np.ascontiguousarray(arr))
+    bufs[name] = d
+  d_lid, d_bins, d_cost = ctx.dev_alloc(n * 48 * 4 + 64), ctx.dev_alloc(n * K * 4 + 64), ctx.dev_alloc(n + 64)
+  p = lambda d: C.c_void_p(d.value + off)
+  ctx.enable_timing(True)
+  ctx.kernel_time_ms(reset=True)
+  with pytest.raises(nat.SagError):
+    ctx.lidar_cost_device(n, 101, p(bufs['robot']), p(bufs['pts']), p(bufs['grp']), p(d_lid), p(d_bins), p(d_cost))
+  ctx.lidar_cost_device(n, K, p(bufs['robot']), p(bufs['pts']), p(bufs['grp']), p(d_lid), p(d_bins), p(d_cost))
+  ctx.wait()
+  ms, cnt = ctx.kernel_time_ms(reset=True)
+  assert cnt == 1 and 0 < ms < 100, (ms, cnt)
+  ctx.enable_timing(False)
+  lidar = ctx.dev_download(p(d_lid), (n, 48), np.float32)
+  bins = ctx.dev_download(p(d_bins), (n, K), np.int32)
+  cost = ctx.dev_download(p(d_cost), (n,), np.uint8)
+  np.testing.assert_array_equal(bins, bins0)
+  np.testing.assert_array_equal(cost, cost0)
+  np.testing.assert_array_equal(lidar, lidar0)
   ctx.close()
 
 
