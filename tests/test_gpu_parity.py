@@ -406,7 +406,8 @@ def test_free_running_drift(nat, oracle, robot, task):
   arr = oracle.make_batch(rf, ri)
   arr_r = oracle.make_batch(rf, ri)   # the oracle itself with its state rounded to fp32 after every step (as the ABI stores it)
   rng, mt = np.random.RandomState(3), np.random.RandomState(4)
-  dev_cost, orc_cost, dev_met, orc_met, dpos, rpos, ref_cost = [], [], [], [], [], [], []
+  dev_cost, orc_cost, dev_met, orc_met, dpos, rpos, ref_cost, ref_met = [], [], [], [], [], [], [], []
+  start = rf[:, :2].copy()
   for t in range(T):
     if robot == 'doggo':
       act = mt.uniform(-1, 1, size=(n, nu)).astype(np.float32)
@@ -417,7 +418,7 @@ def test_free_running_drift(nat, oracle, robot, task):
     d = ctx.step(act, noise, tape)
     o = oracle.step_batch_full(arr, rid, act, noise, tape, obs_dim=od)
     o_r = oracle.step_batch_full(arr_r, rid, act, noise, tape, obs_dim=od)
-    ref_cost.append(o_r[2])
+    ref_cost.append(o_r[2]); ref_met.append(o_r[4])
     r_rf, r_ri = oracle.batch_records(arr_r)
     arr_r = oracle.make_batch(r_rf, r_ri)
     d_rf = ctx.get_state()[0]
@@ -433,7 +434,10 @@ def test_free_running_drift(nat, oracle, robot, task):
   # comparison is the env, not the env-step
   per_env = dev_cost.mean(0) - orc_cost.mean(0)
   cost_se = per_env.std(ddof=1) / np.sqrt(n)
-  ref_rate = np.array(ref_cost).mean()
+  ref_cost, ref_met = np.array(ref_cost), np.array(ref_met)
+  ref_rate = ref_cost.mean()
+  ref_agree = (ref_cost == orc_cost).mean()   # the yardstick for the agreement: the oracle against its own fp32-rounded twin
+  travel = [float(np.hypot(x[:, 0] - start[:, 0], x[:, 1] - start[:, 1]).mean()) for x in (d_rf, o_rf, r_rf)]
   met_agree = (dev_met == orc_met).mean()
   close = (dpos[-1] < 1e-3).mean()
   line = (f'{robot}/{task}: {n} envs x {T} steps free-running vs fp64 oracle | robot position drift [m] median/p90/p99 at '
@@ -441,7 +445,9 @@ def test_free_running_drift(nat, oracle, robot, task):
           f'step 200: {q(199)[0]:.2e}/{q(199)[1]:.2e}/{q(199)[2]:.2e} | envs within 1 mm at step 200: {close:.3f} | '
           f'cost-flag agreement per env-step {cost_agree:.5f} (device rate {dev_cost.mean():.4f}, oracle {orc_cost.mean():.4f}, its fp32-rounded '
           f'twin {ref_rate:.4f}; standard error of the per-env rate difference {cost_se:.4f}) | '
-          f'goal-met agreement {met_agree:.5f} (device {int(dev_met.sum())}, oracle {int(orc_met.sum())} events) | reference level - the '
+          f'goal-met agreement {met_agree:.5f} (device {int(dev_met.sum())}, oracle {int(orc_met.sum())}, twin {int(ref_met.sum())} events) | '
+          f'mean distance travelled in {T} steps: device {travel[0]:.3f}, oracle {travel[1]:.3f}, twin {travel[2]:.3f} m | '
+          f'cost-flag agreement of the twin with the oracle {ref_agree:.5f} | reference level - the '
           f'fp64 oracle against ITSELF with its state rounded to fp32 after every step: median/p90 at step 200 '
           f'{np.median(rpos[-1]):.2e}/{np.quantile(rpos[-1], 0.9):.2e}')
   print(line)
@@ -455,7 +461,10 @@ def test_free_running_drift(nat, oracle, robot, task):
   assert q(199)[0] <= 3 * np.median(rpos[-1]) + 1e-3, 'drift beyond what fp32 state storage alone causes in the oracle'
   if robot != 'doggo':
     assert q(199)[0] < 1e-3, 'the median env should not separate from its oracle twin'
-  assert cost_agree > (0.97 if robot == 'doggo' else 0.99)
+  # Doggo is chaotic: after ~100 steps the flag streams of ANY two runs are independent samples of one distribution
+  # (two independent streams of rate p agree on 1 - 2 p (1 - p) of the env-steps), so the bar is the agreement the
+  # oracle reaches with its own fp32-rounded twin, not a constant
+  assert cost_agree > (ref_agree - 0.01 if robot == 'doggo' else 0.99)
   if robot == 'doggo':
     assert abs(per_env.mean()) < 3 * cost_se, f'cost rates differ by {per_env.mean():.5f}: more than 3 standard errors ({cost_se:.5f}) of the env-to-env scatter'
   else:
