@@ -1016,12 +1016,23 @@ static void car_smooth(World* w, const real ctrl[2], const Sol* sol, int part) {
  *    c_i = aref_i - r_i alpha0_i, D_i = r_i^2 / I_i + R_i) leaves (M + sum_i J_i^T J_i / D_i) a = M a_other + sum_i J_i^T c_i / D_i,
  *    a constant 3 x 3 matrix (block diagonal {x, yaw} + {y} by the car's symmetry); forces clamped to +-mu N;
  *  - then CAR_FRICTION_SWEEPS projected Gauss-Seidel sweeps over the five accumulated forces (exact start when
- *    nothing clamps; 4 sweeps leave 2e-5 m per env-step against the converged solution, one sweep of the six
- *    elements left 3e-3: profiles/r03_sweep_convergence.txt);
+ *    nothing clamps);
+ *  - WARM START (as MuJoCo's solver): only the first solve of an env-step is done that way; every later one - the
+ *    re-solve after contacts, the next substeps - starts from the previous solve's five forces and runs
+ *    CAR_FRICTION_SWEEPS_WARM sweeps (the forces change little from one substep to the next); the forward evaluation
+ *    at the final state (mj_forward, safe_adaptation_gym.py:76: accelerometer, contact flags) starts cold again, so
+ *    that the observation is a function of the state alone;
+ *    together 6e-5 m per env-step (median) from the converged solution, where one cold sweep of the six elements
+ *    left 3e-3: profiles/r03_sweep_convergence.txt;
  *  - solved before the robot's contacts and, when these changed the base acceleration, once more after them
  *    (`a_other` then includes the contact forces).
  * R_i = A_ii (1 - d0) / d0 with A_ii = J_i M^-1 J_i^T + r_i^2 / I_i, bounds mu N_i under the static loads: as before. */
-#define CAR_FRICTION_SWEEPS 4
+#define CAR_FRICTION_SWEEPS 4        /* after the direct solve (the first solve of an env-step) */
+#define CAR_FRICTION_SWEEPS_WARM 2   /* a solve that starts from the previous solve's forces */
+/* the five forces of the previous solve of this env-step (set by sago_step around its forward evaluations; a lone
+ * forward evaluation - sago_observe - has none and solves cold) */
+typedef struct { int have; real f[5]; } CarWarm;
+static _Thread_local CarWarm* g_carws = NULL;
 static void car_floor_friction(World* w, const Sol* sol) {
   Body* r = &w->robot;
   const CarK k = car_constants();
@@ -1069,12 +1080,13 @@ static void car_floor_friction(World* w, const Sol* sol) {
   for (int i = 0; i < 5; i++) b2 += wD[i] * cc[i] * JW[i];
   const real n0 = (K22 * b0 - K02 * b2) * idk, n1 = b1 / K11, n2 = (K00 * b2 - K02 * b0) * idk;
   real f[5], al[5], fa0 = 0, fa1 = 0, fa2 = 0;
+  const int warm = g_carws && g_carws->have;
   for (int i = 0; i < 5; i++) {
-    f[i] = clampr(wD[i] * (cc[i] - ((ISX[i] ? n0 : n1) + JW[i] * n2)), -lim[i], lim[i]);
+    f[i] = warm ? g_carws->f[i] : clampr(wD[i] * (cc[i] - ((ISX[i] ? n0 : n1) + JW[i] * n2)), -lim[i], lim[i]);
     fa0 += U0[i] * f[i]; fa1 += U1[i] * f[i]; fa2 += U2[i] * f[i];
     al[i] = al0[i] + rw[i] * f[i] * iIs[i];
   }
-  for (int sw = 0; sw < CAR_FRICTION_SWEEPS; sw++)
+  for (int sw = 0; sw < (warm ? CAR_FRICTION_SWEEPS_WARM : CAR_FRICTION_SWEEPS); sw++)
     for (int i = 0; i < 5; i++) {
       const real sa = (ISX[i] ? a0 + fa0 : a1 + fa1) + JW[i] * (a2 + fa2) + rw[i] * al[i];
       const real fn = clampr(f[i] + (aref[i] - sa - Rr[i] * f[i]) * iAR[i], -lim[i], lim[i]);
@@ -1083,6 +1095,7 @@ static void car_floor_friction(World* w, const Sol* sol) {
       fa0 += U0[i] * df; fa1 += U1[i] * df; fa2 += U2[i] * df;
       al[i] += rw[i] * df * iIs[i];
     }
+  if (g_carws) { g_carws->have = 1; for (int i = 0; i < 5; i++) g_carws->f[i] = f[i]; }
   a0 += fa0; a1 += fa1; a2 += fa2;
   w->car_fa[0] = fa0; w->car_fa[1] = fa1; w->car_fa[2] = fa2;
   r->ax = c * a0 - s * a1; r->ay = s * a0 + c * a1; r->aw = a2;
@@ -1671,6 +1684,8 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   if (e->i[SAG_I_TASK] == SAG_TASK_CATCH_GOAL) catch_goal_mocap(e, &g, time);
   DgWarm dgws; dgws.n = 0; dgws.evals = 0;
   g_dgws = &dgws;   /* doggo: constraint forces carried from one forward evaluation of this env-step to the next */
+  CarWarm carws; carws.have = 0;
+  g_carws = &carws; /* car: the same for its floor friction */
   substeps_r(e, ctrl, nstep, h, robot);
   e->i[SAG_I_STEP] += 1;
   if (state_bad_r(e, robot)) { /* PhysicsError branch (:73-75) */
@@ -1679,7 +1694,7 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
     else observe(e, robot, z, out->obs);
     out->reward[0] = -10; out->done = 1; out->cost = 0;
     out->tape_used = g.pos;
-    g_dgws = NULL;
+    g_dgws = NULL; g_carws = NULL;
     return;
   }
   /* mj_forward at the final state (:76): contacts + qacc */
@@ -1689,8 +1704,9 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   if (robot == SAG_ROBOT_DOGGO) { w.dg = &dg; dg_load(&dg, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT); }
   Sol sol = make_sol(h);
   uint32_t mask = 0;
+  carws.have = 0;   /* the forward evaluation behind the observation solves the car's friction cold: the accelerometer stays a function of the state */
   int cc = world_forward(&w, e, ctrl, &sol, &mask);
-  g_dgws = NULL;
+  g_dgws = NULL; g_carws = NULL;
   if (ext_cost_contacts >= 0) { cc = ext_cost_contacts; mask = ext_btn_mask; }
   out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
   if (robot == SAG_ROBOT_DOGGO) {
@@ -1720,7 +1736,10 @@ void sago_observe(OEnv* e, int robot, OOut* out) {
   if (robot == SAG_ROBOT_DOGGO) { w.dg = &dg; dg_load(&dg, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT); }
   Sol sol = make_sol(DT[robot]);
   real ctrl[SAG_MAX_NU] = {0};
+  CarWarm carws; carws.have = 0;
+  g_carws = &carws;   /* one cold solve; the re-solve after contacts starts from it, as in a step */
   world_forward(&w, e, ctrl, &sol, &out->btn_contact_mask);
+  g_carws = NULL;
   out->qacc[0] = w.robot.ax; out->qacc[1] = w.robot.ay; out->qacc[2] = w.robot.aw;
   if (robot == SAG_ROBOT_DOGGO) {
     for (int k = 0; k < 3; k++) out->qacc[k] = (real)dg.qacc[k];

@@ -173,7 +173,9 @@ constexpr float CAR_IO =
     2 * CAR_MW * ((3 * 0.0025f + 0.0025f) / 12 + 0.13f * 0.13f + 0.01f) + CAR_MBALL * (0.4f * 0.0025f + 0.01f);
 constexpr float CAR_IW = 0.5f * CAR_MW * 0.0025f + 0.00025f;  // axle inertia + armature (car.xml:22,26)
 constexpr float CAR_IB = 0.4f * CAR_MBALL * 0.0025f;
-constexpr int CAR_FRICTION_SWEEPS = 4;   // projected Gauss-Seidel sweeps over the five floor-friction elements after their direct solve (oracle car_floor_friction)
+// projected Gauss-Seidel sweeps over the car's five floor-friction elements: after the direct solve (the first solve of an
+// env-step) / in a solve that starts from the previous solve's forces (oracle car_floor_friction)
+constexpr int CAR_FRICTION_SWEEPS = 4, CAR_FRICTION_SWEEPS_WARM = 2;
 
 // ---- counter-based generator ------------------------------------------------
 __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -1293,12 +1295,16 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     car_iK11 = 1.0f / (CM + car_w_L + car_w_L + car_w_Y);
   }
   float car_f0 = 0, car_f1 = 0, car_f2 = 0, car_px = 0, car_py = 0, car_pw = 0;   // friction's share of the base acceleration (body axes); R.a after the first solve
+  float car_fL = 0, car_fT = 0, car_fR = 0, car_fX = 0, car_fY = 0;               // the five forces of the previous solve (warm start)
+  bool car_warm = false;
   // Car floor friction solved to convergence (SPECIFICATION: oracle car_floor_friction): given the base
   // acceleration (a0, a1, a2) from everything else, in body axes, (1) the direct solve with all five elements
   // unclamped - eliminating f_i = (c_i - J_i a) / D_i leaves K a = M a_other + sum J_i^T c_i / D_i with the constant
   // K = M + sum J_i^T J_i / D_i, block diagonal {x, yaw} + {y} - and its forces clamped to their bounds, then (2)
-  // CAR_FRICTION_SWEEPS projected Gauss-Seidel sweeps over the accumulated forces (order L, T, R, X, Y).  Writes R.a
-  // (world axes), the spin accelerations eacc and the friction's share car_f* of the base acceleration.
+  // CAR_FRICTION_SWEEPS projected Gauss-Seidel sweeps over the accumulated forces (order L, T, R, X, Y).  Only the
+  // first solve of an env-step does (1): every later one starts from the previous solve's forces (warm start) and
+  // runs CAR_FRICTION_SWEEPS_WARM sweeps.  Writes R.a (world axes), the spin accelerations eacc and the friction's
+  // share car_f* of the base acceleration.
   auto car_floor = [&](const float a0, const float a1, const float a2) {
 #pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
     constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CJD = 0.001f, CRW = 0.05f, AB = -CM * COY;
@@ -1315,17 +1321,21 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     const float rL = -bc * (vby - 0.13f * R.w + CRW * ext[0]), rT = -bc * (vbx - 0.1f * R.w), rR = -bc * (vby + 0.13f * R.w + CRW * ext[1]);
     const float rX = -bc * (vbx + 0.1f * R.w - CRW * ext[3]), rY = -bc * (vby + CRW * ext[2]);
     const float cL = rL - CRW * qL, cR = rR - CRW * qR, cX = rX - CRW * qX, cY = rY - CRW * qY;
-    const float b0 = CM * a0 + AB * a2 + car_w_T * rT + car_w_X * cX;
-    const float b1 = CM * a1 + car_w_L * cL + car_w_L * cR + car_w_Y * cY;
-    const float b2 = AB * a0 + CIO * a2 + (-0.13f * car_w_L) * cL + (-0.1f * car_w_T) * rT + (0.13f * car_w_L) * cR + (0.1f * car_w_X) * cX;
-    const float n0 = (car_K22 * b0 - car_K02 * b2) * car_idk, n1 = b1 * car_iK11, n2 = (car_K00 * b2 - car_K02 * b0) * car_idk;
-    float fL = clampf(car_w_L * (cL - (n1 - 0.13f * n2)), -LIML, LIML), fT = clampf(car_w_T * (rT - (n0 - 0.1f * n2)), -LIMT, LIMT);
-    float fR = clampf(car_w_L * (cR - (n1 + 0.13f * n2)), -LIML, LIML), fX = clampf(car_w_X * (cX - (n0 + 0.1f * n2)), -LIMC, LIMC);
-    float fY = clampf(car_w_Y * (cY - n1), -LIMC, LIMC);
+    float fL = car_fL, fT = car_fT, fR = car_fR, fX = car_fX, fY = car_fY;
+    if (!car_warm) {   // (uniform: the first solve of the step)
+      const float b0 = CM * a0 + AB * a2 + car_w_T * rT + car_w_X * cX;
+      const float b1 = CM * a1 + car_w_L * cL + car_w_L * cR + car_w_Y * cY;
+      const float b2 = AB * a0 + CIO * a2 + (-0.13f * car_w_L) * cL + (-0.1f * car_w_T) * rT + (0.13f * car_w_L) * cR + (0.1f * car_w_X) * cX;
+      const float n0 = (car_K22 * b0 - car_K02 * b2) * car_idk, n1 = b1 * car_iK11, n2 = (car_K00 * b2 - car_K02 * b0) * car_idk;
+      fL = clampf(car_w_L * (cL - (n1 - 0.13f * n2)), -LIML, LIML); fT = clampf(car_w_T * (rT - (n0 - 0.1f * n2)), -LIMT, LIMT);
+      fR = clampf(car_w_L * (cR - (n1 + 0.13f * n2)), -LIML, LIML); fX = clampf(car_w_X * (cX - (n0 + 0.1f * n2)), -LIMC, LIMC);
+      fY = clampf(car_w_Y * (cY - n1), -LIMC, LIMC);
+    }
+    const int nsweeps = car_warm ? CAR_FRICTION_SWEEPS_WARM : CAR_FRICTION_SWEEPS;
     float g0 = UL0 * fL + UT0 * fT - UL0 * fR + UX0 * fX, g1 = M3 * fL + M3 * fR + M3 * fY, g2 = UL2 * fL + UT2 * fT - UL2 * fR + UX2 * fX;
     float sL = qL + CRW * fL * car_iIw, sR = qR + CRW * fR * car_iIw, sX = qX + CRW * fX * car_iIb, sY = qY + CRW * fY * car_iIb;
-#pragma unroll
-    for (int sw = 0; sw < CAR_FRICTION_SWEEPS; sw++) {
+#pragma unroll 1
+    for (int sw = 0; sw < nsweeps; sw++) {
       {
         const float sa = (a1 + g1) - 0.13f * (a2 + g2) + CRW * sL, fn = clampf(fL + (rL - sa - car_R_L * fL) * car_iA_L, -LIML, LIML), df = fn - fL;
         fL = fn; g0 += UL0 * df; g1 += M3 * df; g2 += UL2 * df; sL += CRW * df * car_iIw;
@@ -1348,6 +1358,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       }
     }
     car_f0 = g0; car_f1 = g1; car_f2 = g2;
+    car_fL = fL; car_fT = fT; car_fR = fR; car_fX = fX; car_fY = fY; car_warm = true;
     const float t0 = a0 + g0, t1 = a1 + g1;
     R.ax = cy * t0 - sy * t1; R.ay = sy * t0 + cy * t1; R.aw = a2 + g2;
     eacc[0] = sL; eacc[1] = sR; eacc[2] = sY; eacc[3] = -sX; eacc[4] = -CJD * ext[4] * car_iIb;
@@ -1414,6 +1425,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         R.m0 = (CM * CIO - b * b) * id; R.m1 = (a * b) * id; R.m2 = (-a * CM) * id;
         R.m3 = (CM * CIO - a * a) * id; R.m4 = (-b * CM) * id; R.m5 = (CM * CM) * id;
       }
+      if (sub == nsub) car_warm = false;      // the forward evaluation behind the observation solves cold: obs = f(state)
       car_floor(0.f, R.w * R.w * COY, 0.f);   // M^-1 (centrifugal force of the offset COM) in body axes
       car_px = R.ax; car_py = R.ay; car_pw = R.aw;
     }
