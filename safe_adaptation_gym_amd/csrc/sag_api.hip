@@ -268,6 +268,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.nstep = nstep < 0 ? c->rb.nstep : nstep;
   a.nstep_table = c->rb.nstep;
   a.h = (float)c->rb.dt;
+  a.car = car_fric_constants(a.h);
   a.key0 = (uint32_t)(c->cfg.seed & 0xffffffffu); a.key1 = (uint32_t)(c->cfg.seed >> 32);  // sag_set_seed
   a.obs = d_obs; a.reward = d_rew; a.cost = d_cost; a.done = d_done; a.goal_met = d_met;
   a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;

@@ -97,7 +97,19 @@ __host__ __device__ inline void unpack_tstate(uint32_t t, int32_t* ri) {
   ri[SAG_I_CATCH_TIMER] = t >> 7 & 15; ri[SAG_I_ACTIVE_MASK] = t >> 11 & 63;
 }
 
+// Car floor friction: what depends on the substep length only (oracle car_floor_friction).  Computed on the host
+// (launch_step) and handed over as kernel arguments: wave-uniform values that live in SGPRs instead of ~19 VGPRs of
+// kernels that are short of them (the busy Car kernel spilled its friction solve to scratch: 50x slower there).
+struct CarFricK {
+  float iIw, iIb;                    // 1 / (inertia + h damping) of a wheel / the rear ball
+  float iA_L, iA_T, iA_X, iA_Y;      // 1 / (A + R) per element kind: L wheels rolling, T lateral (merged), X / Y caster
+  float R_L, R_T, R_X, R_Y;          // regulariser R = A (1 - d0) / d0 (T: half, two equal elements merged)
+  float w_L, w_T, w_X, w_Y;          // 1 / D = 1 / (r_w^2 / I_spin + R): weight of the eliminated element in the direct solve
+  float K00, K02, K22, idk, iK11;    // friction-augmented inertia K = M + sum J^T J / D: {x, yaw} block, its 1 / det, 1 / K_yy
+};
+
 struct StepArgs {
+  CarFricK car;
   int envs_per_wave;  // single-launch form (k_step): 8..64 envs per wavefront, by batch size
   float* S;          // [DEV_GROUPS][N] float4 (see didx)
   int32_t* I;        // tstate [N], then (meta, step, envid, flags) [N] int4 (see iaddr)
@@ -969,6 +981,32 @@ enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2, MODE_POST = 3 };
 // the same step
 constexpr uint32_t TS_BUSY_BIT = 1u << 28;
 
+// Car: 1 / inertia of the spinning parts (joint damping implicit: I + h d); per floor-friction element (L / R the
+// wheels' rolling directions, T their merged lateral element, X / Y the caster's: oracle car_floor_friction) the
+// regulariser R = A (1 - d0) / d0 of A = J M^-1 J^T + r_w^2 / I_spin, 1 / (A + R), the weight 1 / D = 1 / (r_w^2 / I_spin + R)
+// of the eliminated element, and the friction-augmented inertia K = M + sum J^T J / D of the direct solve.  Body
+// frame: constants up to the h-dependent spin terms.
+inline CarFricK car_fric_constants(float h) {
+  CarFricK k;
+  constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CRW = 0.05f, AB = -CM * COY;
+  constexpr float IDC = 1.0f / (CM * (CM * CIO - AB * AB));
+  constexpr float M0 = (CM * CIO) * IDC, M2 = (-AB * CM) * IDC, M3 = (CM * CIO - AB * AB) * IDC, M5 = (CM * CM) * IDC;
+  k.iIw = 1.0f / (CAR_IW + h * 0.001f); k.iIb = 1.0f / (CAR_IB + h * 0.001f);
+  const float spw = CRW * CRW * k.iIw, spb = CRW * CRW * k.iIb;
+  // d = body y at lever (rx, .): J = (0, 1, rx) -> A = M3 + M5 rx^2;  d = body x at (., ry): J = (1, 0, -ry) -> A = M0 - 2 M2 ry + M5 ry^2
+  const float A_L = M3 + M5 * 0.13f * 0.13f + spw, A_T = M0 - 2 * M2 * 0.1f + M5 * 0.1f * 0.1f;
+  const float A_X = M0 + 2 * M2 * 0.1f + M5 * 0.1f * 0.1f + spb, A_Y = M3 + spb;
+  constexpr float RF = (1.0f - SOL_D0) / SOL_D0;
+  k.R_L = A_L * RF; k.R_T = 0.5f * A_T * RF; k.R_X = A_X * RF; k.R_Y = A_Y * RF;   // T: two equal elements merged
+  k.iA_L = 1.0f / (A_L + k.R_L); k.iA_T = 1.0f / (A_T + k.R_T); k.iA_X = 1.0f / (A_X + k.R_X); k.iA_Y = 1.0f / (A_Y + k.R_Y);
+  k.w_L = 1.0f / (spw + k.R_L); k.w_T = 1.0f / k.R_T; k.w_X = 1.0f / (spb + k.R_X); k.w_Y = 1.0f / (spb + k.R_Y);
+  k.K00 = CM + k.w_T + k.w_X; k.K02 = AB - 0.1f * k.w_T + 0.1f * k.w_X;
+  k.K22 = CIO + 0.13f * 0.13f * (k.w_L + k.w_L) + 0.1f * 0.1f * k.w_T + 0.1f * 0.1f * k.w_X;
+  k.idk = 1.0f / (k.K00 * k.K22 - k.K02 * k.K02);
+  k.iK11 = 1.0f / (CM + k.w_L + k.w_L + k.w_Y);
+  return k;
+}
+
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX, int MODE>
 __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const int lane, const int i,
                                           const bool live, const int base_env, const int nvalid,
@@ -1267,33 +1305,6 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       }
     }
   } else {
-  // Car: 1 / inertia of the spinning parts (joint damping implicit: I + h d); per floor-friction element (L / R the
-  // wheels' rolling directions, T their merged lateral element, X / Y the caster's: oracle car_floor_friction) the
-  // regulariser R = A (1 - d0) / d0 of A = J M^-1 J^T + r_w^2 / I_spin, 1 / (A + R), the weight 1 / D = 1 / (r_w^2 / I_spin + R)
-  // of the eliminated element, and the friction-augmented inertia K = M + sum J^T J / D of the direct solve.  Body
-  // frame: constants up to the h-dependent spin terms; once per step
-  float car_iIw = 0, car_iIb = 0, car_iA_L = 0, car_iA_T = 0, car_iA_X = 0, car_iA_Y = 0;
-  float car_R_L = 0, car_R_T = 0, car_R_X = 0, car_R_Y = 0, car_w_L = 0, car_w_T = 0, car_w_X = 0, car_w_Y = 0;
-  float car_K00 = 0, car_K02 = 0, car_K22 = 0, car_idk = 0, car_iK11 = 0;
-  if constexpr (CAR) {
-    constexpr float CM = CAR_M, CIO = CAR_IO, COY = CAR_OY, CRW = 0.05f, AB = -CM * COY;
-    constexpr float IDC = 1.0f / (CM * (CM * CIO - AB * AB));
-    constexpr float M0 = (CM * CIO) * IDC, M2 = (-AB * CM) * IDC, M3 = (CM * CIO - AB * AB) * IDC, M5 = (CM * CM) * IDC;
-    car_iIw = 1.0f / (CAR_IW + h * 0.001f); car_iIb = 1.0f / (CAR_IB + h * 0.001f);
-    const float spw = CRW * CRW * car_iIw, spb = CRW * CRW * car_iIb;
-    // d = body y at lever (rx, .): J = (0, 1, rx) -> A = M3 + M5 rx^2;  d = body x at (., ry): J = (1, 0, -ry) -> A = M0 - 2 M2 ry + M5 ry^2
-    const float A_L = M3 + M5 * 0.13f * 0.13f + spw, A_T = M0 - 2 * M2 * 0.1f + M5 * 0.1f * 0.1f;
-    const float A_X = M0 + 2 * M2 * 0.1f + M5 * 0.1f * 0.1f + spb, A_Y = M3 + spb;
-    constexpr float RF = (1.0f - SOL_D0) / SOL_D0;
-    car_R_L = A_L * RF; car_R_T = 0.5f * A_T * RF; car_R_X = A_X * RF; car_R_Y = A_Y * RF;   // T: two equal elements merged
-    car_iA_L = 1.0f / (A_L + car_R_L); car_iA_T = 1.0f / (A_T + car_R_T);
-    car_iA_X = 1.0f / (A_X + car_R_X); car_iA_Y = 1.0f / (A_Y + car_R_Y);
-    car_w_L = 1.0f / (spw + car_R_L); car_w_T = 1.0f / car_R_T; car_w_X = 1.0f / (spb + car_R_X); car_w_Y = 1.0f / (spb + car_R_Y);
-    car_K00 = CM + car_w_T + car_w_X; car_K02 = AB - 0.1f * car_w_T + 0.1f * car_w_X;
-    car_K22 = CIO + 0.13f * 0.13f * (car_w_L + car_w_L) + 0.1f * 0.1f * car_w_T + 0.1f * 0.1f * car_w_X;
-    car_idk = 1.0f / (car_K00 * car_K22 - car_K02 * car_K02);
-    car_iK11 = 1.0f / (CM + car_w_L + car_w_L + car_w_Y);
-  }
   float car_f0 = 0, car_f1 = 0, car_f2 = 0, car_px = 0, car_py = 0, car_pw = 0;   // friction's share of the base acceleration (body axes); R.a after the first solve
   float car_fL = 0, car_fT = 0, car_fR = 0, car_fX = 0, car_fY = 0;               // the five forces of the previous solve (warm start)
   bool car_warm = false;
@@ -1316,52 +1327,59 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     constexpr float LIML = MU * CNL, LIMT = 2 * MU * CNL, LIMC = MU * CNC;
     const float vbx = cy * R.vx + sy * R.vy, vby = cy * R.vy - sy * R.vx, bc = sol0.bcoef;
     // spin accelerations without floor friction (caster x couples to -ball_y), reference accelerations -b slip
-    const float qL = (clampf(ctrl0, -0.02f, 0.02f) - CJD * ext[0]) * car_iIw, qR = (clampf(ctrl1, -0.02f, 0.02f) - CJD * ext[1]) * car_iIw;
-    const float qX = CJD * ext[3] * car_iIb, qY = -CJD * ext[2] * car_iIb;
+    const float qL = (clampf(ctrl0, -0.02f, 0.02f) - CJD * ext[0]) * p.car.iIw, qR = (clampf(ctrl1, -0.02f, 0.02f) - CJD * ext[1]) * p.car.iIw;
+    const float qX = CJD * ext[3] * p.car.iIb, qY = -CJD * ext[2] * p.car.iIb;
     const float rL = -bc * (vby - 0.13f * R.w + CRW * ext[0]), rT = -bc * (vbx - 0.1f * R.w), rR = -bc * (vby + 0.13f * R.w + CRW * ext[1]);
     const float rX = -bc * (vbx + 0.1f * R.w - CRW * ext[3]), rY = -bc * (vby + CRW * ext[2]);
     const float cL = rL - CRW * qL, cR = rR - CRW * qR, cX = rX - CRW * qX, cY = rY - CRW * qY;
     float fL = car_fL, fT = car_fT, fR = car_fR, fX = car_fX, fY = car_fY;
+#ifdef SAG_ABL_CARFRIC   // timing-only build: no floor friction at all
+    car_warm = true;
+#endif
     if (!car_warm) {   // (uniform: the first solve of the step)
-      const float b0 = CM * a0 + AB * a2 + car_w_T * rT + car_w_X * cX;
-      const float b1 = CM * a1 + car_w_L * cL + car_w_L * cR + car_w_Y * cY;
-      const float b2 = AB * a0 + CIO * a2 + (-0.13f * car_w_L) * cL + (-0.1f * car_w_T) * rT + (0.13f * car_w_L) * cR + (0.1f * car_w_X) * cX;
-      const float n0 = (car_K22 * b0 - car_K02 * b2) * car_idk, n1 = b1 * car_iK11, n2 = (car_K00 * b2 - car_K02 * b0) * car_idk;
-      fL = clampf(car_w_L * (cL - (n1 - 0.13f * n2)), -LIML, LIML); fT = clampf(car_w_T * (rT - (n0 - 0.1f * n2)), -LIMT, LIMT);
-      fR = clampf(car_w_L * (cR - (n1 + 0.13f * n2)), -LIML, LIML); fX = clampf(car_w_X * (cX - (n0 + 0.1f * n2)), -LIMC, LIMC);
-      fY = clampf(car_w_Y * (cY - n1), -LIMC, LIMC);
+      const float b0 = CM * a0 + AB * a2 + p.car.w_T * rT + p.car.w_X * cX;
+      const float b1 = CM * a1 + p.car.w_L * cL + p.car.w_L * cR + p.car.w_Y * cY;
+      const float b2 = AB * a0 + CIO * a2 + (-0.13f * p.car.w_L) * cL + (-0.1f * p.car.w_T) * rT + (0.13f * p.car.w_L) * cR + (0.1f * p.car.w_X) * cX;
+      const float n0 = (p.car.K22 * b0 - p.car.K02 * b2) * p.car.idk, n1 = b1 * p.car.iK11, n2 = (p.car.K00 * b2 - p.car.K02 * b0) * p.car.idk;
+      fL = clampf(p.car.w_L * (cL - (n1 - 0.13f * n2)), -LIML, LIML); fT = clampf(p.car.w_T * (rT - (n0 - 0.1f * n2)), -LIMT, LIMT);
+      fR = clampf(p.car.w_L * (cR - (n1 + 0.13f * n2)), -LIML, LIML); fX = clampf(p.car.w_X * (cX - (n0 + 0.1f * n2)), -LIMC, LIMC);
+      fY = clampf(p.car.w_Y * (cY - n1), -LIMC, LIMC);
     }
+#ifdef SAG_ABL_CARFRIC
+    const int nsweeps = 0;
+#else
     const int nsweeps = car_warm ? CAR_FRICTION_SWEEPS_WARM : CAR_FRICTION_SWEEPS;
+#endif
     float g0 = UL0 * fL + UT0 * fT - UL0 * fR + UX0 * fX, g1 = M3 * fL + M3 * fR + M3 * fY, g2 = UL2 * fL + UT2 * fT - UL2 * fR + UX2 * fX;
-    float sL = qL + CRW * fL * car_iIw, sR = qR + CRW * fR * car_iIw, sX = qX + CRW * fX * car_iIb, sY = qY + CRW * fY * car_iIb;
+    float sL = qL + CRW * fL * p.car.iIw, sR = qR + CRW * fR * p.car.iIw, sX = qX + CRW * fX * p.car.iIb, sY = qY + CRW * fY * p.car.iIb;
 #pragma unroll 1
     for (int sw = 0; sw < nsweeps; sw++) {
       {
-        const float sa = (a1 + g1) - 0.13f * (a2 + g2) + CRW * sL, fn = clampf(fL + (rL - sa - car_R_L * fL) * car_iA_L, -LIML, LIML), df = fn - fL;
-        fL = fn; g0 += UL0 * df; g1 += M3 * df; g2 += UL2 * df; sL += CRW * df * car_iIw;
+        const float sa = (a1 + g1) - 0.13f * (a2 + g2) + CRW * sL, fn = clampf(fL + (rL - sa - p.car.R_L * fL) * p.car.iA_L, -LIML, LIML), df = fn - fL;
+        fL = fn; g0 += UL0 * df; g1 += M3 * df; g2 += UL2 * df; sL += CRW * df * p.car.iIw;
       }
       {
-        const float sa = (a0 + g0) - 0.1f * (a2 + g2), fn = clampf(fT + (rT - sa - car_R_T * fT) * car_iA_T, -LIMT, LIMT), df = fn - fT;
+        const float sa = (a0 + g0) - 0.1f * (a2 + g2), fn = clampf(fT + (rT - sa - p.car.R_T * fT) * p.car.iA_T, -LIMT, LIMT), df = fn - fT;
         fT = fn; g0 += UT0 * df; g2 += UT2 * df;
       }
       {
-        const float sa = (a1 + g1) + 0.13f * (a2 + g2) + CRW * sR, fn = clampf(fR + (rR - sa - car_R_L * fR) * car_iA_L, -LIML, LIML), df = fn - fR;
-        fR = fn; g0 -= UL0 * df; g1 += M3 * df; g2 -= UL2 * df; sR += CRW * df * car_iIw;
+        const float sa = (a1 + g1) + 0.13f * (a2 + g2) + CRW * sR, fn = clampf(fR + (rR - sa - p.car.R_L * fR) * p.car.iA_L, -LIML, LIML), df = fn - fR;
+        fR = fn; g0 -= UL0 * df; g1 += M3 * df; g2 -= UL2 * df; sR += CRW * df * p.car.iIw;
       }
       {
-        const float sa = (a0 + g0) + 0.1f * (a2 + g2) + CRW * sX, fn = clampf(fX + (rX - sa - car_R_X * fX) * car_iA_X, -LIMC, LIMC), df = fn - fX;
-        fX = fn; g0 += UX0 * df; g2 += UX2 * df; sX += CRW * df * car_iIb;
+        const float sa = (a0 + g0) + 0.1f * (a2 + g2) + CRW * sX, fn = clampf(fX + (rX - sa - p.car.R_X * fX) * p.car.iA_X, -LIMC, LIMC), df = fn - fX;
+        fX = fn; g0 += UX0 * df; g2 += UX2 * df; sX += CRW * df * p.car.iIb;
       }
       {
-        const float sa = (a1 + g1) + CRW * sY, fn = clampf(fY + (rY - sa - car_R_Y * fY) * car_iA_Y, -LIMC, LIMC), df = fn - fY;
-        fY = fn; g1 += M3 * df; sY += CRW * df * car_iIb;
+        const float sa = (a1 + g1) + CRW * sY, fn = clampf(fY + (rY - sa - p.car.R_Y * fY) * p.car.iA_Y, -LIMC, LIMC), df = fn - fY;
+        fY = fn; g1 += M3 * df; sY += CRW * df * p.car.iIb;
       }
     }
     car_f0 = g0; car_f1 = g1; car_f2 = g2;
     car_fL = fL; car_fT = fT; car_fR = fR; car_fX = fX; car_fY = fY; car_warm = true;
     const float t0 = a0 + g0, t1 = a1 + g1;
     R.ax = cy * t0 - sy * t1; R.ay = sy * t0 + cy * t1; R.aw = a2 + g2;
-    eacc[0] = sL; eacc[1] = sR; eacc[2] = sY; eacc[3] = -sX; eacc[4] = -CJD * ext[4] * car_iIb;
+    eacc[0] = sL; eacc[1] = sR; eacc[2] = sY; eacc[3] = -sX; eacc[4] = -CJD * ext[4] * p.car.iIb;
   };
   // Point: what does not change over the substeps - the inverse inertia's determinant (a^2 + b^2 = mc^2 for any
   // heading), its yaw element, the yaw servo's denominator, the drive force - leaves the loop with its two divisions

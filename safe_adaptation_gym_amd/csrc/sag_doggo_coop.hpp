@@ -598,11 +598,26 @@ __device__ __attribute__((noinline)) double dc_rows_finish(int hf, int u, int nr
   return a0;
 }
 
+// a value the optimiser must treat as new at this point (no instruction is emitted)
+#ifndef DC_OPAQUE
+#define DC_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+// lower half of the wavefront: a, upper half: b.  The lane mask is a CONSTANT (0xffffffff00000000) - written as a
+// select on `half`, it is a computed wave mask that lives in a spilled SGPR pair inside the PGS loop and costs two
+// v_readlane per use.
+#ifndef DC_HALF_SELECT
+__device__ inline int dc_half_select(int a, int b) {
+  int out;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(out) : "v"(a), "v"(b), "s"(0xffffffff00000000ull));
+  return out;
+}
+#define DC_HALF_SELECT(a, b, half) dc_half_select(a, b)
+#endif
 // the same for a float
 __device__ inline float dc_bcastf(float v, int lane_in_half, int half) {
   const int b = __float_as_int(v);
   const int v0 = __builtin_amdgcn_readlane(b, lane_in_half);
-  if (DC_EPW == 2) { const int v1 = __builtin_amdgcn_readlane(b, lane_in_half + 32); return __int_as_float(half ? v1 : v0); }
+  if (DC_EPW == 2) { const int v1 = __builtin_amdgcn_readlane(b, lane_in_half + 32); return __int_as_float(DC_HALF_SELECT(v0, v1, half)); }
   return __int_as_float(v0);
 }
 // v of lane `lane_in_half` of this lane's own half, for every lane (lane index uniform across the wavefront)
@@ -613,7 +628,7 @@ __device__ inline double dc_bcast(double v, int lane_in_half, int half) {
   int l = lo0, h = hi0;
   if (DC_EPW == 2) {
     const int lo1 = __builtin_amdgcn_readlane(lo, lane_in_half + 32), hi1 = __builtin_amdgcn_readlane(hi, lane_in_half + 32);
-    l = half ? lo1 : lo0; h = half ? hi1 : hi0;
+    l = DC_HALF_SELECT(lo0, lo1, half); h = DC_HALF_SELECT(hi0, hi1, half);
   }
   return __longlong_as_double((long long)(((unsigned long long)(unsigned int)h << 32) | (unsigned int)l));
 }
@@ -778,24 +793,27 @@ __device__ __attribute__((noinline)) void dc_pgs_wide(const int e, const int lan
   float fn_contact = isfric ? fpar0 : 0.f;
   if (warm) {
 #pragma unroll
-    for (int r = 0; r < DC_ROWS; r++) {
-      if (r >= nrows) break;
-      acc += Ar[r] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), r));
-    }
+    for (int r = 0; r < DC_ROWS; r++)
+      if (r < __builtin_amdgcn_readfirstlane(nrows)) acc += Ar[r] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), r));   // (no `break`: the loop must unroll - Ar is a register array)
   }
+  // (the same short dependent chain as the 32-lane form in k_doggo_physics: see there)
+  const float ninv = okA ? -inv : 0.f, c1 = okA ? 1.f - reg * inv : 1.f, c0 = okA ? aref * inv : 0.f;
+  const float mu_eff = isfric ? mu : 0.f, hi0 = isfric ? 0.f : 3.0e38f;
+  const int nrows_u = __builtin_amdgcn_readfirstlane(nrows);
 #pragma unroll 1
   for (int it = 0; it < iters; it++)
 #pragma unroll
-    for (int r = 0; r < DC_ROWS; r++) {
-      if (r >= nrows) break;
-      const float hi = isfric ? mu * fn_contact : 3.0e38f, lo = isfric ? -hi : 0.f;
-      const float fnew = fminf(fmaxf(f + (aref - acc - reg * f) * inv, lo), hi);
-      const float df_mine = (lane == r && okA) ? fnew - f : 0.f;
-      const float df = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(df_mine), r));
-      f += df_mine;
-      if (r == parent) fn_contact += df;
-      acc += Ar[r] * df;
-    }
+    for (int r = 0; r < DC_ROWS; r++)
+      if (r < nrows_u) {
+        int uu = lane, pp = parent;
+        DC_OPAQUE(uu); DC_OPAQUE(pp);
+        const float hi = fmaf(mu_eff, fn_contact, hi0);
+        const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
+        const float df = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc - f), r));
+        acc = fmaf(Ar[r], df, acc);
+        f = uu == r ? fc : f;
+        fn_contact += pp == r ? df : 0.f;
+      }
   if (mine) E.rF[lane] = (double)f;
 }
 
@@ -1074,25 +1092,36 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       float acc = (float)a0;
       if (sub > 0) {
 #pragma unroll
-        for (int r = 0; r < DC_PGS_LANES; r++) {
-          if (r >= nmax) break;
-          acc += Ar[r] * dc_bcastf(f, r, half);
-        }
+        for (int r = 0; r < DC_PGS_LANES; r++)
+          if (r < __builtin_amdgcn_readfirstlane(nmax)) acc += Ar[r] * dc_bcastf(f, r, half);   // (no `break`: the loop must unroll - Ar is a register array)
       }
+      // The sweep is ONE dependent chain through all rows (row r+1 needs the acc that row r's increment changed); a
+      // wavefront alone on its SIMD pays every link's latency, so the chain is kept short: the update
+      //   f <- clamp(f + (aref - acc - reg f) inv)  =  clamp(c1 f + c0 - inv acc),  c1 = 1 - reg inv, c0 = aref inv
+      // has its own-force part t = c1 f + c0 precomputed (f changes only at the row's own turn), every lane computes a
+      // candidate increment and the row's is picked by the broadcast itself (no select in front of it); rows that take
+      // no part (A <= 0, lanes beyond the last row) carry inv = 0, c1 = 1, c0 = 0: their candidate is 0.  Chain per
+      // row: fma, max, min, sub, readlane, (half select), fma.
+      // The lane tests `u == r`, `parent == r` are made on the spot (a compare + a select): hoisted out of the sweep
+      // loop they are 64 wave masks that live in spilled SGPRs and come back through two v_readlane each per row.
+      const float ninv = okA ? -inv : 0.f, c1 = okA ? 1.f - reg * inv : 1.f, c0 = okA ? aref * inv : 0.f;
+      const float mu_eff = isfric ? mu : 0.f, hi0 = isfric ? 0.f : 3.0e38f;   // bounds: [-mu fn, mu fn] / [0, inf)
+      const int nmax_u = __builtin_amdgcn_readfirstlane(nmax);               // (uniform: the row tests are scalar branches)
 #pragma unroll 1
       for (int it = 0; it < iters; it++)
 #pragma unroll
-        for (int r = 0; r < DC_PGS_LANES; r++) {   // unrolled: lane index and register index of the row are constants
-          if (r >= nmax) break;
-          const float hi = isfric ? mu * fn_contact : 3.0e38f, lo = isfric ? -hi : 0.f;
-          const float fnew = fminf(fmaxf(f + (aref - acc - reg * f) * inv, lo), hi);
-          const float df_mine = (u == r && okA) ? fnew - f : 0.f;
-          const float df = dc_bcastf(df_mine, r, half);
-          f += df_mine;
-          // a friction row tracks its contact's normal force by the same increments
-          if (r == parent) fn_contact += df;
-          acc += Ar[r] * df;
-        }
+        for (int r = 0; r < DC_PGS_LANES; r++)   // unrolled: lane index and register index of the row are constants
+          if (r < nmax_u) {
+            int uu = u, pp = parent;
+            DC_OPAQUE(uu); DC_OPAQUE(pp);   // (keeps the two compares below inside the loop)
+            const float hi = fmaf(mu_eff, fn_contact, hi0);
+            const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
+            const float df = dc_bcastf(fc - f, r, half);
+            acc = fmaf(Ar[r], df, acc);
+            f = uu == r ? fc : f;
+            // a friction row tracks its contact's normal force by the same increments
+            fn_contact += pp == r ? df : 0.f;
+          }
       if (mine) E.rF[u] = (double)f;
     } else {
       // an env with more than 32 rows (rare: a body deep inside the task box touches several of its geoms): the two envs

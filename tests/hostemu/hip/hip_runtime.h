@@ -306,6 +306,13 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 // v_readlane_b32 (the lane index is wave-uniform): the value of one lane, in every lane of the wavefront
 #define __builtin_amdgcn_readlane(v, l) __shfl((int)(v), (int)(l), 64)
+// v_readfirstlane_b32 is used on values that ARE wave-uniform (to tell the compiler so): the lane's own value
+#define __builtin_amdgcn_readfirstlane(v) (v)
+// v_med3_f32: the median of three = clamp(x, lo, hi) for lo <= hi
+static inline float hostemu_med3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
+#define __builtin_amdgcn_fmed3f(a, b, c) hostemu_med3f(a, b, c)
+#define DC_HALF_SELECT(a, b, half) ((half) ? (b) : (a))   // csrc/sag_doggo_coop.hpp: a v_cndmask with a constant lane mask on the GPU
+#define DC_OPAQUE(x) asm volatile("" : "+r"(x))   // csrc/sag_doggo_coop.hpp: the "+v" (VGPR) constraint is the GPU's
 #if !defined(__clang__)
 #define __builtin_readcyclecounter() __builtin_ia32_rdtsc()
 #endif

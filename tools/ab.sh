@@ -12,7 +12,7 @@
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-BASE="--no-cpu-baseline --no-c2 ${BENCH_ARGS}"
+BASE="--no-cpu-baseline --no-c2 --no-c4 ${BENCH_ARGS}"
 
 variant_env() {  # prints the env assignments that select variant $1
   case "$1" in
