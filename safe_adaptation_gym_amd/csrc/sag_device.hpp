@@ -1443,6 +1443,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         R.m0 = (CM * CIO - b * b) * id; R.m1 = (a * b) * id; R.m2 = (-a * CM) * id;
         R.m3 = (CM * CIO - a * a) * id; R.m4 = (-b * CM) * id; R.m5 = (CM * CM) * id;
       }
+#ifdef SAG_CYC_SPLIT   // (diagnosis: what precedes the friction solve is booked under `load`)
+      CYC(CY_LOAD);
+#endif
       if (sub == nsub) car_warm = false;      // the forward evaluation behind the observation solves cold: obs = f(state)
       car_floor(0.f, R.w * R.w * COY, 0.f);   // M^-1 (centrifugal force of the offset COM) in body axes
       car_px = R.ax; car_py = R.ay; car_pw = R.aw;
@@ -1486,16 +1489,22 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       if (dx * dx + dyy * dyy <= rs * rs) hits |= 1u << BOX_ID;
     }
     if (ABL(ABL_NO_RV)) hits = 0;
-    for (uint32_t m = hits; m; m &= m - 1) {
+    // (the task object is every lane's LAST hit - BOX_ID is the highest body index - but at different positions of
+    // the lanes' lists: walked in one loop, every iteration ran both the 1-geom and the 5-geom form of the pair tests
+    // for some lane.  Vases first for all lanes, then the object in one step of its own: the same order per lane.)
+    for (uint32_t m = hits & ~(1u << BOX_ID); m; m &= m - 1) {
       const int k = __ffs(m) - 1;
-      const bool isb = is_box(k);
       dy.ensure(k, false);
       BV V; float cv, sv; load_body(dy, k, V, cv, sv);
-      const float ax0 = V.ax, ay0 = V.ay, aw0 = V.aw;
-      const int n = collide_list<SH_ME, HAS_TBOX>(R, cy, sy, V, isb ? bk.sh : SH_VASE, cv, sv, vsz, 0.f, isb ? solb : sol0);
-      if (!isb) cost_contacts += n;   // the task object is not an obstacle (consts.OBSTACLES)
+      const int n = collide_list<SH_ME, false>(R, cy, sy, V, SH_VASE, cv, sv, vsz, 0.f, sol0);
+      cost_contacts += n;
       if (n) { dy.set_acc(k, V.ax, V.ay, V.aw); active |= 1u << k; }
-      (void)ax0; (void)ay0; (void)aw0;
+    }
+    if (HAS_TBOX && (hits >> BOX_ID & 1u)) {
+      dy.ensure(BOX_ID, false);
+      BV V; float cv, sv; load_body(dy, BOX_ID, V, cv, sv);
+      const int n = collide_list<SH_ME, HAS_TBOX>(R, cy, sy, V, bk.sh, cv, sv, vsz, 0.f, solb);   // the task object is not an obstacle (consts.OBSTACLES)
+      if (n) { dy.set_acc(BOX_ID, V.ax, V.ay, V.aw); active |= 1u << BOX_ID; }
     }
     // HaulBox tether (haul_box.py:21-29): spatial tendon robot site (z .1) <-> box site (z .2),
     // limited to [0, .75]; beyond the limit a soft constraint pulls the two together
@@ -1519,6 +1528,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         }
       }
     }
+#ifdef SAG_CYC_SPLIT   // (diagnosis: the robot's contacts are booked under `robot-static`, the re-solve alone under `robot-free`)
+    CYC(CY_RS);
+#endif
     if constexpr (CAR) {
       // the floor friction once more when the contacts (or the tether) changed the base acceleration: what they
       // added now belongs to `everything else`
