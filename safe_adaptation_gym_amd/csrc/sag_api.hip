@@ -403,12 +403,22 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   return 0;
 }
 
-// K <= 21 (the reference's point count): the register-resident kernel at 13 wavefronts per CU; more points per env: the
-// LDS-staged one.  SAG_LIDAR_REG=0 forces the latter (A/B).
+// Small batches (the reference's own 4096 poses): a team of lanes per pose, so that the chip is full and a pose's points
+// are not one serial chain (k_lidar_cost_team).  Large ones, a lane per pose: K <= 21 (the reference's point count) the
+// register-resident kernel at 13 wavefronts per CU, more points per env the LDS-staged one.  SAG_LIDAR_TEAM = 0 / 4 / 16
+// forces the team size (tests run every kernel on the same inputs), SAG_LIDAR_REG=0 the LDS-staged kernel (A/B).
 void launch_lidar_cost(sag_ctx* c, int n, int K, const float* d_robot, const float* d_pts, const uint8_t* d_grp, float hazard_size,
                        float* d_lid, int32_t* d_bins, uint8_t* d_cost) {
   static const bool use_reg = [] { const char* e = getenv("SAG_LIDAR_REG"); return !e || atoi(e) != 0; }();
-  if (K <= LC_KREG && use_reg)
+  int team = n <= 16384 ? 16 : (n <= 131072 ? 4 : 0);
+  if (const char* e = getenv("SAG_LIDAR_TEAM")) team = atoi(e);
+  if (team >= 16)
+    hipLaunchKernelGGL(k_lidar_cost_team<16>, dim3((n + 3) / 4), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts, d_grp, hazard_size,
+                       d_lid, d_bins, d_cost);
+  else if (team >= 4)
+    hipLaunchKernelGGL(k_lidar_cost_team<4>, dim3((n + 15) / 16), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts, d_grp, hazard_size,
+                       d_lid, d_bins, d_cost);
+  else if (K <= LC_KREG && use_reg)
     hipLaunchKernelGGL(k_lidar_cost_reg, dim3((n + WAVE - 1) / WAVE), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts, d_grp,
                        hazard_size, d_lid, d_bins, d_cost);
   else

@@ -2728,6 +2728,77 @@ __global__ __launch_bounds__(WAVE, 3) void k_lidar_cost_reg(int n, int K, const 
   if (live) cost[i] = (uint8_t)cst;
 }
 
+// Few poses (a learner's what-if queries at the reference's own batch - BASELINE config 2: 4096): a lane per pose
+// would leave three quarters of the chip idle and run the K points of a pose as ONE serial chain.  Here a team of LPP
+// lanes shares a pose: lane s takes the points s, s + LPP, ...; the team's closeness values meet in the pose's column
+// of a [48 bins][P poses] tile (ds_max_i32: the maximum does not depend on the order, hence bit-identical to the
+// lane-per-pose kernels), the hazard flags in one word per pose (ds_or).  Any K; no staging: the team's lanes read
+// consecutive points.  Same arithmetic, point for point, as k_lidar_cost.
+template <int LPP>
+__global__ __launch_bounds__(WAVE) void k_lidar_cost_team(int n, int K, const float* __restrict__ robot,
+                                                          const float* __restrict__ points, const uint8_t* __restrict__ group,
+                                                          float hazard_size, float* __restrict__ lidar,
+                                                          int32_t* __restrict__ bins, uint8_t* __restrict__ cost) {
+  constexpr int P = WAVE / LPP;
+  static_assert(LPP >= 2 && (LPP & (LPP - 1)) == 0 && (48 * P) % WAVE == 0, "teams tile the wavefront; the tile is whole rounds of it");
+  __shared__ int tile[48 * P];
+  __shared__ int cflag[P];
+  const int lane = threadIdx.x, pose = lane / LPP, sub = lane % LPP;
+  const size_t e0 = (size_t)blockIdx.x * P;
+  const int nenv = (int)((size_t)n - e0 < (size_t)P ? (size_t)n - e0 : (size_t)P);
+  const size_t i = e0 + pose;
+  const bool live = pose < nenv;
+#pragma unroll
+  for (int q = 0; q < 48 * P / WAVE; q++) tile[q * WAVE + lane] = 0;
+  if (lane < P) cflag[lane] = 0;
+  __syncthreads();
+  if (live) {
+    const float rxf = robot[i * 3], ryf = robot[i * 3 + 1], yawf = robot[i * 3 + 2];
+    const double rx = rxf, ry = ryf, cd = cos((double)yawf), sd = sin((double)yawf);
+    const float t2 = hazard_size * hazard_size;
+    int* acc = tile + pose;
+    int cst = 0;
+#pragma unroll 1
+    for (int j = sub; j < K; j += LPP) {
+      const float2 pt = reinterpret_cast<const float2*>(points)[i * K + j];
+      const int gg = group[i * K + j], g = gg & 127;
+      const double W0 = (double)pt.x - rx, W1 = (double)pt.y - ry;
+      if (gg & 128) {
+        const float d2 = (float)(W0 * W0 + W1 * W1);
+        bool in = d2 <= t2;
+        if (fabsf(d2 - t2) < 1e-5f) in = dist2d(rx, ry, pt.x, pt.y) <= (double)hazard_size;
+        cst |= in;
+      }
+      int b = -1;
+      if (g >= 1 && g <= 3) {
+        const float ex = (float)(W0 * cd + W1 * sd), ey = (float)(W0 * -sd + W1 * cd);
+        const float dist = __builtin_amdgcn_sqrtf(__builtin_fmaf(ex, ex, ey * ey));
+        float alias, sensor = fmaxf(5.0f - dist, 0.0f) * 0.2f;
+        lidar_bin_alias(ex, ey, b, alias);
+        const float edge = fminf(alias, 1.0f - alias);
+        if (!(edge * dist >= __builtin_fmaf(2e-5f, dist, 1.5e-6f)) || b > 15) {
+          const LidarHit h = lidar_exact(rxf, ryf, yawf, pt.x, pt.y);
+          b = h.bin; alias = h.alias; sensor = h.sensor;
+        }
+        const int base = (g == 1 ? 0 : (g == 3 ? 16 : 32)) * P;
+        atomicMax(acc + base + b * P, __float_as_int(sensor));
+        atomicMax(acc + base + ((b + 1) & 15) * P, __float_as_int(alias * sensor));
+        atomicMax(acc + base + ((b + 15) & 15) * P, __float_as_int((1.0f - alias) * sensor));
+      }
+      if (bins) bins[i * K + j] = b;
+    }
+    if (cst) atomicOr(cflag + pose, 1);
+  }
+  __syncthreads();
+  // the block's poses are one contiguous piece of the output: nenv * 48 floats
+  float* dst = lidar + e0 * 48;
+  for (int q = lane; q < nenv * 48; q += WAVE) {
+    const int env = (int)(((uint32_t)q * 43691u) >> 21);   // q / 48, exact for q < 1536
+    dst[q] = __int_as_float(tile[(q - 48 * env) * P + env]);
+  }
+  if (live && sub == 0) cost[i] = (uint8_t)(cflag[pose] != 0);
+}
+
 // synthetic policy: U(-1,1)^nu from Philox stream 2
 __global__ void k_fill_actions(float* actions, const int32_t* I, int N, int nu, uint32_t k0,
                                uint32_t k1, uint32_t step_index) {

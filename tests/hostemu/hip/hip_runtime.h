@@ -295,6 +295,7 @@ static inline long long __double_as_longlong(double d) { long long i; memcpy(&i,
 static inline int atomicAdd(int* p, int v) { const int o = *p; *p = o + v; return o; }
 static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 static inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+static inline int atomicOr(int* p, int v) { const int o = *p; *p = o | v; return o; }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 // gfx950 hardware approximations -> libm (the tests' tolerances cover the ulp-level differences)

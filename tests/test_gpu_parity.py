@@ -51,11 +51,16 @@ def _lidar_inputs(n, K, seed):
   return robot, pts, grp
 
 
+@pytest.mark.parametrize('team', [None, 0, 4, 16])
 @pytest.mark.parametrize('K', [21, 13, 30])
-def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle, K):
-  """K <= 21 runs the register-resident kernel (k_lidar_cost_reg), more points per env the LDS-staged one."""
+def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle, K, team, monkeypatch):
+  """Every kernel behind sag_lidar_cost on the same inputs.  A lane per pose (team 0: the large-batch form): K <= 21 runs
+  the register-resident kernel (k_lidar_cost_reg), more points per env the LDS-staged one; teams of 4 / 16 lanes per
+  pose (k_lidar_cost_team) are what this batch size (BASELINE config 2's 4096) selects by itself (team None)."""
   n = 4096
   robot, pts, grp = _lidar_inputs(n, K, 1)
+  if team is not None:
+    monkeypatch.setenv('SAG_LIDAR_TEAM', str(team))
   ctx = nat.Context('point', n)
   lidar, bins, cost = ctx.lidar_cost(robot, pts, grp)
   o_lidar, o_bins, o_cost = oracle.lidar_cost(robot, pts, grp)
@@ -66,16 +71,19 @@ def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle, K):
   ctx.close()
 
 
+@pytest.mark.parametrize('team', [0, 4, 16])
 @pytest.mark.parametrize('K', [21, 30])
-def test_lidar_cost_device_entry_partial_block_and_unaligned_buffers(nat, K):
-  """sag_lidar_cost_device (the entry bench.py times): n not a multiple of the 64-env block and buffers that start 4
-  bytes into their allocation (the kernels' linear 16-byte copies need their unaligned branch) give the same bins,
-  values and flags as the host-buffer entry; one timed launch is reported as one launch; a rejected call (K beyond the
-  LDS staging) reserves no timing slot."""
+def test_lidar_cost_device_entry_partial_block_and_unaligned_buffers(nat, K, team, monkeypatch):
+  """sag_lidar_cost_device (the entry bench.py times): n not a multiple of the 64-env block (nor of a team kernel's 16 /
+  4 poses) and buffers that start 4 bytes into their allocation (the kernels' linear 16-byte copies need their unaligned
+  branch) give the same bins, values and flags as the host-buffer entry; one timed launch is reported as one launch; a
+  rejected call (K beyond the LDS staging) reserves no timing slot."""
   n = 1000 + 37
   robot, pts, grp = _lidar_inputs(n, K, 3)
   ctx = nat.Context('point', 64)
+  monkeypatch.setenv('SAG_LIDAR_TEAM', '0')     # (read at every launch) the host-buffer entry on the lane-per-pose kernels ...
   lidar0, bins0, cost0 = ctx.lidar_cost(robot, pts, grp)
+  monkeypatch.setenv('SAG_LIDAR_TEAM', str(team))   # ... against the device entry on each kernel form
   off = 4
   bufs = {}
   for name, arr in (('robot', robot.astype(np.float32)), ('pts', pts.astype(np.float32)), ('grp', grp.astype(np.uint8))):
