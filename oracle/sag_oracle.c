@@ -1776,6 +1776,7 @@ void sago_step_batch(OEnv* envs, int n, int robot, const float* actions, uint32_
                      uint32_t key1, float* obs, float* reward, uint8_t* cost, uint8_t* done,
                      uint8_t* goal_met, int nthreads) {
   int nu = NU[robot], od = OBS_DIM[robot];
+  dg_init();   /* shared model tables: before the threads start (see dg_init) */
 #pragma omp parallel for num_threads(nthreads) schedule(static)
   for (int i = 0; i < n; i++) {
     OOut o;
@@ -1797,6 +1798,7 @@ void sago_step_batch_full(OEnv* envs, int n, int robot, const float* actions, co
                           int nstep, float* obs, float* reward, uint8_t* cost, uint8_t* done,
                           uint8_t* goal_met, int32_t* tape_used, double* cost_margin) {
   int nu = NU[robot], od = OBS_DIM[robot];
+  dg_init();
 #pragma omp parallel for num_threads(g_full_threads) schedule(dynamic, 4)
   for (int i = 0; i < n; i++) {
     OOut o;

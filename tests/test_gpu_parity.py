@@ -392,7 +392,7 @@ DRIFT_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpur
 
 
 @pytest.mark.parametrize('robot,task', [('point', 'go_to_goal'), ('car', 'push_box'), ('doggo', 'go_to_goal')])
-def test_free_running_drift(nat, oracle, robot, task):
+def test_free_running_drift(nat, oracle, robot, task, request):
   """Device and fp64 oracle start from the same state and run 200 steps on the same actions, noise and random
   tapes WITHOUT ever being resynchronised (the lockstep tests bound the one-step error only).  Contact dynamics
   amplify rounding - a vase touched one substep earlier ends somewhere else, and a legged robot under random
@@ -407,6 +407,7 @@ def test_free_running_drift(nat, oracle, robot, task):
   # legs run on the host's cores (envs are independent)
   n, T = (2048 if robot == 'doggo' else 192), 200
   oracle.lib.sago_set_threads(min(16, len(os.sched_getaffinity(0))))
+  request.addfinalizer(lambda: oracle.lib.sago_set_threads(1))   # (also when an assertion below fails)
   rf, ri = bu.sample_records_native(robot, task, n, seed=4242)
   ctx = nat.Context(robot, n, seed=99)
   ctx.set_layout(rf, ri)
@@ -478,7 +479,6 @@ def test_free_running_drift(nat, oracle, robot, task):
   else:
     assert abs(per_env.mean()) < max(0.01, 4 * cost_se + 0.002), 'cost rates differ beyond the env-to-env scatter'
   assert met_agree > 0.995
-  oracle.lib.sago_set_threads(1)
   ctx.close()
 
 

@@ -285,3 +285,35 @@ def test_doggo_lidar_uses_the_reference_pinned_routine(oracle):
     np.testing.assert_allclose(obs[:16], obst, rtol=0, atol=1e-14)
     np.testing.assert_allclose(obs[16:32], 0, atol=0)
     np.testing.assert_allclose(obs[32:48], gl, rtol=0, atol=1e-14)
+
+
+def test_first_doggo_call_may_come_from_many_threads():
+  """The model tables are built on first use; the batch driver steps envs on OpenMP threads (sago_set_threads), so the
+  first Doggo call of a process can come from all of them at once (it did in the GPU suite's free-running test, and the
+  racing builds doubled the masses for the rest of the process).  Fresh processes whose FIRST Doggo call is an 8-thread
+  batch (thread pool warm) must report the geoms' total mass afterwards."""
+  import subprocess
+  import sys
+  code = '''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import oracle_lib as ol
+from test_oracle_doggo import doggo_record
+o = ol.Oracle()
+o.lib.sago_set_threads(8)
+from golden_util import base_record
+prf, pri = base_record('go_to_goal', ['robot', 'goal'], {'robot': 0.4})
+for _ in range(3):   # a Point batch first: the thread pool exists and all threads enter the Doggo batch together
+  o.step_batch_full(o.make_batch(np.stack([prf] * 64), np.stack([pri] * 64)), 0, np.zeros((64, 2), np.float32), obs_dim=60)
+recs = [doggo_record(x=0.1 * k) for k in range(64)]
+arr = o.make_batch(np.stack([r[0] for r in recs]), np.stack([r[1] for r in recs]))
+o.step_batch_full(arr, 2, np.zeros((64, 12), np.float32), obs_dim=104)
+rf, ri = doggo_record()
+print(repr(float(o.doggo_debug(o.env(rf, ri))[0][0, 0])))
+''' % __import__('os').path.dirname(__import__('os').path.abspath(__file__))
+  want = 2 * 0.5 * np.pi * 0.075**2 * 0.2
+  for _ in range(6):
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = float(out.stdout.strip().splitlines()[-1])
+    assert m > want and abs(m - 0.039679578751884034) < 1e-12, m
