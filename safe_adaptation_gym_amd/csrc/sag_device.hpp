@@ -505,9 +505,8 @@ __device__ inline float shape_bound(int sh, float vsz, float rstatic) {
 }
 
 // every geom pair of two bodies, geoms of A outer, of B inner (the specification's order).
-// CONST_R: cull with the constant bounding radii of shape_geom; the Doggo instances keep the run-time
-// sqrt form they were validated with (their lane-per-env kernel is at the edge of what the register
-// allocator handles: see DESIGN.md 3.4)
+// CONST_R: cull with the constant bounding radii of shape_geom; the Doggo's planar world (sag_doggo_coop.hpp)
+// keeps the run-time sqrt form it was validated with
 template <bool CONST_R = false>
 __device__ inline int collide_shapes(BV& A, int shA, float ca, float sa, BV& B, int shB, float cb,
                                      float sb, float vsz, float rstatic, const Sol& sol) {
