@@ -109,3 +109,39 @@ def test_shard_ranges():
   assert shard_ranges(4096 * 8, 8)[-1] == (4096 * 7, 4096 * 8)
   r = shard_ranges(5, 8)
   assert r[0] == (0, 1) and r[-1] == (5, 5)
+
+
+def test_roofline_blocks_are_checked_against_the_committed_profile(monkeypatch):
+  """bench.checked(): a block whose kernel the profile of THESE sources lacks is refused (replaced by the reason); one it
+  holds carries the profile's figures; a profile of other sources is reported as such and checks nothing."""
+  sys.path.insert(0, ROOT)
+  import bench
+  sha = bench.source_sha16()
+  prof = {'src_sha16': sha, 'summary': 'profiles/rXX_all_summary.txt',
+          'kernels': {'void sag::k_step_quiet<0, false, false>(sag::StepArgs)': {'calls': 10, 'avg_us': 900.0},
+                      'sag::k_compact(int const*, int, int, int*, int*, int*)': {'calls': 10, 'avg_us': 30.0}}}
+  monkeypatch.setattr(bench, '_PROFILE', prof)
+  ok = bench.roofline_block(892, 1 << 22, 0.95, ['k_compact', 'k_step_quiet<0'])
+  assert ok['profile']['src_sha16'] == sha and set(ok['profile']['kernels']) == {'k_compact', 'k_step_quiet<0'}
+  assert abs(ok['frac'] - 892 * (1 << 22) / 0.95e-3 / 8e12) < 1e-12
+  bad = bench.roofline_block(376, 4096, 0.01, ['k_lidar_cost_team<16>'])
+  assert 'refused' in bad and 'frac' not in bad and 'k_lidar_cost_team<16>' in bad['refused']
+  monkeypatch.setattr(bench, '_PROFILE', dict(prof, src_sha16='0' * 16))
+  other = bench.roofline_block(376, 4096, 0.01, ['k_lidar_cost_team<16>'])
+  assert other['profile'] is None and 'frac' in other and 'other device sources' in other['profile_note']
+
+
+def test_committed_profile_covers_every_kernel_bench_names():
+  """If profiles/kernels.json is of the current device sources it must hold every kernel a bench block names - the same
+  check bench.py makes at run time, here at commit time."""
+  sys.path.insert(0, ROOT)
+  import bench
+  prof = json.load(open(os.path.join(ROOT, 'profiles', 'kernels.json')))
+  if prof.get('src_sha16') != bench.source_sha16():
+    pytest.skip('profiles/kernels.json was measured on other device sources (re-run tools/gpu_final.sh before the round ends)')
+  names = list(prof['kernels'])
+  want = (bench.step_kernels('point', 1 << 22) + bench.step_kernels('point', 4096) + bench.step_kernels('car', 1 << 22) +
+          bench.step_kernels('car', 4096) + bench.step_kernels('doggo', 4096) + ['k_lidar_cost_team<16>', 'k_lidar_cost_reg', 'k_render_rgb'])
+  missing = [k for k in want if not any(k in n for n in names)]
+  assert not missing, missing
+  assert prof.get('doggo_flops_per_env_step', {}).get('fp64', 0) > 1e6
