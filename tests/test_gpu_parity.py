@@ -377,7 +377,17 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
   # (the ball's contact is stiff and underdamped - k h^2 = 1.4 - and amplifies rounding more)
   # (the car has 8 geoms and a 2x longer step: proportionally more contact onsets per env-step)
   # (car mix: one dribble_ball env in sustained stiff contact accounts for ~85 of its env-steps on its own)
-  budget = (0.005 if task == 'dribble_ball' else ((0.004 if robot == 'car' else 0.003) if task == MIXED else (0.0015 if robot == 'car' else 0.0005))) * n * T
+  # Budgets sit at ~2-3x the measured counts (profiles/r03_lockstep_counts.txt: Point tasks <= 3 of 30 720 env-steps, Car tasks <= 9,
+  # car/haul_box 29 against the fp32 build, the Point mix 54 of 245 760), except the two stiff cases that are near theirs
+  # (dribble_ball 105 of 30 720 against the fp32 build; the Car mix 3.4e-3, its dribble_ball envs).
+  if task == 'dribble_ball': frac = 0.005
+  elif task == MIXED: frac = 0.004 if robot == 'car' else 0.0005
+  elif robot == 'car': frac = 0.0015 if task == 'haul_box' else 0.0005
+  else: frac = 0.0002
+  budget = frac * n * T
+  _log_lockstep(f'{robot}/{task}: {n} envs x {T} steps resynchronised every step | env-steps outside the stated tolerance vs fp64 oracle {viol64} '
+                f'({viol64 / (n * T):.2e}), vs fp32 oracle {viol32} ({viol32 / (n * T):.2e}), budget {budget / (n * T):.1e} | cost flags within 1e-5 of a '
+                f'threshold {n_near} | accelerometer off on identical state {acc_bad}, end to end {acc_e2e} | goal-met events {n_met}, cost events {n_cost}')
   assert viol64 <= budget, f'{viol64} env-steps outside the fp64 tolerance'
   assert viol32 <= budget, f'{viol32} env-steps outside the fp32 tolerance'
   assert acc_bad <= 0.0005 * n * T, f'{acc_bad} accelerometer readings off on identical state'
@@ -388,6 +398,20 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
 # ----------------------------------------------------------------------------------
 # free-running comparison: no resynchronisation, the drift is observed and bounded
 # ----------------------------------------------------------------------------------
+LOCKSTEP_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r03_lockstep_counts.txt')
+
+
+def _log_lockstep(line):
+  """What the lockstep budgets are budgets OF: the measured counts, one line per case (copied to profiles/ at round end)."""
+  print(line)
+  try:
+    os.makedirs(os.path.dirname(LOCKSTEP_LOG), exist_ok=True)
+    with open(LOCKSTEP_LOG, 'a') as f:
+      f.write(line + '\n')
+  except OSError:
+    pass
+
+
 DRIFT_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r03_free_running_drift.txt')
 
 
@@ -835,8 +859,10 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task):
     np.testing.assert_allclose(d_obs[ok, 60:68], o_obs[ok, 60:68], rtol=2e-2, atol=2e-3, err_msg=f'touch step {t}')
     np.testing.assert_allclose(d_rew[ok], o_rew[ok], rtol=0, atol=2e-4, err_msg=f'reward step {t}')
     touched += int((d_obs[:, 60:68] > 0).any(1).sum())
+  _log_lockstep(f'doggo/{task}: {n} envs x {T} steps resynchronised every step | env-steps outside the stated tolerance vs fp64 oracle {viol} '
+                f'({viol / n_rows:.2e}), budget 5.0e-03 | env-steps with floor touch {touched}')
   assert touched > 0.8 * n * (T - 3), 'the robots should stand on the floor'
-  assert viol <= 0.02 * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'
+  assert viol <= 0.005 * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'   # measured: <= 1 of 1920 (profiles/r03_lockstep_counts.txt)
   ctx.close()
 
 
