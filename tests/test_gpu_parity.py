@@ -996,21 +996,24 @@ def test_render_env_api(nat):
   env.close()
 
 
-def test_two_device_shards_equal_one_context(nat):
-  """make(..., devices=[0, 1]): the batch is split into contiguous shards, one context / stream / host thread per
-  GPU, no collective.  Shard-concatenated results must equal a single-context run bit for bit (same global env ids
-  -> same layouts and the same counter-based noise).  Needs two visible GPUs."""
-  if nat.device_count() < 2:
-    pytest.skip('needs 2 GPUs (the 8-GPU node of the driver runs it)')
+def _shards_equal_one_context(devices, robot='point', task='go_to_goal', n=300, steps=12):
   import safe_adaptation_gym_amd as sag
-  n = 300   # odd split: 150 + 150 envs, not multiples of the wavefront
-  one = sag.make('point', 'go_to_goal', seed=11, n_envs=n, devices=[0])
-  two = sag.make('point', 'go_to_goal', seed=11, n_envs=n, devices=[0, 1])
+  nu = gu.ROBOT_NU[robot]
+  if task == 'multitask':   # heterogeneous batch: one Task object per env, in the benchmark's TaskSampler order
+    from safe_adaptation_gym_amd import benchmark
+    names = [nm for nm, _ in benchmark.make('multitask', batch_size=n, seed=666).train_tasks]
+    mk = lambda dev: sag.make(robot, None, seed=11, n_envs=n, devices=dev)
+    one, two = mk([0]), mk(devices)
+    for e in (one, two):
+      e.set_task([benchmark.TASKS[nm]() for nm in names])
+  else:
+    one = sag.make(robot, task, seed=11, n_envs=n, devices=[0])
+    two = sag.make(robot, task, seed=11, n_envs=n, devices=devices)
   o1, o2 = one.reset(), two.reset()
   np.testing.assert_array_equal(o1, o2)
   rng = np.random.RandomState(0)
-  for _ in range(12):
-    a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+  for _ in range(steps):
+    a = rng.uniform(-1, 1, (n, nu)).astype(np.float32)
     r1, r2 = one.step(a), two.step(a)
     np.testing.assert_array_equal(r1[0], r2[0])
     np.testing.assert_array_equal(r1[1], r2[1])
@@ -1020,6 +1023,25 @@ def test_two_device_shards_equal_one_context(nat):
   np.testing.assert_array_equal(s1[0], s2[0])
   np.testing.assert_array_equal(s1[1], s2[1])
   one.close(); two.close()
+
+
+def test_two_device_shards_equal_one_context(nat):
+  """make(..., devices=[0, 1]): the batch is split into contiguous shards, one context / stream / host thread per
+  GPU, no collective.  Shard-concatenated results must equal a single-context run bit for bit (same global env ids
+  -> same layouts and the same counter-based noise).  Needs two visible GPUs."""
+  if nat.device_count() < 2:
+    pytest.skip('needs 2 GPUs (the 8-GPU node of the driver runs it)')
+  _shards_equal_one_context([0, 1])   # odd split: 150 + 150 envs, not multiples of the wavefront
+
+
+@pytest.mark.parametrize('robot,task,n,steps', [('point', 'go_to_goal', 300, 12), ('car', 'push_box', 130, 8), ('doggo', 'multitask', 70, 4)])
+def test_shards_on_one_device_equal_one_context(nat, robot, task, n, steps):
+  """The same sharding path on the 1-GPU box: devices=[0, 0, 0] = three contexts, streams and host threads on ONE GPU
+  (what differs from the multi-GPU case is only the device ordinal).  Ragged shards (300 = 100 x 3, 130 = 44 + 43 + 43,
+  70 = 24 + 23 + 23), global env ids as RNG stream ids, the multitask order of BASELINE config 4 for the Doggo."""
+  if os.environ.get('SAG_HOSTEMU'):
+    pytest.skip('the host emulator (tests/hostemu) runs one kernel at a time: no concurrent host threads')
+  _shards_equal_one_context([0, 0, 0], robot, task, n, steps)
 
 
 def test_rgb_observation_env_api(nat):
