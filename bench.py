@@ -286,7 +286,7 @@ def main(argv=None, run_factory=None, emit=print):
   ap.add_argument('--envs', type=int, default=1 << 22, help='environments per GPU (weak scaling)')
   ap.add_argument('--task', default='go_to_goal')
   ap.add_argument('--robot', default='point', help='point (headline) | car | doggo: profile another config as the main line')
-  ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (stationary contact load)')
+  ap.add_argument('--burn-in', type=int, default=200, help='untimed steps before warmup (the contact load depends on the state age: see checks.state_age_steps)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0, help='CPU time spent on the cpu_baseline sample')
   ap.add_argument('--no-c2', action='store_true', help='skip the 4096-env (BASELINE config 2 size) line and the other single-GPU config lines')

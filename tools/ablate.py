@@ -1,4 +1,4 @@
-"""GPU: time ONE step kernel from a stationary snapshot for several library variants
+"""GPU: time ONE step kernel from a state snapshot (250 burn-in steps) for several library variants
 (timing-only ablation builds, see SAG_ABLATE in sag_device.hpp).
   python tools/ablate.py snapshot          -> gpurun_out/snap.npz (burn-in with the default lib)
   SAG_LIB=... python tools/ablate.py time  -> mean kernel ms over repeats from the snapshot"""
