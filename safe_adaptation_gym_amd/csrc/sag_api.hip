@@ -498,7 +498,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
   }
   CREATE_CHK(hipMalloc(&c->S, N * DEV_FLOATS * sizeof(float)));
-  CREATE_CHK(hipMalloc(&c->I, N * DI_COUNT * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->I, icount(N) * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->d_rows, 2 * N * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->d_count, 4 * sizeof(int32_t)));
@@ -527,7 +527,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMemsetAsync(c->d_cost, 0, N, c->stream));
   CREATE_CHK(hipMemsetAsync(c->d_obs, 0, N * c->rb.obs_dim * sizeof(float), c->stream));
   CREATE_CHK(hipMemsetAsync(c->S, 0, N * DEV_FLOATS * sizeof(float), c->stream));
-  CREATE_CHK(hipMemsetAsync(c->I, 0, N * DI_COUNT * sizeof(int32_t), c->stream));
+  CREATE_CHK(hipMemsetAsync(c->I, 0, icount(N) * sizeof(int32_t), c->stream));
   CREATE_CHK(hipStreamSynchronize(c->stream));
 #undef CREATE_CHK
   *out = c;

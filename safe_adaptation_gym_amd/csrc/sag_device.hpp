@@ -30,8 +30,11 @@ constexpr int WAVE = 64;
 enum { DI_META = 0, DI_TSTATE = 1, DI_STEP = 2, DI_ENVID = 3, DI_FLAGS = 4, DI_COUNT = 5 };
 // the FLAGS word: record flags in the low byte, the episode nonce (SAG_I_EPISODE) above it
 constexpr int FLAG_EPISODE_SHIFT = 8;
+// (the int4 block starts on a 16-byte boundary for any N: the TSTATE column is padded to a multiple of four words)
+__host__ __device__ constexpr size_t ipad(size_t N) { return (N + 3) & ~(size_t)3; }
+__host__ __device__ constexpr size_t icount(size_t N) { return ipad(N) + 4 * N; }   // words of the whole block
 __host__ __device__ constexpr size_t iaddr(int w, size_t N, size_t i) {
-  return w == DI_TSTATE ? i : N + i * 4 + (w == DI_META ? 0 : (w == DI_STEP ? 1 : (w == DI_ENVID ? 2 : 3)));
+  return w == DI_TSTATE ? i : ipad(N) + i * 4 + (w == DI_META ? 0 : (w == DI_STEP ? 1 : (w == DI_ENVID ? 2 : 3)));
 }
 
 // ---- device layout of the float state ---------------------------------------------------------
@@ -1045,7 +1048,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     iw = make_int4(__float_as_int(hi.x), __float_as_int(hi.y), __float_as_int(hi.z), __float_as_int(hi.w));
     tstate = (uint32_t)__float_as_int(ht.x);
   } else {
-    iw = reinterpret_cast<const int4*>(I + N)[i];
+    iw = reinterpret_cast<const int4*>(I + ipad((size_t)N))[i];
     tstate = (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)];
   }
   const uint32_t meta = (uint32_t)iw.x;
@@ -1722,7 +1725,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     step += 1;
     // whole int4 (meta, step, envid, flags): a 4-byte store at a 16-byte stride would leave partial lines
-    reinterpret_cast<int4*>(I + N)[i] = make_int4(iw.x, step, iw.z, iw.w);
+    reinterpret_cast<int4*>(I + ipad((size_t)N))[i] = make_int4(iw.x, step, iw.z, iw.w);
   }
   tstate = (tstate & ~(TS_AWAKE_BITS << TS_AWAKE_SHIFT)) | (awake & TS_AWAKE_BITS) << TS_AWAKE_SHIFT;
   // ---- classification for the NEXT step (QUIET / BUSY split): busy unless provably nothing can
@@ -2358,7 +2361,7 @@ __global__ __launch_bounds__(256) void k_hot_refresh(const float* __restrict__ S
   float4* H = reinterpret_cast<float4*>(hot) + i * HOT_GROUPS;
   for (int g = 0; g < 5; g++) H[g] = S4[(size_t)g * N + i];
   for (int g = 0; g < 9; g++) H[5 + g] = S4[(size_t)(DG_POS + g) * N + i];
-  const int4 iw = reinterpret_cast<const int4*>(I + N)[i];
+  const int4 iw = reinterpret_cast<const int4*>(I + ipad((size_t)N))[i];
   H[14] = make_float4(__int_as_float(iw.x), __int_as_float(iw.y), __int_as_float(iw.z), __int_as_float(iw.w));
   H[15] = make_float4(__int_as_float(I[i]), 0.f, 0.f, 0.f);
   float4* Z = reinterpret_cast<float4*>(hot_haz) + i * 5;
