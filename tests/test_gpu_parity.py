@@ -1027,6 +1027,97 @@ def _shards_equal_one_context(devices, robot='point', task='go_to_goal', n=300, 
   one.close(); two.close()
 
 
+@pytest.mark.parametrize('robot', ['point', 'car'])
+def test_maximum_capacity_worlds_lockstep(nat, oracle, robot):
+  """Edge case "maximum sizes": every slot of the record in use - 9 hazards, 10 vases, 2 pillars, 6 buttons (Collect's)
+  on a larger field - declared through the tasks/* surface (a subclass overriding `obstacles` / `placement_extents`), drawn
+  by the native sampler, stepped on the device and compared with the oracle from identical state every step."""
+  from safe_adaptation_gym_amd.tasks.press_buttons import Collect
+
+  class Crowded(Collect):
+    @property
+    def obstacles(self):
+      return [nat.MAX_HAZARDS, nat.MAX_VASES, 0, nat.MAX_PILLARS]
+
+    @property
+    def placement_extents(self):
+      return [-3.0, -3.0, 3.0, 3.0]
+
+  n, T = 96, 60
+  rf, ri, st = nat.sample_layouts(robot, 4000 + np.arange(n), 0, descs=[Crowded().descriptor()])
+  assert not st.any()
+  assert (ri[:, nat.I_NH] == nat.MAX_HAZARDS).all() and (ri[:, nat.I_NV] == nat.MAX_VASES).all()
+  assert (ri[:, nat.I_NP] == nat.MAX_PILLARS).all() and (ri[:, nat.I_NB] == nat.MAX_BUTTONS).all()
+  rid, nu, od = {'point': (0, 2, 60), 'car': (1, 2, 72)}[robot]
+  ctx = nat.Context(robot, n, seed=77)
+  ctx.set_layout(rf, ri)
+  rng, mt = np.random.RandomState(1), np.random.RandomState(2)
+  obs0 = ctx.observe()
+  rf, ri = ctx.get_state()
+  np.testing.assert_allclose(obs0, oracle.observe_batch(oracle.make_batch(rf, ri), rid, od), rtol=0, atol=2e-5)
+  assert (obs0[:, :48] > 0).mean() > 0.3, 'a crowded field shows up in all three lidar groups'
+  bad_rows = n_cost = 0
+  for t in range(T):
+    rf, ri = ctx.get_state()
+    arr = oracle.make_batch(rf, ri)
+    act = bu.pursuit_actions(rf, ri, rng, robot=robot)
+    noise = mt.normal(size=(n, nu)).astype(np.float32)
+    tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
+    d = ctx.step(act, noise, tape)
+    o = oracle.step_batch_full(arr, rid, act, noise, tape, obs_dim=od)
+    d_rf, d_ri = ctx.get_state()
+    o_rf, o_ri = oracle.batch_records(arr)
+    bad = (np.abs(d_rf - o_rf) > 1e-4 + 1e-4 * np.abs(o_rf)).any(1)
+    bad_rows += int(bad.sum())
+    ok = ~bad
+    np.testing.assert_array_equal(d[3], o[3])                      # done
+    np.testing.assert_array_equal(d[4][ok], o[4][ok])              # goal met (a button collected)
+    np.testing.assert_array_equal(d_ri[ok], o_ri[ok])              # task state incl. the collected-button mask
+    near = o[6] <= 1e-5                                            # cost decision within 1e-5 of a threshold
+    np.testing.assert_array_equal(d[2][ok & ~near], o[2][ok & ~near])
+    np.testing.assert_allclose(d[1][ok], o[1][ok], rtol=0, atol=2e-4)
+    n_cost += int(d[2].sum())
+  assert n_cost > 50, 'nine hazards should be driven through'
+  assert bad_rows <= 0.002 * n * T, f'{bad_rows} env-steps outside the stated tolerance'
+  ctx.close()
+
+
+@pytest.mark.parametrize('robot', ['point', 'car', 'doggo'])
+def test_empty_world_lockstep(nat, oracle, robot):
+  """Edge case "empty input": a GoToGoal world with no obstacle at all (obstacles = [0, 0, 0, 0] through the tasks/* surface).
+  The obstacle and object lidar groups stay zero, no cost is ever raised, and the step still matches the oracle."""
+  from safe_adaptation_gym_amd.tasks.go_to_goal import GoToGoal
+
+  class Empty(GoToGoal):
+    @property
+    def obstacles(self):
+      return [0, 0, 0, 0]
+
+  n, T = 64, 25
+  rf, ri, st = nat.sample_layouts(robot, 9000 + np.arange(n), 0, descs=[Empty().descriptor()])
+  assert not st.any() and not ri[:, [nat.I_NH, nat.I_NV, nat.I_NP, nat.I_NB]].any()
+  rid, nu, od = {'point': (0, 2, 60), 'car': (1, 2, 72), 'doggo': (2, 12, 104)}[robot]
+  ctx = nat.Context(robot, n, seed=78)
+  ctx.set_layout(rf, ri)
+  rng, mt = np.random.RandomState(1), np.random.RandomState(2)
+  tol = 2e-3 if robot == 'doggo' else 1e-4
+  for t in range(T):
+    rf, ri = ctx.get_state()
+    arr = oracle.make_batch(rf, ri)
+    act = mt.uniform(-1, 1, size=(n, nu)).astype(np.float32) if robot == 'doggo' else bu.pursuit_actions(rf, ri, rng, robot=robot)
+    noise = mt.normal(size=(n, nu)).astype(np.float32)
+    tape = mt.randint(0, 2**32, size=(n, 64), dtype=np.uint32)
+    d = ctx.step(act, noise, tape)
+    o = oracle.step_batch_full(arr, rid, act, noise, tape, obs_dim=od)
+    assert not d[0][:, :32].any(), 'obstacle and object lidar groups of an empty world'
+    assert (d[0][:, 32:48] > 0).any(1).all(), 'the goal is always in lidar range'
+    assert not d[2].any() and not o[2].any()
+    np.testing.assert_array_equal(d[4], o[4])
+    np.testing.assert_allclose(d[1], o[1], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(ctx.get_state()[0], oracle.batch_records(arr)[0], rtol=tol, atol=tol)
+  ctx.close()
+
+
 def test_two_device_shards_equal_one_context(nat):
   """make(..., devices=[0, 1]): the batch is split into contiguous shards, one context / stream / host thread per
   GPU, no collective.  Shard-concatenated results must equal a single-context run bit for bit (same global env ids
