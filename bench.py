@@ -397,8 +397,8 @@ def main(argv=None, run_factory=None, emit=print):
                  'busy_env_fraction_first_timed_step': getattr(run, 'busy_first', None),
                  'busy_env_fraction_last_step': getattr(run, 'busy_frac', None),
                  'state_age_steps': [args.burn_in + args.warmup, args.burn_in + args.warmup + args.steps],
-                 'spread_note': ('the same library measures this step between 0.81 and 0.99 ms on MI355X boxes of one pool, +-4 % from process to '
-                                 'process on one box (DESIGN.md 9, tools/alloc_spread.py): compare builds interleaved in one call (tools/ab.sh run -r N)')
+                 'spread_note': ('the same library measures this step between 0.81 and 0.99 ms on MI355X boxes of one pool: the value comes with the allocation and is '
+                                 'constant within a context (DESIGN.md 9, tools/alloc_spread.py, tools/clock_probe.py); compare builds interleaved in one call (tools/ab.sh run -r N)')
                                 if args.robot == 'point' and args.envs == 1 << 22 else None},
   }
   run.close()
