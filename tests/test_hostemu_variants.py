@@ -59,3 +59,20 @@ def test_wide_pgs_path_matches_the_32_lane_path(libs, tmp_path):
   # (the two paths sum the same products in another order: rounding only; a threshold event may flip a contact)
   assert bad.mean() <= 0.02, f'{bad.sum()} of {bad.size} env-steps differ beyond the lockstep tolerance'
   np.testing.assert_array_equal(a['ints'][~bad], b['ints'][~bad])
+
+
+def test_front_end_api_on_the_emulated_device(libs):
+  """The NumPy front end (make / reset / step / set_task / seed / get_state, envs.py and _native.py) and the C ABI's error
+  and edge behaviour, exercised WITHOUT a GPU: the API cases of the `-m gpu` suite run in a subprocess against the host build
+  of the device sources.  (A checker, not a fallback: the product loader opens libsag.so only and reports no device here;
+  the host build is selected by the test through SAG_LIB + SAG_HOSTEMU.)"""
+  env = dict(os.environ, SAG_LIB=libs['base'], SAG_HOSTEMU='1', PYTHONPATH=ROOT + os.pathsep + os.path.join(ROOT, 'tests'))
+  pick = ('test_env_api_shapes or test_car_env_api or state_roundtrip or physics_error_is_data or parity_rng_mode or '
+          'maximum_capacity or lidar_cost_empty or lidar_cost_kernel_golden')
+  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-m', 'gpu', '-q', '-x',
+                      '-p', 'no:cacheprovider', '-k', pick], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+  tail = r.stdout[-1500:] + r.stderr[-1500:]
+  assert r.returncode == 0, tail
+  import re
+  m = re.search(r'(\d+) passed', r.stdout)
+  assert m and int(m.group(1)) >= 8 and 'skipped' not in r.stdout.splitlines()[-1], tail
