@@ -330,7 +330,12 @@ static int circle_circle(real ax, real ay, real ra, real bx, real by, real rb, C
   return 1;
 }
 
-/* circle A vs oriented box B (centre bx,by; cos/sin cb,sb; half hx,hy) */
+/* circle A vs oriented box B (centre bx,by; cos/sin cb,sb; half hx,hy).
+ * g_box_tie (0 except inside the Doggo's dg_collide_body): a circle centre INSIDE the box takes the x face also when the
+ * y face is nearer by less than this.  The Doggo's capsules need it: the deepest point of an axis that crosses a box is
+ * where the two face distances are EQUAL (a kink of the signed distance, dg_seg_box_t), so the plain `<` would be decided
+ * by rounding there - structurally, not by coincidence. */
+static _Thread_local real g_box_tie = 0;
 static int circle_box(real ax, real ay, real ra, real bx, real by, real cb, real sb, real hx,
                       real hy, Contact* out) {
   real wx = ax - bx, wy = ay - by;
@@ -340,8 +345,9 @@ static int circle_box(real ax, real ay, real ra, real bx, real by, real cb, real
   real onx, ony, depth; /* outward normal of the box in its frame */
   if (ddx == 0 && ddy == 0) { /* centre inside the box */
     real px = hx - R_FABS(lx), py = hy - R_FABS(ly);
-    if (px < py) { onx = lx >= 0 ? 1 : -1; ony = 0; depth = ra + px; qx = onx * hx; }
-    else { onx = 0; ony = ly >= 0 ? 1 : -1; depth = ra + py; qy = ony * hy; }
+    /* (likewise the + face when the centre is within g_box_tie of the mid-plane: the other kink of the signed distance) */
+    if (px < py || (g_box_tie > 0 && px <= py + g_box_tie)) { onx = lx >= -g_box_tie ? 1 : -1; ony = 0; depth = ra + px; qx = onx * hx; }
+    else { onx = 0; ony = ly >= -g_box_tie ? 1 : -1; depth = ra + py; qy = ony * hy; }
   } else {
     real d2 = ddx * ddx + ddy * ddy;
     if (d2 >= ra * ra) return 0;
@@ -1278,8 +1284,9 @@ void sago_doggo_substeps(OEnv* e, const double* ctrl12, int nstep, double h) {
   substeps_r(e, c, nstep, h, SAG_ROBOT_DOGGO);
   g_dgws = NULL;
 }
-/* doggo diagnostics for the analytic tests: total energy; mass matrix [19x19], bias [19], sphere
- * centres [17x3], total mass, contact-free qacc [19] at zero control */
+/* doggo diagnostics for the analytic tests: total energy; mass matrix [19x19], bias [19], collision geometry
+ * (the 16 floor points' lowest points [16x3], then the 14 geoms' axis end points [14x6]), total mass,
+ * contact-free qacc [19] at zero control */
 double sago_doggo_energy(const OEnv* e) {
   Doggo D;
   dg_load(&D, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT);
@@ -1292,13 +1299,34 @@ void sago_doggo_debug(const OEnv* e, double* M, double* bias, double* sph, doubl
   dg_mass_matrix(&D);
   for (int i = 0; i < DG_NV; i++) for (int j = 0; j < DG_NV; j++) M[i * DG_NV + j] = D.L[i][j];
   dg_bias(&D, bias);
-  for (int s = 0; s < DG_NS; s++) for (int k = 0; k < 3; k++) sph[3 * s + k] = D.sph[s][k];
+  for (int s = 0; s < DG_NFP; s++) for (int k = 0; k < 3; k++) sph[3 * s + k] = D.fpt[s][k];
+  for (int g = 0; g < DG_NCG; g++)
+    for (int k = 0; k < 3; k++) { sph[3 * DG_NFP + 6 * g + k] = D.ga[g][k]; sph[3 * DG_NFP + 6 * g + 3 + k] = D.gb[g][k]; }
   *mass = 0;
   for (int b = 0; b < DG_NB; b++) *mass += D.Ib[b].m;
   double tau[DG_NV];
   for (int i = 0; i < DG_NV; i++) tau[i] = -bias[i];
   for (int j = 0; j < DG_NJ; j++) tau[6 + j] += -DG_STIFF * (D.q[j] - DG_SPRINGREF_DEG[j] * PI / 180);
   if (dg_cholesky(D.L)) dg_solve(D.L, tau, qacc0);
+}
+
+/* the contacts (normal rows) of ONE forward evaluation of a Doggo env at zero control: out[k] = key, point xyz,
+ * normal xyz (into the robot), depth, solved normal force; returns their number, *cost_contacts = the count the
+ * cost rule sees (robot geoms x vases / pillars).  Keys: sag_oracle_doggo.inc (floor 0x1000 + 4 point,
+ * object 0x10000 + 4 (32 (8 (8 obj + geom of the object) + contact) + robot geom)) */
+int sago_doggo_contacts(const OEnv* e, int max, double* out, int* cost_contacts) {
+  World w;
+  Doggo dg;
+  real ctrl[12] = {0};
+  world_from_env_r(e, &w, SAG_ROBOT_DOGGO);
+  w.dg = &dg;
+  dg_load(&dg, e->f + SAG_F_ROBOT, e->f + SAG_F_ROBOT_EXT);
+  Sol sol = make_sol(DT[SAG_ROBOT_DOGGO]);
+  g_dg_dump = out; g_dg_dump_max = max; g_dg_dump_n = 0;
+  const int cc = world_forward(&w, e, ctrl, &sol, NULL);
+  g_dg_dump = NULL;
+  if (cost_contacts) *cost_contacts = cc;
+  return g_dg_dump_n;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1705,6 +1733,7 @@ void sago_step(OEnv* e, int robot, const float* action, const float* noise, cons
   Sol sol = make_sol(h);
   uint32_t mask = 0;
   carws.have = 0;   /* the forward evaluation behind the observation solves the car's friction cold: the accelerometer stays a function of the state */
+  dgws.n = 0; dgws.evals = 0;   /* ... and the Doggo's rows (DG_PGS_ITERS0 sweeps from zero): accelerometer and touch columns of step() == sago_observe() of the same state */
   int cc = world_forward(&w, e, ctrl, &sol, &mask);
   g_dgws = NULL; g_carws = NULL;
   if (ext_cost_contacts >= 0) { cc = ext_cost_contacts; mask = ext_btn_mask; }

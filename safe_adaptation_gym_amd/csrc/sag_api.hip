@@ -164,14 +164,16 @@ void dg_build_model(DgModel& M) {
       {5, {-.1, 0, 0}, {-.2, .1, 0}, .032, 5, true}, {5, {-.1, 0, 0}, {-.2, -.1, 0}, .032, 5, true},
       {6, {0, 0, 0}, {.098, .0566, -.05}, .032, 5, true}, {7, {0, 0, 0}, {-.1176, -.0679, -.1}, .032, 5, true},
       {8, {0, 0, 0}, {.098, -.0566, -.05}, .032, 5, true}, {9, {0, 0, 0}, {-.1176, .0679, -.1}, .032, 5, true}};
-  struct Sp { int body; double p[3], r; int touch; };
-  static const Sp spheres[DG_NS] = {
-      {0, {0, 0, 0}, .075, -1}, {0, {.1, 0, 0}, .075, -1}, {0, {.2, 0, 0}, .075, -1},
-      {1, {0, 0, 0}, .032, -1}, {2, {0, 0, 0}, .032, 0}, {2, {-.1176, -.0679, -.1}, .032, 4},
-      {3, {0, 0, 0}, .032, -1}, {4, {0, 0, 0}, .032, 3}, {4, {-.1176, .0679, -.1}, .032, 7},
-      {5, {-.1, 0, 0}, .075, -1}, {5, {-.2, 0, 0}, .075, -1},
-      {6, {0, 0, 0}, .032, -1}, {7, {0, 0, 0}, .032, 1}, {7, {-.1176, -.0679, -.1}, .032, 5},
-      {8, {0, 0, 0}, .032, -1}, {9, {0, 0, 0}, .032, 2}, {9, {-.1176, .0679, -.1}, .032, 6}};
+  // floor contact points (oracle DG_FLOORPTS): geom, end, rim, merged, touch slot, half share
+  struct Fp { int geom, end, rim, dbl, touch, half; };
+  static const Fp floorpts[DG_NFP] = {
+      {0, 1, 1, 0, -1, 0}, {0, 0, 1, 0, -1, 0},
+      {3, 0, 0, 1, -1, 0}, {4, 0, 0, 1, 0, 1}, {4, 1, 0, 0, 4, 0},
+      {5, 0, 0, 1, -1, 0}, {6, 0, 0, 1, 3, 1}, {6, 1, 0, 0, 7, 0},
+      {7, 1, 1, 0, -1, 0}, {7, 0, 1, 0, -1, 0},
+      {10, 0, 0, 1, -1, 0}, {11, 0, 0, 1, 1, 1}, {11, 1, 0, 0, 5, 0},
+      {12, 0, 0, 1, -1, 0}, {13, 0, 0, 1, 2, 1}, {13, 1, 0, 0, 6, 0}};
+  static const int geom_touch[14] = {-1, -1, -1, -1, 0, -1, 3, -1, -1, -1, -1, 1, -1, 2};
   const double pi = 3.14159265358979323846;
   memset(&M, 0, sizeof(M));
   for (int b = 0; b < DG_NB; b++) {
@@ -214,13 +216,14 @@ void dg_build_model(DgModel& M) {
     for (int a = 0; a < 3; a++)
       for (int c = 0; c < 3; c++) M.I[b][3 * a + c] += gI[g][3 * a + c] + gm[g] * ((a == c ? d2 : 0.0) - d[a] * d[c]);
   }
-  for (int s = 0; s < DG_NS; s++) {
-    M.sph_body[s] = spheres[s].body; M.sph_touch[s] = spheres[s].touch; M.sph_r[s] = spheres[s].r;
-    for (int k = 0; k < 3; k++) M.sph_p[s][k] = spheres[s].p[k];
+  for (int s = 0; s < DG_NFP; s++) {
+    const Fp& f = floorpts[s];
+    M.fp_code[s] = f.geom | f.end << 4 | f.rim << 5 | f.dbl << 6 | (f.touch + 1) << 7 | f.half << 11;
   }
   static_assert(DG_NGEOM == 14, "geom table");
   for (int g = 0; g < DG_NGEOM; g++) {
     M.geom_body[g] = geoms[g].body; M.geom_capsule[g] = geoms[g].capsule ? 1 : 0; M.geom_r[g] = geoms[g].r;
+    M.geom_touch[g] = geom_touch[g];
     // ankle geoms = the shin capsules on bodies 2, 4 (front legs: blue) and 7, 9 (rear legs: green)
     M.geom_ankle[g] = (geoms[g].body == 2 || geoms[g].body == 4) ? 1 : ((geoms[g].body == 7 || geoms[g].body == 9) ? 2 : 0);
     for (int k = 0; k < 3; k++) { M.geom_a[g][k] = geoms[g].a[k]; M.geom_b[g][k] = geoms[g].b[k]; }

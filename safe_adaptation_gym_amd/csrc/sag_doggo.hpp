@@ -5,7 +5,8 @@
 // free base + waist hinge + 4 x (hip_z, hip_y, ankle); composite-rigid-body mass matrix and
 // recursive Newton-Euler bias in world axes about the base origin; dense Cholesky; joint limits,
 // floor and object contacts as MuJoCo-style soft constraints solved by warm-started projected Gauss-Seidel;
-// 17 collision spheres; horizontal contacts against the extruded planar world.
+// the XML's 14 collision geoms (2 torso cylinders, 12 capsules: round 4; 17 spheres before); horizontal contacts
+// against the extruded planar world.
 //
 // Arithmetic: fp64 for the articulated solve.  The mass matrix spans base mass 4e-2 kg to ankle inertia 1e-5 kg m^2
 // and the contact rows need M^-1 J^T: in fp32 the Cholesky solve loses 4-5 of its 7 digits.  State in HBM
@@ -15,7 +16,10 @@
 
 namespace sag {
 
-constexpr int DG_NB = 10, DG_NV = 19, DG_NJ = 13, DG_NS = 17, DG_MAXROWS = 3 * 12 + DG_NJ + 1, DG_NGEOM = 14;
+constexpr int DG_NB = 10, DG_NV = 19, DG_NJ = 13, DG_NFP = 16, DG_MAXROWS = 3 * 12 + DG_NJ + 1, DG_NGEOM = 14;
+constexpr int DG_PAIR_CAP = 5;              // contacts per (robot geom, world object): oracle DG_PAIR_CAP
+constexpr double DG_SITE_R = 0.036;         // touch sites (doggo.xml:8)
+constexpr float DG_FACE_TIE = 1e-6f;        // oracle DG_FACE_TIE
 // projected Gauss-Seidel sweeps of a forward evaluation that starts from the previous one's forces / of the first
 // (cold) one of an env-step: oracle DG_PGS_ITERS, DG_PGS_ITERS0
 constexpr int DG_PGS_ITERS = 24, DG_PGS_ITERS0 = 48;
@@ -30,15 +34,19 @@ struct DgPhys {                    // what the dynamics read (the cooperative ke
   double lo[DG_NJ], hi[DG_NJ], springref[DG_NJ];
   int act_joint[12];
   double m[DG_NB], com[DG_NB][3], I[DG_NB][9];  // inertia about the com, body axes
-  int sph_body[DG_NS], sph_touch[DG_NS];
-  double sph_p[DG_NS][3], sph_r[DG_NS];
+  // the XML's geoms = the collision geometry (and what the renderer draws): body, axis end points in the body frame,
+  // radius, capsule (1) / cylinder (0), touch slot of the site at the geom's START (ankle_ka; the one at its end is + 4) or -1
+  int geom_body[DG_NGEOM], geom_capsule[DG_NGEOM], geom_touch[DG_NGEOM];
+  double geom_a[DG_NGEOM][3], geom_b[DG_NGEOM][3], geom_r[DG_NGEOM];
+  // the 16 floor contact points (oracle DG_FLOORPTS, same order), each an end of a geom's axis:
+  //   geom | end << 4 | rim << 5 (cylinder: lowest rim point) | merged << 6 (two coincident end spheres: one row, half
+  //   the regulariser) | (touch slot + 1) << 7 | half << 11 (the sensor reads half of the merged knee row)
+  int fp_code[DG_NFP];
   unsigned anc[DG_NB];            // bit a set: body a is on the path root -> b (inclusive)
 };
 struct DgModel : DgPhys {
-  // the XML's geoms (rendering): body, end points in the body frame, radius, capsule (1) / cylinder (0),
-  // ankle colour class (0 default red, 1 front ankles blue, 2 rear ankles green: doggo.xml:26,40,58,72)
-  int geom_body[DG_NGEOM], geom_capsule[DG_NGEOM], geom_ankle[DG_NGEOM];
-  double geom_a[DG_NGEOM][3], geom_b[DG_NGEOM][3], geom_r[DG_NGEOM];
+  // rendering: ankle colour class (0 default red, 1 front ankles blue, 2 rear ankles green: doggo.xml:26,40,58,72)
+  int geom_ankle[DG_NGEOM];
 };
 static __constant__ DgModel g_dg;   // uploaded by sag_create
 
@@ -208,8 +216,10 @@ __device__ inline int dg_circle_geom(float ax, float ay, float ra, const Geom& g
   float onx, ony, depth;
   if (ddx == 0 && ddy == 0) {
     const float px = g.a - fabsf(lx), py = g.b - fabsf(ly);
-    if (px < py) { onx = lx >= 0 ? 1.f : -1.f; ony = 0; depth = ra + px; qx = onx * g.a; }
-    else { onx = 0; ony = ly >= 0 ? 1.f : -1.f; depth = ra + py; qy = ony * g.b; }
+    // (the x face also when the y face is nearer by less than DG_FACE_TIE: the deepest point of a capsule's axis inside a
+    //  box is where the two are EQUAL - dg_seg_box_t's diagonal kinks -, and rounding must not pick the face there)
+    if (px <= py + DG_FACE_TIE) { onx = lx >= -DG_FACE_TIE ? 1.f : -1.f; ony = 0; depth = ra + px; qx = onx * g.a; }
+    else { onx = 0; ony = ly >= -DG_FACE_TIE ? 1.f : -1.f; depth = ra + py; qy = ony * g.b; }
   } else {
     const float d2 = ddx * ddx + ddy * ddy;
     if (d2 >= ra * ra) return 0;
@@ -222,7 +232,81 @@ __device__ inline int dg_circle_geom(float ax, float ay, float ra, const Geom& g
   return 1;
 }
 
-
-
+// ---- capsules and cylinders against the extruded planar world (oracle: dg_box_sd, dg_seg_box_t, dg_collide_body) ----
+// signed distance of the point (x, y) in a box's frame to the box |x| <= hx, |y| <= hy (negative inside)
+__device__ inline float dg_box_sd(float x, float y, float hx, float hy) {
+  const float qx = fabsf(x) - hx, qy = fabsf(y) - hy;
+  const float ox = qx > 0 ? qx : 0.f, oy = qy > 0 ? qy : 0.f;
+  float in = qx > qy ? qx : qy;
+  if (in > 0) in = 0.f;
+  return sqrtf(ox * ox + oy * oy) + in;
+}
+// The parameter t in [t0, t1] of the segment a + t d (box frame) with the smallest signed distance to the box: the
+// distance to a convex set is convex along a line, so the minimiser is an end of the range, the foot of a corner on the
+// line, or a kink (the box's axes and the diagonals |x| - hx = |y| - hy inside it).  Twelve candidates in the oracle's
+// order, the first of the smallest wins.
+__device__ inline float dg_seg_box_t(float ax, float ay, float dx, float dy, float hx, float hy, float t0, float t1) {
+  const float dd = dx * dx + dy * dy, e = hx - hy;
+  float best_t = t0, best = dg_box_sd(ax + t0 * dx, ay + t0 * dy, hx, hy);
+  auto tryt = [&](float t) {
+    if (!(t > t0)) t = t0;
+    if (t > t1) t = t1;
+    const float sd = dg_box_sd(ax + t * dx, ay + t * dy, hx, hy);
+    if (sd < best) { best = sd; best_t = t; }
+  };
+  tryt(t1);
+  if (dd > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float cx = (k == 0 || k == 3) ? hx : -hx, cy = k < 2 ? hy : -hy;
+      tryt(((cx - ax) * dx + (cy - ay) * dy) / dd);
+    }
+    if (dx != 0) tryt(-ax / dx);
+    if (dy != 0) tryt(-ay / dy);
+    if (dx - dy != 0) { tryt((e - (ax - ay)) / (dx - dy)); tryt((-e - (ax - ay)) / (dx - dy)); }
+    if (dx + dy != 0) { tryt((e - (ax + ay)) / (dx + dy)); tryt((-e - (ax + ay)) / (dx + dy)); }
+  }
+  return best_t;
+}
+// vertices of box P strictly inside box Q -> hits with the outward normal of Q's least-penetrated face times `sign`
+// (oracle verts_in_box; vertex order (+,+), (-,+), (-,-), (+,-)); appends to out[n..cap)
+__device__ inline void dg_verts_in_box(float pxc, float pyc, float cp, float sp, float phx, float phy, float qxc, float qyc,
+                                       float cq, float sq, float qhx, float qhy, float sign, DgHit* out, int& n, int cap) {
+#pragma unroll 1
+  for (int k = 0; k < 4; k++) {
+    const float sx = (k == 0 || k == 3) ? phx : -phx, sy = (k < 2) ? phy : -phy;
+    const float vx = pxc + cp * sx - sp * sy, vy = pyc + sp * sx + cp * sy;
+    const float wx = vx - qxc, wy = vy - qyc;
+    const float lx = cq * wx + sq * wy, ly = -sq * wx + cq * wy;
+    const float dx = qhx - fabsf(lx), dy = qhy - fabsf(ly);
+    if (dx <= 0 || dy <= 0) continue;
+    float onx, ony, depth;
+    if (dx < dy) { onx = lx >= 0 ? 1.f : -1.f; ony = 0; depth = dx; }
+    else { onx = 0; ony = ly >= 0 ? 1.f : -1.f; depth = dy; }
+    if (n < cap) {
+      out[n].nx = sign * (cq * onx - sq * ony); out[n].ny = sign * (sq * onx + cq * ony);
+      out[n].px = vx; out[n].py = vy; out[n].depth = depth;
+    }
+    n++;
+  }
+}
+// oriented rectangle (A: centre, cos / sin, half extents) vs one footprint geom (B): hits with the normal from A to B, in
+// the oracle's geom_pair order; returns how many the pair has (only the first cap - n0 are stored)
+__device__ inline int dg_rect_geom(float ax, float ay, float ca, float sa, float ahx, float ahy, const Geom& g, float bx, float by,
+                                   float cb, float sb, DgHit* out, int n0, int cap) {
+  int n = n0;
+  if (!g.box) {   // circle_box(circle = B, box = A), normal flipped
+    Geom r; r.box = 1; r.ox = 0; r.oy = 0; r.a = ahx; r.b = ahy; r.r = 0;
+    DgHit h;
+    if (dg_circle_geom(bx, by, g.a, r, ax, ay, ca, sa, h)) {
+      if (n < cap) { h.nx = -h.nx; h.ny = -h.ny; out[n] = h; }
+      n++;
+    }
+    return n - n0;
+  }
+  dg_verts_in_box(ax, ay, ca, sa, ahx, ahy, bx, by, cb, sb, g.a, g.b, -1.f, out, n, cap);
+  dg_verts_in_box(bx, by, cb, sb, g.a, g.b, ax, ay, ca, sa, ahx, ahy, 1.f, out, n, cap);
+  return n - n0;
+}
 
 }  // namespace sag

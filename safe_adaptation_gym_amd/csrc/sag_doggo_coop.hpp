@@ -4,7 +4,7 @@
 // Specification: oracle/sag_oracle_doggo.inc / DESIGN.md §4 "Doggo" (same row order, same warm-started PGS).  A
 // lane-per-env kernel would walk every dependent chain (Cholesky, 40+ triangular solves, row construction) through
 // private memory at ~100 clocks per step (round 1: 17 ms per step for 4096 envs).  Here lane i owns dof i (row i of
-// the mass matrix, component i of every generalised vector), lane b body b, lane s collision sphere s:
+// the mass matrix, component i of every generalised vector), lane b body b, lane s floor point s, lane g collision geom g:
 //   kinematics / inertias / RNEA   each lane walks its own root-to-body chain (<= 3 joints)
 //   mass matrix                    lane i computes row i from the composite inertias
 //   Cholesky                       right-looking, 19 rank-1 steps, lane i updates row i
@@ -26,7 +26,8 @@ struct DcContact {                              // a contact as its owner lane f
   double dir[3][3], c[3], depth;                // normal + two tangents, point, penetration
   float bcoef, kcoef, mu;
   uint32_t key;                                 // identity of the contact's normal row (+1, +2: its tangents): warm start
-  short s, other;                               // robot sphere, planar body (-1: static / floor)
+  short body, other;                            // robot body of the geom, planar body (-1: static / floor)
+  short touch, dbl;                             // touch slot (+ 8: the sensor reads half of the row) or -1; merged row (half the regulariser)
 };
 struct DcEnv {                                  // one env's working set in LDS
   double pos[3], quat[4], q[DG_NJ], vlin[3], wloc[3], qd[DG_NJ];
@@ -52,7 +53,6 @@ struct DcEnv {                                  // one env's working set in LDS
     struct {
       double M[DG_NV][DG_NV + 1];               // mass matrix -> Cholesky factor L (lower) -> L and L^-1 -> M^-1
       double bias[DG_NV], tau[DG_NV];
-      double sph[DG_NS][3];
     };
     float rW[DC_ROWS][DG_NV];                   // W = J M^-1 (fp32 like J): written once M^-1 sits in registers
   };
@@ -207,17 +207,6 @@ __device__ __attribute__((noinline)) void dc_kinematics(int hf, int u) {
     I[7] = Iw[4] + m * (d2 - c[1] * c[1]); I[8] = Iw[5] - m * c[1] * c[2]; I[9] = Iw[8] + m * (d2 - c[2] * c[2]);
   }
 }
-// sphere centres (needs E.R / E.p)
-__device__ __attribute__((noinline)) void dc_spheres(int hf, int u) {
-  DC_ENV;
-  if (u < DG_NS) {
-    const int b = g_dc_phys.sph_body[u];
-    double o[3];
-    dg_matvec(E.R[b], g_dc_phys.sph_p[u], o);
-    for (int k = 0; k < 3; k++) E.sph[u][k] = E.p[b][k] + o[k];
-  }
-}
-
 // f = I v for the 10-double inertia layout
 __device__ inline void dc_inertia_apply(const double* I, const double* v, double* f) {
   const double* w = v; const double* l = v + 3;
@@ -425,7 +414,6 @@ __device__ inline void dc_smooth(int hf, int u, const float* ctrl12) {
   dc_kinematics(hf, u);
   __syncthreads();
   DCC(DCY_KIN);
-  dc_spheres(hf, u);
   dc_composite(hf, u);
   dc_rnea_bodies(hf, u);
   __syncthreads();
@@ -649,10 +637,10 @@ __device__ inline void dc_jac(int hf, int r, int b, const double* c, const doubl
   }
 }
 
-// Contact j of the substep, registered by its owner lane (sphere s): directions, point and coefficients only.  Its
+// Contact j of the substep, registered by its owner lane (floor point / collision geom): directions, point and coefficients only.  Its
 // three rows - 57 Jacobian entries - are computed by all lanes together in dc_contacts_finish: one lane per contact
 // doing them while the others idle was 17 % of the kernel.
-__device__ inline void dc_contact_add(int hf, int j, int s, const double* n, const double* c, double depth, int other,
+__device__ inline void dc_contact_add(int hf, int j, int body, int touch, int dbl, const double* n, const double* c, double depth, int other,
                                       double bcoef, double kcoef, double mu, uint32_t key) {
   DC_ENV;
   DcContact& C = E.ct[j];
@@ -665,7 +653,7 @@ __device__ inline void dc_contact_add(int hf, int j, int s, const double* n, con
     for (int a = 0; a < 3; a++) C.dir[k][a] = dir[k][a];
   for (int a = 0; a < 3; a++) C.c[a] = c[a];
   C.depth = depth; C.bcoef = (float)bcoef; C.kcoef = (float)kcoef; C.mu = (float)mu;   // (float-valued: exact)
-  C.s = (short)s; C.other = (short)other; C.key = key;
+  C.body = (short)body; C.other = (short)other; C.touch = (short)touch; C.dbl = (short)dbl; C.key = key;
 }
 
 // rows [r0, r0 + 3 nct) of the nct registered contacts: Jacobians entry by entry across the lanes, then one row per lane
@@ -677,7 +665,7 @@ __device__ __attribute__((noinline)) void dc_contacts_finish(int hf, int u, int 
   for (int e = u; e < total; e += 32) {
     const int j = e / (3 * DG_NV), rem = e - j * (3 * DG_NV), k = rem / DG_NV, i = rem - k * DG_NV;
     const DcContact& C = E.ct[j];
-    const int b = g_dc_phys.sph_body[C.s];
+    const int b = C.body;
     double v = 0;
     if (g_dc_phys.anc[b] >> g_dc_phys.dof_body[i] & 1u) {
       const double rr[3] = {C.c[0] - E.pos[0], C.c[1] - E.pos[1], C.c[2] - E.pos[2]};
@@ -694,39 +682,112 @@ __device__ __attribute__((noinline)) void dc_contacts_finish(int hf, int u, int 
     const int j = q / 3, k = q - 3 * j, r = r0 + q, base = r0 + 3 * j;
     const DcContact& C = E.ct[j];
     const double vel = dc_build_row(hf, r, C.other, -C.dir[k][0], -C.dir[k][1], C.c[0], C.c[1]);
-    E.rImp[r] = (float)dg_impedance(C.depth);
+    double imp = dg_impedance(C.depth);
+    if (C.dbl) imp = 2 * imp / (1 + imp);   // two coincident contacts in one row: half the regulariser
+    E.rImp[r] = (float)imp;
     E.rKey[r] = C.key + (uint32_t)k;
-    if (k == 0) { E.rAref[r] = -(double)C.bcoef * vel + (double)C.kcoef * C.depth; E.rTouch[r] = (short)g_dc_phys.sph_touch[C.s]; }
+    if (k == 0) { E.rAref[r] = -(double)C.bcoef * vel + (double)C.kcoef * C.depth; E.rTouch[r] = C.touch; }
     else { E.rAref[r] = -(double)C.bcoef * vel; E.rParent[r] = (short)base; E.rMu[r] = C.mu; }
   }
 }
 
-// spheres of the robot (one per lane) vs one planar body: appends the contact rows in (sphere, geom)
-// order; returns the number of contacts (uniform in the half)
+// the robot's collision geoms (one per lane) vs one planar body (oracle dg_collide_body): appends the contacts in
+// (robot geom, geom of the body, contact) order; returns the number of contacts (uniform in the half)
 __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, int& nrows, int fbi, int obj, int shape, float bx, float by, float byaw,
                                       float rbound, float vsz, float rstatic, double top, double bcoef, double kcoef, double mu) {
   DC_ENV;
-  DgHit hits[5];
-  int hg[5] = {0, 0, 0, 0, 0};   // geom of each hit (row identity)
+  DgHit hits[DG_PAIR_CAP];
+  int hgk[DG_PAIR_CAP] = {0, 0, 0, 0, 0};   // 8 * geom of the body + contact of the pair (row identity)
+  float hz[DG_PAIR_CAP] = {0, 0, 0, 0, 0};  // height of each contact
   int cnt = 0;
-  double cz = 0;
-  if (u < DG_NS) {
-    const double* c = E.sph[u];
-    double r = g_dc_phys.sph_r[u];
-    cz = c[2];
-    bool go = c[2] - r < top;
-    if (go && c[2] > top) r = sqrt(r * r - (c[2] - top) * (c[2] - top));
-    const double dx = (double)bx - c[0], dy = (double)by - c[1], rs = r + (double)rbound;
-    go = go && dx * dx + dy * dy <= rs * rs;
+  double A3[3] = {0, 0, 0}, B3[3] = {0, 0, 0};
+  if (u < DG_NGEOM) {
+    const int b = g_dc_phys.geom_body[u];
+    double o[3];
+    dg_matvec(E.R[b], g_dc_phys.geom_a[u], o);
+    for (int k = 0; k < 3; k++) A3[k] = E.p[b][k] + o[k];
+    dg_matvec(E.R[b], g_dc_phys.geom_b[u], o);
+    for (int k = 0; k < 3; k++) B3[k] = E.p[b][k] + o[k];
+    const double r = g_dc_phys.geom_r[u];
+    // the part [t0, t1] of the axis at or below the object's top; all of it when all of it is above
+    const bool a_in = A3[2] <= top, b_in = B3[2] <= top;
+    bool go = a_in || b_in || fmin(A3[2], B3[2]) - r < top;
+    float t0 = 0.f, t1 = 1.f;
+    if (a_in != b_in) {
+      const float tc = (float)((top - A3[2]) / (B3[2] - A3[2]));
+      if (a_in) t1 = tc; else t0 = tc;
+    }
+    const float ax = (float)(A3[0] - (double)bx), ay = (float)(A3[1] - (double)by);
+    const float dx = (float)(B3[0] - A3[0]), dy = (float)(B3[1] - A3[1]), dz = (float)(B3[2] - A3[2]);
+    const float dd = dx * dx + dy * dy;
+    if (go) {   // cull (conservative): the body's bounding circle against the axis
+      float t = dd > 0 ? -(ax * dx + ay * dy) / dd : 0.f;
+      t = t < 0 ? 0.f : (t > 1 ? 1.f : t);
+      const float ex = ax + t * dx, ey = ay + t * dy, rs = (float)(1.5 * r) + rbound + 1e-4f;
+      go = !(ex * ex + ey * ey > rs * rs);
+    }
     if (go) {
       float cb = 1, sb = 0;
       if (fbi >= 0) sincosf(byaw, &sb, &cb);
       const int ng = shape_ngeom(shape);
-      for (int g = 0; g < ng && cnt < 5; g++) {
-        const Geom ge = shape_geom(shape, g, vsz, rstatic);
-        const float gx = bx + cb * ge.ox - sb * ge.oy, gy = by + sb * ge.ox + cb * ge.oy;
-        DgHit h;
-        if (dg_circle_geom((float)c[0], (float)c[1], (float)r, ge, gx, gy, cb, sb, h)) { hits[cnt] = h; hg[cnt] = g; cnt++; }
+      if (!g_dc_phys.geom_capsule[u]) {
+        // cylinder: the rectangle under [t0, t1] of its axis
+        const float len = sqrtf(dd), tm = 0.5f * (t0 + t1), zm = (float)A3[2] + tm * dz;
+        float hw = (float)r;
+        bool ok = true;
+        if (zm > (float)top) {
+          const float q = (float)(r * r) - (zm - (float)top) * (zm - (float)top);
+          ok = q > 0;
+          hw = sqrtf(fmaxf(q, 0.f));
+        }
+        if (ok) {
+          const float l3 = sqrtf(dd + dz * dz), ext = l3 > 0 ? (float)r * fabsf(dz) / l3 : (float)r;
+          const float ux = len > 0 ? dx / len : 1.f, uy = len > 0 ? dy / len : 0.f;
+          float s0 = t0 * len, s1 = t1 * len;
+          if (t0 == 0) s0 -= ext;
+          if (t1 == 1) s1 += ext;
+          const float rcx = (float)A3[0] + ux * 0.5f * (s0 + s1), rcy = (float)A3[1] + uy * 0.5f * (s0 + s1);
+          const float rc = ux, rsn = uy;   // (the oracle stores the rectangle's yaw = atan2(uy, ux) and takes cos / sin of it: the same up to rounding)
+#pragma unroll 1
+          for (int g = 0; g < ng && cnt < DG_PAIR_CAP; g++) {
+            const Geom ge = shape_geom(shape, g, vsz, rstatic);
+            const float gx = bx + cb * ge.ox - sb * ge.oy, gy = by + sb * ge.ox + cb * ge.oy;
+            const int c0 = cnt;
+            const int n = dg_rect_geom(rcx, rcy, rc, rsn, 0.5f * (s1 - s0), hw, ge, gx, gy, cb, sb, hits, cnt, DG_PAIR_CAP);
+            cnt = min(cnt + n, DG_PAIR_CAP);
+            for (int k = c0; k < cnt; k++) {
+              float tcn = len > 0 ? ((hits[k].px - (float)A3[0]) * ux + (hits[k].py - (float)A3[1]) * uy) / len : tm;
+              tcn = tcn < t0 ? t0 : (tcn > t1 ? t1 : tcn);
+              hz[k] = (float)A3[2] + tcn * dz;
+              hgk[k] = 8 * g + (k - c0);
+            }
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int g = 0; g < ng && cnt < DG_PAIR_CAP; g++) {
+          const Geom ge = shape_geom(shape, g, vsz, rstatic);
+          const float gox = cb * ge.ox - sb * ge.oy, goy = sb * ge.ox + cb * ge.oy;
+          const float wx = ax - gox, wy = ay - goy;
+          float ts;
+          if (!ge.box) {
+            ts = dd > 0 ? -(wx * dx + wy * dy) / dd : t0;
+            if (!(ts > t0)) ts = t0;
+            if (ts > t1) ts = t1;
+          } else {
+            ts = dg_seg_box_t(cb * wx + sb * wy, -sb * wx + cb * wy, cb * dx + sb * dy, -sb * dx + cb * dy, ge.a, ge.b, t0, t1);
+          }
+          const double cz = A3[2] + (double)ts * (B3[2] - A3[2]);
+          float rr = (float)r;
+          if (cz > top) {
+            const double q = r * r - (cz - top) * (cz - top);
+            if (!(q > 0)) continue;
+            rr = (float)sqrt(q);
+          }
+          const float cx = (float)(A3[0] + (double)ts * (B3[0] - A3[0])), cy = (float)(A3[1] + (double)ts * (B3[1] - A3[1]));
+          DgHit h;
+          if (dg_circle_geom(cx, cy, rr, ge, bx + gox, by + goy, cb, sb, h)) { hits[cnt] = h; hgk[cnt] = 8 * g; hz[cnt] = (float)cz; cnt++; }
+        }
       }
     }
   }
@@ -738,9 +799,16 @@ __device__ __attribute__((noinline)) int dc_collide_body(int hf, int u, int r0, 
   for (int k = 0; k < cnt; k++) {
     const int idx = excl + k;
     if (idx < fit) {
-      const double nn[3] = {-(double)hits[k].nx, -(double)hits[k].ny, 0}, pc[3] = {(double)hits[k].px, (double)hits[k].py, cz};
-      dc_contact_add(hf, (nrows - r0) / 3 + idx, u, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu,
-                     0x10000u + 4u * (uint32_t)(32 * (8 * (8 * obj + hg[k])) + u));
+      const double nn[3] = {-(double)hits[k].nx, -(double)hits[k].ny, 0}, pc[3] = {(double)hits[k].px, (double)hits[k].py, (double)hz[k]};
+      int touch = -1;
+      const int t0s = g_dc_phys.geom_touch[u];
+      if (t0s >= 0) {   // an ankle capsule: is the contact point inside the knee's / the foot's site?
+        const double da[3] = {pc[0] - A3[0], pc[1] - A3[1], pc[2] - A3[2]}, db[3] = {pc[0] - B3[0], pc[1] - B3[1], pc[2] - B3[2]};
+        if (dg_dot(da, da) <= DG_SITE_R * DG_SITE_R) touch = t0s;
+        else if (dg_dot(db, db) <= DG_SITE_R * DG_SITE_R) touch = t0s + 4;
+      }
+      dc_contact_add(hf, (nrows - r0) / 3 + idx, g_dc_phys.geom_body[u], touch, 0, nn, pc, (double)hits[k].depth, fbi, bcoef, kcoef, mu,
+                     0x10000u + 4u * (uint32_t)(32 * (8 * 8 * obj + hgk[k]) + u));
     }
   }
   nrows += 3 * fit;
@@ -978,18 +1046,39 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       }
       nrows += fit;
     }
-    // ---- floor (lane s) --------------------------------------------------------------------
+    // ---- floor (lane s: floor point s = an end of a geom's axis) ------------------------------------
     const int r0 = nrows;   // the contacts' rows start here
     {
-      double depth = 0;
-      if (u < DG_NS) depth = g_dc_phys.sph_r[u] - E.sph[u][2];
+      double depth = 0, lp[3] = {0, 0, 0};
+      int code = 0;
+      if (u < DG_NFP) {
+        code = g_dc_phys.fp_code[u];
+        const int g = code & 15, b = g_dc_phys.geom_body[g];
+        const double* R = E.R[b];
+        const double r = g_dc_phys.geom_r[g];
+        double o[3];
+        dg_matvec(R, (code >> 4 & 1) ? g_dc_phys.geom_b[g] : g_dc_phys.geom_a[g], o);
+        for (int k = 0; k < 3; k++) lp[k] = E.p[b][k] + o[k];
+        if (!(code >> 5 & 1)) lp[2] -= r;   // a capsule's end sphere: the point under its centre
+        else {
+          // lowest point of the cylinder's rim: centre + r (-z + u_z u) / |..|, u = the axis (the body's x); upright: the centre
+          const double ux = R[0], uy = R[3], uz = R[6], n2 = 1 - uz * uz;
+          if (n2 > 1e-12) {
+            const double sc = r / sqrt(n2);
+            lp[0] += sc * uz * ux; lp[1] += sc * uz * uy; lp[2] += sc * (uz * uz - 1);
+          }
+        }
+        depth = -lp[2];
+      }
       int total;
       const int excl = dc_scan32(depth > 0 ? 1 : 0, u, total);
       const int fit = min(total, (DC_ROWS - nrows) / 3);
       if (fit < total && u == 0) E.flag |= 2;
       if (depth > 0 && excl < fit) {
-        const double n[3] = {0, 0, 1}, c[3] = {E.sph[u][0], E.sph[u][1], 0.5 * (E.sph[u][2] - g_dc_phys.sph_r[u])};
-        dc_contact_add(hf, excl, u, n, c, depth, -1, (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU, 0x1000u + 4u * (uint32_t)u);
+        const double n[3] = {0, 0, 1}, c[3] = {lp[0], lp[1], 0.5 * lp[2]};
+        const int slot = (code >> 7 & 15) - 1;
+        dc_contact_add(hf, excl, g_dc_phys.geom_body[code & 15], slot < 0 ? -1 : slot + 8 * (code >> 11 & 1), code >> 6 & 1, n, c, depth, -1,
+                       (double)W.sol0.bcoef, (double)W.sol0.kcoef, (double)MU, 0x1000u + 4u * (uint32_t)u);
       }
       nrows += 3 * fit;
     }
@@ -1059,7 +1148,10 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     const bool fast = nmax <= SAG_DC_FAST_ROWS;
     const double a0 = dc_rows_finish(hf, u, nrows, fast);
     DCC(DCY_FINISH);
-    const int iters = sub == 0 ? DG_PGS_ITERS0 : DG_PGS_ITERS;   // the first forward evaluation of an env-step starts cold
+    // the first forward evaluation of an env-step starts cold, and so does the one at the final state behind the observation
+    // (accelerometer and touch are functions of the state alone: a step's columns equal sag_observe's of the same state)
+    const bool warm = sub > 0 && sub < nsub;
+    const int iters = warm ? DG_PGS_ITERS : DG_PGS_ITERS0;
     if (fast) {
       // ---- projected Gauss-Seidel on the Delassus matrix: lane r owns row r (its accumulated force f and its
       //      constraint acceleration acc = J_r qacc + planar-body term).  Updating row r changes every row's acc by
@@ -1076,7 +1168,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       const bool okA = mine && E.rA[ur] > 0, isfric = parent >= 0;
       // warm start: the force this row had in the previous forward evaluation (matched by identity), inside its bounds
       float f = 0.f;
-      if (sub > 0) {
+      if (warm) {
         const uint32_t key = E.rKey[ur];
         const int nprev = E.wsN;
         float raw = 0.f;
@@ -1090,7 +1182,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       const float fpar0 = __shfl(f, isfric ? parent : 0, 32);   // (every lane takes part in the exchange)
       float fn_contact = isfric ? fpar0 : 0.f;
       float acc = (float)a0;
-      if (sub > 0) {
+      if (warm) {
 #pragma unroll
         for (int r = 0; r < DC_PGS_LANES; r++)
           if (r < __builtin_amdgcn_readfirstlane(nmax)) acc += Ar[r] * dc_bcastf(f, r, half);   // (no `break`: the loop must unroll - Ar is a register array)
@@ -1127,8 +1219,8 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
       // an env with more than 32 rows (rare: a body deep inside the task box touches several of its geoms): the two envs
       // take turns on all 64 lanes.  Three barriers per row update made such a wavefront the kernel's tail (13 ms).
       const int n0 = __shfl(nrows, 0), n1 = DC_EPW == 2 ? __shfl(nrows, 32) : 0;
-      dc_pgs_wide(0, lane, n0, iters, sub > 0);
-      if (DC_EPW == 2) dc_pgs_wide(1, lane, n1, iters, sub > 0);
+      dc_pgs_wide(0, lane, n0, iters, warm);
+      if (DC_EPW == 2) dc_pgs_wide(1, lane, n1, iters, warm);
     }
     __syncthreads();
     DCC(DCY_PGS);
@@ -1152,7 +1244,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     if (u < 8) {
       double t = 0;
       for (int r = 0; r < nrows; r++)
-        if (E.rTouch[r] == u && E.rParent[r] < 0) t += E.rF[r];
+        if (E.rTouch[r] >= 0 && (E.rTouch[r] & 7) == u && E.rParent[r] < 0) t += E.rTouch[r] >= 8 ? 0.5 * E.rF[r] : E.rF[r];
       E.touch[u] = t;
     }
     // this evaluation's rows and forces for the next one's warm start

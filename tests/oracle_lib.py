@@ -115,12 +115,20 @@ class Oracle:
     return self.lib.sago_doggo_energy(C.byref(e))
 
   def doggo_debug(self, e):
-    M, bias, sph = np.zeros((19, 19)), np.zeros(19), np.zeros((17, 3))
+    M, bias, sph = np.zeros((19, 19)), np.zeros(19), np.zeros(16 * 3 + 14 * 6)   # floor points [16x3], geom axes [14x6]
     mass, qacc = np.zeros(1), np.zeros(19)
     dp = C.POINTER(C.c_double)
     self.lib.sago_doggo_debug(C.byref(e), M.ctypes.data_as(dp), bias.ctypes.data_as(dp),
                               sph.ctypes.data_as(dp), mass.ctypes.data_as(dp), qacc.ctypes.data_as(dp))
     return M, bias, sph, float(mass[0]), qacc
+
+  def doggo_contacts(self, e, max_contacts=64):
+    """Contacts of one forward evaluation at zero control: rows [key, px, py, pz, nx, ny, nz, depth, force] and the
+    count the cost rule sees."""
+    out = np.zeros((max_contacts, 9))
+    cc = C.c_int(0)
+    n = self.lib.sago_doggo_contacts(C.byref(e), max_contacts, out.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cc))
+    return out[:n], cc.value
 
   # -- single env ----------------------------------------------------------
   def env(self, rec_f, rec_i):

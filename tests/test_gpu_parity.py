@@ -398,7 +398,7 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
 # ----------------------------------------------------------------------------------
 # free-running comparison: no resynchronisation, the drift is observed and bounded
 # ----------------------------------------------------------------------------------
-LOCKSTEP_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r03_lockstep_counts.txt')
+LOCKSTEP_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r04_lockstep_counts.txt')
 
 
 def _log_lockstep(line):
@@ -412,7 +412,7 @@ def _log_lockstep(line):
     pass
 
 
-DRIFT_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r03_free_running_drift.txt')
+DRIFT_LOG = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'r04_free_running_drift.txt')
 
 
 @pytest.mark.parametrize('robot,task', [('point', 'go_to_goal'), ('car', 'push_box'), ('doggo', 'go_to_goal')])
@@ -865,6 +865,36 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task):
                 f'({viol / n_rows:.2e}), budget 5.0e-03 | env-steps with floor touch {touched}')
   assert touched > 0.8 * n * (T - 3), 'the robots should stand on the floor'
   assert viol <= 0.005 * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'   # measured: <= 1 of 1920 (profiles/r03_lockstep_counts.txt)
+  ctx.close()
+
+
+def test_doggo_capsule_and_cylinder_contacts_on_device(nat, oracle):
+  """VERDICT r3 item 1 on the device: the analytic contact cases of tests/test_oracle_doggo.py (a vase corner against the
+  SHAFT of ankle_1 - which no end sphere reaches -, a pillar against two shafts, a vase face against the torso
+  cylinders, the flat end cap, the merged knee rows) evaluated by k_doggo_physics on the same states: cost flags as
+  stated, accelerometer and touch columns equal to the oracle's (the forward evaluation behind an observation is solved
+  cold on both sides, so sag_observe and an nstep = 0 step agree too)."""
+  from test_oracle_doggo import contact_scenarios
+  sc = contact_scenarios()
+  rf = np.stack([v[0] for v in sc.values()]); ri = np.stack([v[1] for v in sc.values()])
+  want = np.array([v[2] for v in sc.values()], np.uint8)
+  n = len(sc)
+  ctx = nat.Context('doggo', n, seed=1)
+  ctx.set_layout(rf.astype(np.float32), ri)
+  rf32, ri32 = ctx.get_state()
+  arr = oracle.make_batch(rf32, ri32)
+  zero = np.zeros((n, 12), np.float32)
+  tape = np.zeros((n, 64), np.uint32)
+  d_obs, _, d_cost, d_done, _, _ = ctx.step(zero, zero, tape, nstep=0)
+  o_obs, _, o_cost, _, _, _, _ = oracle.step_batch_full(arr, 2, zero, zero, tape, obs_dim=104, nstep=0)
+  np.testing.assert_array_equal(d_cost, want)
+  np.testing.assert_array_equal(o_cost, want)
+  assert not d_done.any()
+  np.testing.assert_allclose(d_obs[:, 48:51], o_obs[:, 48:51], rtol=2e-3, atol=2e-3, err_msg='accelerometer')
+  np.testing.assert_allclose(d_obs[:, 60:68], o_obs[:, 60:68], rtol=2e-3, atol=1e-4, err_msg='touch')
+  lying = list(sc).index('lying on its left side on the knees of legs 1 and 2')
+  assert d_obs[lying, 60] > 0.01 and d_obs[lying, 61] > 0.01 and not d_obs[lying, 62:68].any()   # half of each merged knee row
+  np.testing.assert_allclose(ctx.observe()[:, 48:68], d_obs[:, 48:68], rtol=0, atol=1e-6)      # observe == step(nstep = 0)
   ctx.close()
 
 

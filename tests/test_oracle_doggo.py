@@ -317,3 +317,173 @@ print(repr(float(o.doggo_debug(o.env(rf, ri))[0][0, 0])))
     assert out.returncode == 0, out.stderr
     m = float(out.stdout.strip().splitlines()[-1])
     assert m > want and abs(m - 0.039679578751884034) < 1e-12, m
+
+
+# ---- collision geometry (round 4): the XML's capsules and cylinders, not spheres ----------------------------------
+def _decode(key):
+  """(kind, floor point | (object, object geom, contact, robot geom)) of a contact row key (sag_oracle_doggo.inc)."""
+  key = int(key)
+  if key < 0x10000:
+    return 'floor', (key - 0x1000) // 4
+  q = (key - 0x10000) // 4
+  return 'object', (q // 2048, q // 256 % 8, q // 32 % 8, q % 32)
+
+
+VASE0, PILLAR0 = 2 + 6, 0   # object numbering of the keys: pillars 0.., buttons 2.., vases 8.., task object 18
+ANKLE_1, HIP_1, TORSO_FRONT, TORSO_REAR = 4, 3, 0, 7   # indices into the 14 collision geoms (doggo.xml order)
+
+
+def contact_scenarios():
+  """Analytic contact cases shared by the oracle tests below and the device test (tests/test_gpu_parity.py:
+  test_doggo_capsule_and_cylinder_contacts_on_device): name -> (record, expected cost flag)."""
+  out = {}
+  knee = np.array([.298, .1566, .17]); foot = knee + [-.1176, -.0679, -.1]
+  spot = knee + 0.75 * (foot - knee)
+  d = (foot - knee)[:2] / np.linalg.norm((foot - knee)[:2])
+  nrm = np.array([d[1], -d[0]])
+  for name, gap in [('vase corner 5 mm inside the shaft of ankle_1', 0.0), ('the same vase 1 cm further out', 0.01)]:
+    rf, ri = doggo_record(names=('robot', 'vases0', 'goal'))
+    corner = spot[:2] + (0.032 - 0.005 + gap) * nrm
+    rf[ol.F_VASES:ol.F_VASES + 3] = [*(corner + 0.1 * np.sqrt(2) * nrm), np.arctan2(-nrm[1], -nrm[0]) - np.pi / 4]
+    out[name] = (rf, ri, int(gap == 0))
+  rf, ri = doggo_record(names=('robot', 'pillars0', 'goal'))
+  a = np.array([.2, .1, .22])
+  p = a + 0.8 * (knee - a)
+  dh = (knee - a)[:2] / np.linalg.norm((knee - a)[:2])
+  rf[ol.F_PILLARS:ol.F_PILLARS + 2] = p[:2] + (0.032 + 0.2 - 0.003) * np.array([-dh[1], dh[0]])
+  out['pillar 3 mm inside the shafts of hip_1 and ankle_1'] = (rf, ri, 1)
+  hw = np.sqrt(0.075**2 - 0.02**2)
+  rf, ri = doggo_record(names=('robot', 'vases0', 'goal'))
+  rf[ol.F_VASES:ol.F_VASES + 3] = [0.03, -(hw - 0.004) - 0.1, 0.0]
+  out['vase face 4 mm inside the torso cylinders at the waist'] = (rf, ri, 1)
+  rf, ri = doggo_record(names=('robot', 'vases0', 'goal'))
+  rf[ol.F_VASES:ol.F_VASES + 3] = [0.2 + hw + 0.005 + 0.1, 0.0, 0.0]
+  out['vase face 5 mm beyond where the old nose sphere ended, straight ahead'] = (rf, ri, 0)
+  rf, ri = doggo_record(z=0.1566 + 0.032 - 0.005)
+  rf[EXT + 1:EXT + 5] = [np.cos(-np.pi / 4), np.sin(-np.pi / 4), 0, 0]
+  out['lying on its left side on the knees of legs 1 and 2'] = (rf, ri, 0)
+  return out
+
+
+def test_contact_scenarios_cost_flags(oracle):
+  for name, (rf, ri, cost) in contact_scenarios().items():
+    assert oracle.step(oracle.env(rf, ri), DOGGO, np.zeros(12), noise=np.zeros(12), nstep=0).cost == cost, name
+
+
+def test_collision_geometry_is_the_xml(oracle):
+  """Axis end points of the 14 geoms at the reset pose (doggo.xml:15-72) and the 16 floor points under them."""
+  rf, ri = doggo_record(x=1.0, y=-2.0)
+  geo = oracle.doggo_debug(oracle.env(rf, ri))[2]
+  fpt, ax = geo[:48].reshape(16, 3), geo[48:].reshape(14, 6)
+  o = np.array([1.0, -2.0, 0.22])
+  knee1 = o + [.2, .1, 0] + [.098, .0566, -.05]
+  np.testing.assert_allclose(ax[TORSO_FRONT], np.r_[o, o + [.2, 0, 0]], atol=1e-12)
+  np.testing.assert_allclose(ax[TORSO_REAR], np.r_[o + [-.2, 0, 0], o], atol=1e-12)
+  np.testing.assert_allclose(ax[1], np.r_[o + [.1, 0, 0], o + [.2, .1, 0]], atol=1e-12)            # aux_1
+  np.testing.assert_allclose(ax[HIP_1], np.r_[o + [.2, .1, 0], knee1], atol=1e-12)
+  np.testing.assert_allclose(ax[ANKLE_1], np.r_[knee1, knee1 + [-.1176, -.0679, -.1]], atol=1e-12)
+  # floor points: rim of the front cylinder under x = .2 and x = 0, then hip / knee / foot of leg 1 (lowest points)
+  np.testing.assert_allclose(fpt[0], o + [.2, 0, -.075], atol=1e-12)
+  np.testing.assert_allclose(fpt[1], o + [0, 0, -.075], atol=1e-12)
+  np.testing.assert_allclose(fpt[3], knee1 - [0, 0, .032], atol=1e-12)
+  np.testing.assert_allclose(fpt[4], knee1 + [-.1176, -.0679, -.1 - .032], atol=1e-12)
+
+
+def test_cylinder_rim_is_the_floor_point_of_a_pitched_torso(oracle):
+  """A cylinder meets a plane with the lowest point of an end rim: nose down by th, that point is r cos th below the
+  end-cap centre and r sin th BEHIND it along the heading - not a sphere's r straight below."""
+  th = 0.4
+  rf, ri = doggo_record(z=0.3)
+  rf[EXT + 1:EXT + 5] = [np.cos(th / 2), 0, np.sin(th / 2), 0]      # rotation about +y: x axis dips
+  fpt = oracle.doggo_debug(oracle.env(rf, ri))[2][:48].reshape(16, 3)
+  end = np.array([.2 * np.cos(th), 0, .3 - .2 * np.sin(th)])
+  np.testing.assert_allclose(fpt[0], end + .075 * np.array([-np.sin(th), 0, -np.cos(th)]), atol=1e-12)
+
+
+def test_capsule_shaft_against_a_vase_corner_is_a_contact_and_a_cost(oracle):
+  """a vase corner 5 mm inside ankle_1's SHAFT - three quarters of the way from the knee to the
+  foot, 4.3 cm from the foot's end sphere (r 3.2 cm) and clear of every other geom (in plan view the ankle doubles back
+  exactly under hip_1, so the spot is chosen beyond the part of the hip that is below the vase's top) - is a contact
+  of that capsule and raises the cost (mujoco_bridge.py:177-191 counts any robot geom; world.py:144-155).  The
+  17-sphere model of rounds 1-3 found nothing here."""
+  rf, ri = doggo_record(names=('robot', 'vases0', 'goal'))
+  knee = np.array([.298, .1566, .17]); foot = knee + [-.1176, -.0679, -.1]
+  mid = knee + 0.75 * (foot - knee)
+  d = (foot - knee)[:2] / np.linalg.norm((foot - knee)[:2])
+  out = np.array([d[1], -d[0]])   # horizontal normal of the shaft on the +y side (away from the torso)
+  assert out[1] > 0
+  corner = mid[:2] + (0.032 - 0.005) * out
+  rf[ol.F_VASES:ol.F_VASES + 3] = [*(corner + 0.1 * np.sqrt(2) * out), np.arctan2(-out[1], -out[0]) - np.pi / 4]
+  e = oracle.env(rf, ri)
+  rows, cc = oracle.doggo_contacts(e)
+  obj = [(r, _decode(r[0])[1]) for r in rows if _decode(r[0])[0] == 'object']
+  assert len(obj) == 1 and cc == 1
+  r, (o, bg, k, g) = obj[0]
+  assert (o, bg, k, g) == (VASE0, 0, 0, ANKLE_1)
+  assert r[7] == pytest.approx(0.005, abs=1e-9)                      # depth
+  np.testing.assert_allclose(r[4:7], [-out[0], -out[1], 0], atol=1e-9)   # the vase pushes the leg away from itself
+  assert r[3] == pytest.approx(mid[2], abs=1e-9)                     # at the height of that axis point
+  assert r[8] > 0                                                    # and the solver loads it
+  assert oracle.step(oracle.env(rf, ri), DOGGO, np.zeros(12), noise=np.zeros(12), nstep=0).cost == 1
+  # the same vase 1 cm further out touches nothing
+  rf[ol.F_VASES:ol.F_VASES + 2] += 0.01 * out
+  e = oracle.env(rf, ri)
+  rows, cc = oracle.doggo_contacts(e)
+  assert cc == 0 and oracle.step(e, DOGGO, np.zeros(12), noise=np.zeros(12), nstep=0).cost == 0
+
+
+def test_capsule_shafts_against_a_pillar(oracle):
+  """Circle footprint: the contact sits at the foot of the pillar's centre on the capsule's axis.  In plan view ankle_1
+  doubles back exactly under hip_1 (doggo.xml:24,27: both run along (.866, .5)), so a pillar (1 m tall) beside the leg
+  meets both shafts, each at its own height."""
+  rf, ri = doggo_record(names=('robot', 'pillars0', 'goal'))
+  a = np.array([.2, .1, .22]); b = np.array([.298, .1566, .17]); foot = b + [-.1176, -.0679, -.1]
+  t = 0.8                                                           # 80 % down the hip: z = .18
+  p = a + t * (b - a)
+  d = (b - a)[:2] / np.linalg.norm((b - a)[:2])
+  out = np.array([-d[1], d[0]])
+  rf[ol.F_PILLARS:ol.F_PILLARS + 2] = p[:2] + (0.032 + 0.2 - 0.003) * out
+  rows, cc = oracle.doggo_contacts(oracle.env(rf, ri))
+  obj = [(r, _decode(r[0])[1]) for r in rows if _decode(r[0])[0] == 'object']
+  assert cc == len(obj) == 2 and [o[1] for o in obj] == [(PILLAR0, 0, 0, HIP_1), (PILLAR0, 0, 0, ANKLE_1)]
+  s_ankle = np.dot(p[:2] - b[:2], (foot - b)[:2]) / np.dot((foot - b)[:2], (foot - b)[:2])
+  for (r, _), z in zip(obj, [p[2], b[2] + s_ankle * (foot[2] - b[2])]):
+    assert r[7] == pytest.approx(0.003, abs=3e-6) and r[3] == pytest.approx(z, abs=1e-4)   # (the XML's .0566 / .0679 are rounded: not exactly parallel)
+    np.testing.assert_allclose(r[4:6], -out, atol=2e-4)
+
+
+def test_torso_cylinders_present_their_cross_section_at_a_vase_top(oracle):
+  """The torso axis (z .22) is 2 cm above a vase (top .2): the cylinders present half width sqrt(.075^2 - .02^2) and
+  flat ends.  A vase face 4 mm inside that width under the waist meets each cylinder's rectangle in two vertex
+  contacts; the hemispherical caps the sphere model had in front of x = .2 are gone."""
+  hw = np.sqrt(0.075**2 - 0.02**2)
+  rf, ri = doggo_record(names=('robot', 'vases0', 'goal'))
+  rf[ol.F_VASES:ol.F_VASES + 3] = [0.03, -(hw - 0.004) - 0.1, 0.0]   # (x = .03: clear of leg 3's knee and of aux_4)
+  rows, cc = oracle.doggo_contacts(oracle.env(rf, ri))
+  obj = [(r, _decode(r[0])[1]) for r in rows if _decode(r[0])[0] == 'object']
+  assert cc == 4 and sorted(g for _, (_, _, _, g) in obj) == [TORSO_FRONT, TORSO_FRONT, TORSO_REAR, TORSO_REAR]
+  for r, _ in obj:
+    assert r[7] == pytest.approx(0.004, abs=1e-7) and r[3] == pytest.approx(0.22, abs=1e-9)
+    np.testing.assert_allclose(r[4:7], [0, 1, 0], atol=1e-9)
+  # a vase face 5.2 cm in front of the flat end cap (x = .2): the torso does not reach it (the sphere the round-3 model
+  # had at the end of the axis did, by 2 cm); the legs on either side do
+  rf[ol.F_VASES:ol.F_VASES + 3] = [0.2 + 0.032 + 0.02 + 0.1, 0.0, 0.0]
+  rows, cc = oracle.doggo_contacts(oracle.env(rf, ri))
+  geoms = [_decode(r[0])[1][3] for r in rows if _decode(r[0])[0] == 'object']
+  assert cc == len(geoms) > 0 and TORSO_FRONT not in geoms
+
+
+def test_merged_knee_row_and_touch_share(oracle):
+  """Hip_k's end sphere and ankle_k's start sphere coincide at the knee: one row with half the regulariser, and the
+  touch sensor ankle_ka (a site on the ANKLE body) reads half of its force; a foot's row is read in full.  Lying on
+  its left side (base rolled by -90 degrees: body +y points down) the robot rests on the knees of legs 1 and 2."""
+  rf, ri = doggo_record(z=0.1566 + 0.032 - 0.005)
+  rf[EXT + 1:EXT + 5] = [np.cos(-np.pi / 4), np.sin(-np.pi / 4), 0, 0]
+  e = oracle.env(rf, ri)
+  rows, _ = oracle.doggo_contacts(e)
+  force = {_decode(r[0])[1]: r[8] for r in rows if _decode(r[0])[0] == 'floor'}
+  assert sorted(force) == [3, 11]            # floor points 3, 11 = knees of legs 1, 2
+  touch = np.array(oracle.observe(e, DOGGO).obs[60:68])
+  assert force[3] > 0 and force[11] > 0
+  np.testing.assert_allclose(touch, [0.5 * force[3], 0.5 * force[11], 0, 0, 0, 0, 0, 0], rtol=1e-6)
+  # standing (test_settles_standing_on_the_floor) the feet's rows are read in full: the sensors sum to m g there
