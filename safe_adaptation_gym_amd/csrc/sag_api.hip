@@ -98,6 +98,8 @@ struct sag_ctx {
   int n_cu = 256;      // compute units of the device
   uint8_t* d_rgb = nullptr; size_t rgb_bytes = 0;  // [N][H][W][3] staging of sag_render, grown on demand
   double* d_dr = nullptr;    // Doggo: per-env result block of the physics kernel (k_doggo_physics: 2 envs per wavefront)
+  int32_t* d_dg_sched = nullptr; int dg_phase = 0;   // Doggo: longest-first launch order (sag_doggo_coop.hpp); SAG_DOGGO_SCHED=0 turns it off
+  bool dg_sched_on = true;
   int epw_override = 0;  // SAG_EPW (read once at create): envs per wavefront of the single-launch form
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
@@ -278,7 +280,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   a.has_box = c->cfg.has_box; a.G = c->G;
   a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
-  a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr;
+  a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr; a.dg_sched = nullptr; a.dg_phase = -1;
   a.hot = nullptr; a.hot_haz = nullptr;
   // external contact results: for the one step with nstep == 0 that follows sag_set_ext_contacts
   const bool use_ext = c->ext_pending && !observe_only && a.nstep == 0;
@@ -392,7 +394,11 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   else {
     // Doggo: wave-cooperative physics (32 lanes per env) + the generic step without physics
     a.DR = c->d_dr;
-    hipLaunchKernelGGL(k_doggo_physics, dim3((c->N + DC_EPW - 1) / DC_EPW), dim3(32 * DC_EPW), 0, c->stream, a, c->d_dr);
+    const bool sched = c->dg_sched_on && c->d_dg_sched && !observe_only;
+    a.dg_sched = sched ? c->d_dg_sched : nullptr;
+    a.dg_phase = sched ? c->dg_phase : -1;
+    if (sched) c->dg_phase = (c->dg_phase + 1) % 6;   // (the kernel uses it mod 2 and mod 3)
+    hipLaunchKernelGGL(k_doggo_physics, dim3(sched ? dc_sched_blocks(c->N) : (c->N + DC_EPW - 1) / DC_EPW), dim3(32 * DC_EPW), 0, c->stream, a, c->d_dr);
     hipLaunchKernelGGL((k_step_doggo_post<true, true>), dim3(blocks), dim3(WAVE), 0, c->stream, a);
   }
 #undef SAG_LAUNCH
@@ -521,7 +527,12 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->d_used, N * sizeof(int32_t)));
   if (c->split && c->use_hot && cfg->robot != SAG_ROBOT_DOGGO)
     CREATE_CHK(hipMalloc(&c->d_hot, N * (HOT_FLOATS + 20) * sizeof(float)));
-  if (cfg->robot == SAG_ROBOT_DOGGO) CREATE_CHK(hipMalloc(&c->d_dr, N * DR_STRIDE * sizeof(double)));
+  if (cfg->robot == SAG_ROBOT_DOGGO) {
+    CREATE_CHK(hipMalloc(&c->d_dr, N * DR_STRIDE * sizeof(double)));
+    CREATE_CHK(hipMalloc(&c->d_dg_sched, dc_sched_ints(N) * sizeof(int32_t)));
+    CREATE_CHK(hipMemset(c->d_dg_sched, 0, dc_sched_ints(N) * sizeof(int32_t)));
+    if (const char* e = getenv("SAG_DOGGO_SCHED")) c->dg_sched_on = atoi(e) != 0;
+  }
   if (cfg->robot == SAG_ROBOT_DOGGO) {
     DgModel model;
     dg_build_model(model);
@@ -543,7 +554,7 @@ int sag_destroy(sag_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
-                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr, c->d_hot,
+                  c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr, c->d_dg_sched, c->d_hot,
                   c->d_ext_cc, c->d_ext_btn};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->pin) (void)hipHostFree(c->pin);

@@ -146,6 +146,8 @@ struct StepArgs {
   const float* hot_haz;   // [N][20]: the five hazard groups env-major (static: written by k_hot_refresh only)
   double* DR;             // Doggo, cooperative form: per-env result block of k_doggo_physics [N][DR_STRIDE]
                           // (k_step<DOGGO> with DR set skips the physics and reads it); else nullptr
+  int32_t* dg_sched;      // Doggo: longest-first launch order of k_doggo_physics (sag_doggo_coop.hpp), or nullptr
+  int32_t dg_phase;       //   step counter of that rotation; < 0: this launch neither uses nor builds the lists (observe)
 };
 // "Hot record": the 16 float4 a busy env's prologue needs (groups 0-4, the nine position groups, the int4
 // words and tstate), contiguous per env = two cache lines.  The busy kernel reads compacted, scattered

@@ -22,6 +22,9 @@ namespace sag {
 
 constexpr int DC_ROWS = DG_MAXROWS;              // max constraint rows per env
 constexpr int DC_PGS_LANES = 32;                // fast PGS path: one constraint row per lane
+#ifndef SAG_DC_FAST_ROWS
+#define SAG_DC_FAST_ROWS DC_PGS_LANES           // (test builds lower it so that the 64-lane path runs on ordinary states)
+#endif
 struct DcContact {                              // a contact as its owner lane found it; its three rows are built by all lanes
   double dir[3][3], c[3], depth;                // normal + two tangents, point, penetration
   float bcoef, kcoef, mu;
@@ -885,6 +888,94 @@ __device__ __attribute__((noinline)) void dc_pgs_wide(const int e, const int lan
   if (mine) E.rF[lane] = (double)f;
 }
 
+// The 32-lane PGS path: every row of an env on its own lane of the env's half (`part`: this half takes part in the pass;
+// npass: rows of the pass = the larger count of the halves taking part, uniform; a0: the lane's row's J qacc0).  Leaves
+// the forces in E.rF.  Not inlined: the kernel calls it once for both halves together or once per half (k_doggo_physics).
+__device__ __attribute__((noinline)) void dc_pgs_fast(const int hf, const int u, const int half, const int nrows, const int npass, const bool part,
+                                                      const double a0, const int iters, const bool warm) {
+  DC_ENV;
+  // ---- projected Gauss-Seidel on the Delassus matrix: lane r owns row r (its accumulated force f and its
+  //      constraint acceleration acc = J_r qacc + planar-body term).  Updating row r changes every row's acc by
+  //      A[.][r] df: one broadcast (v_readlane: r is uniform) and one multiply-add per lane, no barrier, no
+  //      19-term dot product.  fp32 like A (round 2 ran these sweeps in fp64: 4 of them; the specification now runs
+  //      24, and a sweep is a contraction, so rounding does not accumulate).  Same sweep order and bounds as the oracle.
+  const bool mine = part && u < nrows;
+  const int ur = mine ? u : 0;
+  float Ar[DC_PGS_LANES];         // the lane's row of A in registers (A[r][u] = A[u][r]: consecutive words across lanes)
+#pragma unroll
+  for (int r = 0; r < DC_PGS_LANES; r++) Ar[r] = mine && r < nrows ? E.A[r * DC_PGS_LANES + ur] : 0.f;
+  const float aref = (float)E.rAref[ur], reg = (float)E.rReg[ur], inv = (float)E.rInv[ur], mu = E.rMu[ur];
+  const int parent = E.rParent[ur];
+  const bool okA = mine && E.rA[ur] > 0, isfric = parent >= 0;
+  // warm start: the force this row had in the previous forward evaluation (matched by identity), inside its bounds
+  float f = 0.f;
+  if (warm) {
+    const uint32_t key = E.rKey[ur];
+    const int nprev = E.wsN;
+    float raw = 0.f;
+#pragma unroll 1
+    for (int q = 0; q < nprev; q++) raw = E.wsKey[q] == key ? E.wsF[q] : raw;   // (same address in every lane: LDS broadcast)
+    if (!okA || key == 0) raw = 0.f;
+    const float fn0 = fmaxf(raw, 0.f);                       // a normal / limit row: [0, inf)
+    const float fpar = __shfl(fn0, isfric ? parent : 0, 32);  // a friction row: +-mu x its normal row's force
+    f = isfric ? fminf(fmaxf(raw, -mu * fpar), mu * fpar) : fn0;
+  }
+  const float fpar0 = __shfl(f, isfric ? parent : 0, 32);   // (every lane takes part in the exchange)
+  float fn_contact = isfric ? fpar0 : 0.f;
+  float acc = (float)a0;
+  if (warm) {
+#pragma unroll
+    for (int r = 0; r < DC_PGS_LANES; r++)
+      if (r < __builtin_amdgcn_readfirstlane(npass)) acc += Ar[r] * dc_bcastf(f, r, half);   // (no `break`: the loop must unroll - Ar is a register array)
+  }
+  // The sweep is ONE dependent chain through all rows (row r+1 needs the acc that row r's increment changed); a
+  // wavefront alone on its SIMD pays every link's latency, so the chain is kept short: the update
+  //   f <- clamp(f + (aref - acc - reg f) inv)  =  clamp(c1 f + c0 - inv acc),  c1 = 1 - reg inv, c0 = aref inv
+  // has its own-force part t = c1 f + c0 precomputed (f changes only at the row's own turn), every lane computes a
+  // candidate increment and the row's is picked by the broadcast itself (no select in front of it); rows that take
+  // no part (A <= 0, lanes beyond the last row) carry inv = 0, c1 = 1, c0 = 0: their candidate is 0.  Chain per
+  // row: fma, max, min, sub, readlane, (half select), fma.
+  // The lane tests `u == r`, `parent == r` are made on the spot (a compare + a select): hoisted out of the sweep
+  // loop they are 64 wave masks that live in spilled SGPRs and come back through two v_readlane each per row.
+  const float ninv = okA ? -inv : 0.f, c1 = okA ? 1.f - reg * inv : 1.f, c0 = okA ? aref * inv : 0.f;
+  const float mu_eff = isfric ? mu : 0.f, hi0 = isfric ? 0.f : 3.0e38f;   // bounds: [-mu fn, mu fn] / [0, inf)
+  const int nmax_u = __builtin_amdgcn_readfirstlane(npass);              // (uniform: the row tests are scalar branches)
+#pragma unroll 1
+  for (int it = 0; it < iters; it++)
+#pragma unroll
+    for (int r = 0; r < DC_PGS_LANES; r++)   // unrolled: lane index and register index of the row are constants
+      if (r < nmax_u) {
+        int uu = u, pp = parent;
+        DC_OPAQUE(uu); DC_OPAQUE(pp);   // (keeps the two compares below inside the loop)
+        const float hi = fmaf(mu_eff, fn_contact, hi0);
+        const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
+        const float df = dc_bcastf(fc - f, r, half);
+        acc = fmaf(Ar[r], df, acc);
+        f = uu == r ? fc : f;
+        // a friction row tracks its contact's normal force by the same increments
+        fn_contact += pp == r ? df : 0.f;
+      }
+  if (mine) E.rF[u] = (double)f;
+}
+
+// Longest-first launch order.  The kernel is as long as its last wavefront, and a wavefront's time goes with its envs'
+// constraint rows (the PGS is one dependent chain through all of them): 15 rows is the median; a robot lying on the floor
+// has 25 - 35; one entangled with the HaulBox box 50, on the 64-lane path - 2.5 ms alone where an ordinary pair takes
+// 1.4.  ONE such env among 4096, started in the second round of wavefronts, made the multitask step 4.0 instead of
+// 3.0 ms.  So every env files itself, at the end of a step, under the cost class of the rows it had (atomic append to
+// one of DC_NCLS lists), and the next step's workgroups take the lists in order, costliest first (the mapping is at
+// the head of k_doggo_physics).  sched: [0 .. 12) three rotating
+// sets of DC_NCLS counters (this step's lists, the ones being built, the ones being cleared), [16 ..) two buffers of
+// DC_NCLS lists of N env ids.  The order inside a list is the order of arrival: it changes from run to run, the results
+// do not - an env's arithmetic depends on its own row count only (which PGS path it takes is decided per env).
+constexpr int DC_NCLS = 4;
+#ifndef SAG_DC_CLS2
+#define SAG_DC_CLS2 26   // rows from which an env is filed in class 2 / class 1
+#define SAG_DC_CLS1 20
+#endif
+__host__ __device__ inline size_t dc_sched_ints(size_t N) { return 16 + 2 * DC_NCLS * N; }
+__host__ __device__ inline int dc_sched_blocks(int N) { return (N + DC_EPW - 1) / DC_EPW; }
+
 // inputs of the planar world shared by the lanes of a half
 struct DcWorldK {
   int nV, nP, nB, task;
@@ -899,11 +990,40 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
   __shared__ float stx_s[DC_EPW][SAG_MAX_PILLARS + SAG_MAX_BUTTONS], sty_s[DC_EPW][SAG_MAX_PILLARS + SAG_MAX_BUTTONS];
   const int lane = threadIdx.x, half = lane >> 5, u = lane & 31;
   const size_t N = (size_t)p.N;
-  const size_t gi = (size_t)blockIdx.x * DC_EPW + half;
-  const bool live = gi < N;
+  size_t gi = (size_t)blockIdx.x * DC_EPW + half;
+  bool live = gi < N;
+  const bool sched = p.dg_sched != nullptr && p.dg_phase >= 0;
+  int32_t* const sc = p.dg_sched;
+  if (sched) {   // longest-first order (above)
+    const int32_t* cnt = sc + (p.dg_phase % 3) * DC_NCLS;
+    if (blockIdx.x == 0 && lane < DC_NCLS) sc[((p.dg_phase + 2) % 3) * DC_NCLS + lane] = 0;
+    const int n3 = cnt[3], n2 = cnt[2], n1 = cnt[1], n0 = cnt[0];
+    int b = (int)blockIdx.x;
+    if ((size_t)n3 + n2 + n1 + n0 != N) {   // no complete set of lists yet (first step): plain order
+      gi = (size_t)b * DC_EPW + half; live = gi < N;
+    } else {
+      // The envs as ONE sequence, costliest first: class 3, 2, 1, 0, each list read from its END (envs arrive in the order
+      // their wavefronts finished).  Workgroup b < n3 takes the b-th env of the sequence AND the b-th from its end - an env
+      // on the 64-lane path with one of the cheapest (the two are solved one after the other) -, the others take
+      // consecutive pairs of what lies between.  Exactly ceil(N / 2) workgroups have work: with 4096 envs the chip runs
+      // two full rounds of them, and a single workgroup more starts a third.
+      const int32_t* lists = sc + 16 + (size_t)(p.dg_phase & 1) * DC_NCLS * N;
+      const int heavy = min(n3, (int)(N / 2));
+      int q;   // this half's position in the sequence
+      if (b < heavy) q = half == 0 ? b : (int)N - 1 - b;
+      else q = heavy + (b - heavy) * DC_EPW + half;
+      live = q < (int)N - (b < heavy ? 0 : heavy) && b < (int)((N + DC_EPW - 1) / DC_EPW);
+      int cls = 3, off = q;
+      if (off >= n3) { off -= n3; cls = 2; if (off >= n2) { off -= n2; cls = 1; if (off >= n1) { off -= n1; cls = 0; } } }
+      const int end = cls == 3 ? n3 : (cls == 2 ? n2 : (cls == 1 ? n1 : n0));
+      gi = live ? (size_t)lists[(size_t)cls * N + (end - 1 - off)] : 0;
+    }
+    if (__ballot(live) == 0) return;   // (one wavefront per workgroup: uniform)
+  }
   const size_t i = live ? gi : N - 1;
   const int hf = half;
   DC_ENV;
+  int rows_max = 0;
 #ifdef SAG_CYCLES
   if (lane == 0) { for (int k = 0; k < DCY_N; k++) g_dc_cyc[k] = 0; g_dc_cyc_t = __builtin_readcyclecounter(); }
 #endif
@@ -1140,87 +1260,32 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     DCC(DCY_ROWS_WORLD);
     // both envs of the wavefront take the same path: every row on its own lane of the env's half (<= 32 rows: the
     // usual case), or one env after the other on all 64 lanes
+    if (!live) nrows = 0;   // an idle half (odd batch, an env that runs in a front workgroup) takes no part in the solve
     const int nother = DC_EPW == 2 ? __shfl(nrows, (lane + 32) & 63) : nrows;
     const int nmax = max(nrows, nother);
-#ifndef SAG_DC_FAST_ROWS
-#define SAG_DC_FAST_ROWS DC_PGS_LANES   // (test builds lower it so that the 64-lane path runs on ordinary states)
+    rows_max = max(rows_max, nrows);
+    // which path an env takes is decided by ITS row count alone (its arithmetic must not depend on its partner in the
+    // wavefront: the launch order pairs envs differently from run to run)
+    const bool fast = nrows <= SAG_DC_FAST_ROWS;
+#ifdef SAG_CYCLES
+    if (lane == 0) atomicAdd(&g_cyc[0][min(nmax >> 2, CY_N)], 1ull);   // histogram of the wavefront's row count per evaluation, buckets of 4
 #endif
-    const bool fast = nmax <= SAG_DC_FAST_ROWS;
     const double a0 = dc_rows_finish(hf, u, nrows, fast);
     DCC(DCY_FINISH);
     // the first forward evaluation of an env-step starts cold, and so does the one at the final state behind the observation
     // (accelerometer and touch are functions of the state alone: a step's columns equal sag_observe's of the same state)
     const bool warm = sub > 0 && sub < nsub;
     const int iters = warm ? DG_PGS_ITERS : DG_PGS_ITERS0;
-    if (fast) {
-      // ---- projected Gauss-Seidel on the Delassus matrix: lane r owns row r (its accumulated force f and its
-      //      constraint acceleration acc = J_r qacc + planar-body term).  Updating row r changes every row's acc by
-      //      A[.][r] df: one broadcast (v_readlane: r is uniform) and one multiply-add per lane, no barrier, no
-      //      19-term dot product.  fp32 like A (round 2 ran these sweeps in fp64: 4 of them; the specification now runs
-      //      24, and a sweep is a contraction, so rounding does not accumulate).  Same sweep order and bounds as the oracle.
-      const bool mine = u < nrows;
-      const int ur = mine ? u : 0;
-      float Ar[DC_PGS_LANES];         // the lane's row of A in registers (A[r][u] = A[u][r]: consecutive words across lanes)
-#pragma unroll
-      for (int r = 0; r < DC_PGS_LANES; r++) Ar[r] = r < nrows ? E.A[r * DC_PGS_LANES + ur] : 0.f;
-      const float aref = (float)E.rAref[ur], reg = (float)E.rReg[ur], inv = (float)E.rInv[ur], mu = E.rMu[ur];
-      const int parent = E.rParent[ur];
-      const bool okA = mine && E.rA[ur] > 0, isfric = parent >= 0;
-      // warm start: the force this row had in the previous forward evaluation (matched by identity), inside its bounds
-      float f = 0.f;
-      if (warm) {
-        const uint32_t key = E.rKey[ur];
-        const int nprev = E.wsN;
-        float raw = 0.f;
-#pragma unroll 1
-        for (int q = 0; q < nprev; q++) raw = E.wsKey[q] == key ? E.wsF[q] : raw;   // (same address in every lane: LDS broadcast)
-        if (!okA || key == 0) raw = 0.f;
-        const float fn0 = fmaxf(raw, 0.f);                       // a normal / limit row: [0, inf)
-        const float fpar = __shfl(fn0, isfric ? parent : 0, 32);  // a friction row: +-mu x its normal row's force
-        f = isfric ? fminf(fmaxf(raw, -mu * fpar), mu * fpar) : fn0;
-      }
-      const float fpar0 = __shfl(f, isfric ? parent : 0, 32);   // (every lane takes part in the exchange)
-      float fn_contact = isfric ? fpar0 : 0.f;
-      float acc = (float)a0;
-      if (warm) {
-#pragma unroll
-        for (int r = 0; r < DC_PGS_LANES; r++)
-          if (r < __builtin_amdgcn_readfirstlane(nmax)) acc += Ar[r] * dc_bcastf(f, r, half);   // (no `break`: the loop must unroll - Ar is a register array)
-      }
-      // The sweep is ONE dependent chain through all rows (row r+1 needs the acc that row r's increment changed); a
-      // wavefront alone on its SIMD pays every link's latency, so the chain is kept short: the update
-      //   f <- clamp(f + (aref - acc - reg f) inv)  =  clamp(c1 f + c0 - inv acc),  c1 = 1 - reg inv, c0 = aref inv
-      // has its own-force part t = c1 f + c0 precomputed (f changes only at the row's own turn), every lane computes a
-      // candidate increment and the row's is picked by the broadcast itself (no select in front of it); rows that take
-      // no part (A <= 0, lanes beyond the last row) carry inv = 0, c1 = 1, c0 = 0: their candidate is 0.  Chain per
-      // row: fma, max, min, sub, readlane, (half select), fma.
-      // The lane tests `u == r`, `parent == r` are made on the spot (a compare + a select): hoisted out of the sweep
-      // loop they are 64 wave masks that live in spilled SGPRs and come back through two v_readlane each per row.
-      const float ninv = okA ? -inv : 0.f, c1 = okA ? 1.f - reg * inv : 1.f, c0 = okA ? aref * inv : 0.f;
-      const float mu_eff = isfric ? mu : 0.f, hi0 = isfric ? 0.f : 3.0e38f;   // bounds: [-mu fn, mu fn] / [0, inf)
-      const int nmax_u = __builtin_amdgcn_readfirstlane(nmax);               // (uniform: the row tests are scalar branches)
-#pragma unroll 1
-      for (int it = 0; it < iters; it++)
-#pragma unroll
-        for (int r = 0; r < DC_PGS_LANES; r++)   // unrolled: lane index and register index of the row are constants
-          if (r < nmax_u) {
-            int uu = u, pp = parent;
-            DC_OPAQUE(uu); DC_OPAQUE(pp);   // (keeps the two compares below inside the loop)
-            const float hi = fmaf(mu_eff, fn_contact, hi0);
-            const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
-            const float df = dc_bcastf(fc - f, r, half);
-            acc = fmaf(Ar[r], df, acc);
-            f = uu == r ? fc : f;
-            // a friction row tracks its contact's normal force by the same increments
-            fn_contact += pp == r ? df : 0.f;
-          }
-      if (mine) E.rF[u] = (double)f;
-    } else {
-      // an env with more than 32 rows (rare: a body deep inside the task box touches several of its geoms): the two envs
-      // take turns on all 64 lanes.  Three barriers per row update made such a wavefront the kernel's tail (13 ms).
-      const int n0 = __shfl(nrows, 0), n1 = DC_EPW == 2 ? __shfl(nrows, 32) : 0;
-      dc_pgs_wide(0, lane, n0, iters, warm);
-      if (DC_EPW == 2) dc_pgs_wide(1, lane, n1, iters, warm);
+    // both envs on the 32-lane path: one pass for the two halves together; otherwise one env after the other, each on its path
+    if (nmax <= SAG_DC_FAST_ROWS) dc_pgs_fast(hf, u, half, nrows, nmax, true, a0, iters, warm);
+    else {
+      // more than 32 rows (a robot lying on the floor, or deep inside the task box): on all 64 lanes.  (Three barriers
+      // per row update made such a wavefront the kernel's tail: 13 ms.)
+      const int n0 = __shfl(nrows, 0), n1 = DC_EPW == 2 ? __shfl(nrows, 32) : 0;   // (uniform)
+      if (n0 > SAG_DC_FAST_ROWS) dc_pgs_wide(0, lane, n0, iters, warm);
+      else if (n0 > 0) dc_pgs_fast(hf, u, half, nrows, n0, half == 0, a0, iters, warm);
+      if (n1 > SAG_DC_FAST_ROWS) dc_pgs_wide(1, lane, n1, iters, warm);
+      else if (n1 > 0) dc_pgs_fast(hf, u, half, nrows, n1, half == 1, a0, iters, warm);
     }
     __syncthreads();
     DCC(DCY_PGS);
@@ -1364,6 +1429,11 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
   }
 
   // ---- results: per-env block for the post kernel, state back to HBM ---------------------------
+  if (sched && live && u == 0) {   // file the env under its cost class for the next step's order
+    const int cls = rows_max > SAG_DC_FAST_ROWS ? 3 : (rows_max > SAG_DC_CLS2 ? 2 : (rows_max > SAG_DC_CLS1 ? 1 : 0));
+    const int slot = atomicAdd(&sc[((p.dg_phase + 1) % 3) * DC_NCLS + cls], 1);
+    sc[16 + ((size_t)((p.dg_phase + 1) & 1) * DC_NCLS + cls) * N + slot] = (int32_t)gi;
+  }
   if (live) {
     double* dr = DR + gi * DR_STRIDE;
     if (u < 3) dr[u] = E.qacc[u];
@@ -1393,7 +1463,12 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
   }
 #ifdef SAG_CYCLES
   DCC(DCY_STORE);
-  if (lane == 0) { for (int k = 0; k < DCY_N; k++) atomicAdd(&g_cyc[1][k], g_dc_cyc[k]); atomicAdd(&g_cyc[1][CY_N], 1ull); }
+  if (lane == 0) {
+    unsigned long long tot = 0;
+    for (int k = 0; k < DCY_N; k++) { atomicAdd(&g_cyc[1][k], g_dc_cyc[k]); tot += g_dc_cyc[k]; }
+    atomicAdd(&g_cyc[1][CY_N], 1ull);
+    atomicAdd(&g_cyc[2][min((int)(tot >> 19), CY_N)], 1ull);   // histogram of the wavefronts' total ticks, buckets of 2^19
+  }
 #endif
 }
 
