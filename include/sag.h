@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SAG_ABI_VERSION 4
+#define SAG_ABI_VERSION 5
 
 /* ---- capacities (maxima over the reference's task set: Task.obstacles) ---- */
 #define SAG_MAX_HAZARDS 9  /* tasks/go_to_goal.py:83-84  [9,10,0,1]          */
@@ -136,6 +136,12 @@ enum sag_rec_int {
                            * choice) differ from episode to episode as the reference's reseeded
                            * RandomState does (safe_adaptation_gym.py:97-101).  sag_set_layout takes it
                            * from the record, sag_reset adds one */
+  SAG_I_AWAKE = 15,       /* bit k: free body k (vases 0 .., the task object = bit SAG_MAX_VASES) takes part in the NEXT forward
+                           * evaluation although it is at rest.  sag_set_layout sets it for bodies whose bounding circle
+                           * overlaps another free body's, a pillar's or a button's (HaulBox spawns its box at robot + .6
+                           * without a keep-out check, haul_box.py:17-18: MuJoCo separates such a pair in the first steps,
+                           * and so does this); the first substep clears it (a body in motion is awake by its velocity);
+                           * sag_set_state / sag_get_state carry it like any other field (ABI v5) */
   SAG_REC_INTS = 16
 };
 
@@ -326,6 +332,11 @@ typedef struct sag_task_desc {
 } sag_task_desc;
 /* the descriptor of one of the reference's 14 tasks; returns SAG_ERR_ARG for an unknown id */
 int sag_task_desc_default(int32_t task_id, sag_task_desc* out);
+/* NULL if the descriptor is one the sampler and the device can serve, else a static string naming the offending field
+ * and the rule (capacities, button_timer 0..5 and 5 with button_reset 1, finite non-negative keep-outs, rectangles with
+ * xmin < xmax and ymin < ymax or all zero, no goal together with buttons).  sag_sample_layouts_desc returns SAG_ERR_ARG
+ * when this is not NULL for one of its descriptors. */
+const char* sag_task_desc_check(const sag_task_desc* desc);
 
 /* Replaces World.__init__ + sample_layout + _build_world_config + World.reset's host draws
  * (world.py:36-137,172-217; tasks' setup_placements/build_world_config/reset) for n envs on the
@@ -341,8 +352,8 @@ int sag_sample_layouts(int32_t robot, int32_t n, const uint32_t* seeds, const in
                        float* rec_f, int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos,
                        int32_t* mt_has_gauss, double* mt_gauss, int32_t* status, int32_t nthreads);
 /* The same with explicit task descriptors: env j uses descs[desc_of_env[j]] (n_descs of them).  sag_sample_layouts is
- * this call with the 14 default descriptors and desc_of_env = task_ids.  SAG_ERR_ARG if a descriptor exceeds the
- * record's capacity (SAG_MAX_HAZARDS / VASES / PILLARS / BUTTONS) or is inconsistent. */
+ * this call with the 14 default descriptors and desc_of_env = task_ids.  SAG_ERR_ARG if sag_task_desc_check rejects a
+ * descriptor. */
 int sag_sample_layouts_desc(int32_t robot, int32_t n, const uint32_t* seeds, const sag_task_desc* descs, int32_t n_descs,
                             const int32_t* desc_of_env, const sag_world_config* cfg, int32_t first_episode, int32_t env_id0,
                             float* rec_f, int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos,

@@ -610,6 +610,7 @@ typedef struct {
   int act_v[SAG_MAX_VASES], act_box;          /* free bodies that take part in this forward evaluation (see world_forward) */
   real ext_acc0[5], car_fa[3];                /* car: spin accelerations without floor friction; the friction's share of the base acceleration (body axes) */
   void* dg;                                   /* doggo: Doggo* articulated state (sag_oracle_doggo.inc) */
+  uint32_t awake0;   /* SAG_I_AWAKE: free bodies that take part in the NEXT forward evaluation although at rest (install-time overlap) */
 } World;
 
 static void material_default(Body* b) { b->mu = (real)FRICTION_MU; b->tc = (real)SOL_TC; b->dr = 1; b->prio = 0; }
@@ -813,6 +814,7 @@ static void world_from_env_r(const OEnv* e, World* w, int robot) {
                        (real)BUTTON_R);
   w->r_button = (real)BUTTON_R;
   box_from_env(e, w);
+  w->awake0 = (uint32_t)e->i[SAG_I_AWAKE];
 }
 
 static void world_to_env(const World* w, OEnv* e) {
@@ -837,6 +839,12 @@ static void world_to_env(const World* w, OEnv* e) {
     real* v = f + SAG_F_BOX;
     v[0] = b->x; v[1] = b->y; v[2] = b->yaw; v[3] = b->vx; v[4] = b->vy; v[5] = b->w;
   }
+  /* SAG_I_AWAKE as the device exports it: awake although at rest */
+  uint32_t at_rest = w->awake0;
+  for (int k = 0; k < w->nV; k++)
+    if (w->vase[k].vx != 0 || w->vase[k].vy != 0 || w->vase[k].w != 0) at_rest &= ~(1u << k);
+  if (w->box_kind == SAG_BOX_NONE || w->box.vx != 0 || w->box.vy != 0 || w->box.w != 0) at_rest &= ~(1u << SAG_MAX_VASES);
+  e->i[SAG_I_AWAKE] = (int32_t)at_rest;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1132,6 +1140,10 @@ static void car_integrate_ext(World* w, real h) {
  *   robot-pillars, robot-buttons, robot-vases, robot-box, haul tendon,
  *   vase-pillars/buttons, box-pillars/buttons, free-body pairs (i<j, lexicographic, the task
  *   object counting as the last body), then floor friction of each vase and of the box.
+ * (Round 4, ADVICE r3: bodies that OVERLAP something when a new world is installed are flagged awake for the first
+ * forward evaluation - SAG_I_AWAKE, set by sag_set_layout's bounding-circle test; the oracle takes the flags from the
+ * record - so a HaulBox box spawned over a vase or pillar is pushed clear in the first steps, as MuJoCo does.  The
+ * rest-capture rule below concerns bodies that came to rest DURING the simulation.)
  * SLEEPING BODIES (specification; the device kernels skip them): a free body takes part in a forward evaluation
  * only if it is ACTIVE - it has a non-zero velocity component, or a contact with the robot (or the pull of the
  * tether) was found in this evaluation, or a contact with an active free body was found in the pair walk.  Its
@@ -1154,8 +1166,8 @@ static int world_forward(World* w, const OEnv* e, const real* ctrl, const Sol* s
     w->box.minv[3] = s * s * ix + c * c * iy;
   }
   const int has_box = w->box_kind != SAG_BOX_NONE;
-  for (int k = 0; k < w->nV; k++) w->act_v[k] = g_sweeps > 1 || w->vase[k].vx != 0 || w->vase[k].vy != 0 || w->vase[k].w != 0;
-  w->act_box = has_box && (g_sweeps > 1 || w->box.vx != 0 || w->box.vy != 0 || w->box.w != 0);
+  for (int k = 0; k < w->nV; k++) w->act_v[k] = g_sweeps > 1 || (w->awake0 >> k & 1u) || w->vase[k].vx != 0 || w->vase[k].vy != 0 || w->vase[k].w != 0;
+  w->act_box = has_box && (g_sweeps > 1 || (w->awake0 >> SAG_MAX_VASES & 1u) || w->box.vx != 0 || w->box.vy != 0 || w->box.w != 0);
   int cost_contacts = 0;
   uint32_t mask = 0;
   /* every robot row of the Doggo (limits, floor, pillars, buttons, vases, box, tether) in one PGS of its own */
@@ -1271,6 +1283,7 @@ static void substeps_r(OEnv* e, const real* ctrl, int nstep, double h, int robot
     if (robot == SAG_ROBOT_CAR) car_integrate_ext(&w, sol.h);
     for (int k = 0; k < w.nV; k++) integrate_free(&w.vase[k], sol.h);
     if (w.box_kind != SAG_BOX_NONE) integrate_free(&w.box, sol.h);
+    w.awake0 = 0;   /* the install-time flags last for one forward evaluation + integration: from here on a body is awake by its velocity */
   }
   world_to_env(&w, e);
 }

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SAG_LIB overrides the library file (A/B builds of the same ABI during kernel tuning)
 LIB_PATH = os.environ.get('SAG_LIB') or os.path.join(_HERE, 'libsag.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_HAZARDS, MAX_VASES, MAX_PILLARS, MAX_BUTTONS, MAX_NU = 9, 10, 2, 6, 12
 REC_FLOATS, REC_INTS = 184, 16
 
@@ -23,7 +23,7 @@ F_HAZARDS, F_PILLARS, F_BUTTONS, F_VASES = 47, 65, 69, 81
 F_ROBOT_EXT = 144
 F_BOUND = 141
 (I_TASK, I_NH, I_NV, I_NP, I_NB, I_BOX_KIND, I_GOAL_BUTTON, I_BTN_STATE, I_BTN_TIMER,
- I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS, I_EPISODE) = range(15)
+ I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS, I_EPISODE, I_AWAKE) = range(16)
 
 ROBOT_IDS = {'point': 0, 'car': 1, 'doggo': 2}
 
@@ -32,7 +32,7 @@ EXPORTS = [
     'sag_reset', 'sag_get_state', 'sag_set_state', 'sag_step', 'sag_step_device', 'sag_wait',
     'sag_observe', 'sag_set_ext_contacts', 'sag_lidar_cost', 'sag_lidar_cost_device', 'sag_set_seed', 'sag_dev_alloc', 'sag_dev_free', 'sag_dev_upload',
     'sag_dev_download', 'sag_dev_fill_actions', 'sag_kernel_time_ms', 'sag_enable_timing', 'sag_busy_count', 'sag_debug_cycles', 'sag_render_rgb', 'sag_render_rgb_device', 'sag_render', 'sag_render_device', 'sag_debug_doggo_coop',
-    'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts', 'sag_sample_layouts_desc', 'sag_task_desc_default'
+    'sag_device_count', 'sag_world_config_default', 'sag_sample_layouts', 'sag_sample_layouts_desc', 'sag_task_desc_default', 'sag_task_desc_check'
 ]
 
 
@@ -152,6 +152,15 @@ def task_desc_default(task_id):
   return t.to_dict()
 
 
+def task_desc_check(desc):
+  """None, or what the library objects to in a descriptor dict (the field's name and the rule: include/sag.h)."""
+  lib = load()
+  lib.sag_task_desc_check.argtypes = [C.POINTER(TaskDesc)]
+  lib.sag_task_desc_check.restype = C.c_char_p
+  msg = lib.sag_task_desc_check(C.byref(TaskDesc.from_dict(desc)))
+  return None if msg is None else msg.decode()
+
+
 def sample_layouts(robot, seeds, task_ids, config=None, first_episode=True, env_id0=0,
                    want_rng=False, nthreads=None, descs=None):
   """Native reset path: records for len(seeds) envs, env j drawn with
@@ -186,6 +195,10 @@ def sample_layouts(robot, seeds, task_ids, config=None, first_episode=True, env_
   if descs is None:
     rc = lib.sag_sample_layouts(rid, n, _ptr(seeds, C.c_uint32), _ptr(tids, C.c_int32), *tail)
   else:
+    for k, d in enumerate(descs):
+      msg = task_desc_check(d)
+      if msg:
+        raise SagError(f'task descriptor {k}: {msg}')
     arr = (TaskDesc * len(descs))(*[TaskDesc.from_dict(d) for d in descs])
     rc = lib.sag_sample_layouts_desc(rid, n, _ptr(seeds, C.c_uint32), arr, len(descs), _ptr(tids, C.c_int32), *tail)
   if rc < 0:

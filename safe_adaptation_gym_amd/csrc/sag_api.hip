@@ -605,6 +605,7 @@ int sag_set_layout(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* r
   hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 1);
   c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
+  c->ext_pending = false;   // contact results supplied for another state do not carry over (sag_set_ext_contacts: "for the NEXT step")
   hipLaunchKernelGGL(k_clear_cost, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_cost, env_ids ? c->st_ids : nullptr, n);
   // keep a copy for sag_reset: read the installed state back into the AoS layout store
   hipLaunchKernelGGL(k_extract, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
@@ -632,6 +633,7 @@ int sag_set_state(sag_ctx* c, const int32_t* env_ids, int32_t n, const float* re
   hipLaunchKernelGGL(k_install, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->I, c->N,
                      env_ids ? c->st_ids : nullptr, n, c->st_f, c->st_i, 0);
   c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
+  c->ext_pending = false;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->have_layout = true;
@@ -679,6 +681,7 @@ int sag_reset(sag_ctx* c, const int32_t* env_ids, int32_t n) {
   }
   hipLaunchKernelGGL(k_clear_cost, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_cost, env_ids ? c->st_ids : nullptr, n);
   c->list_valid = false; c->hot_valid = false;  // busy bits / state changed outside a step
+  c->ext_pending = false;
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return SAG_OK;

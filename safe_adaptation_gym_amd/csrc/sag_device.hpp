@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     R.x = (float)dgs.pos[0]; R.y = (float)dgs.pos[1]; R.vx = (float)dgs.vlin[0]; R.vy = (float)dgs.vlin[1]; R.w = wz;
     R.ax = (float)dgr.qacc_lin[0]; R.ay = (float)dgr.qacc_lin[1];
-    awake = 0;
+    if (nsub > 0) awake = 0;   // (a step without substeps keeps the install-time flags, SAG_I_AWAKE)
     for (int k = 0; k < NBODY; k++) {
       const bool isb = k == BOX_ID;
       if (isb ? !has_box : k >= nV) continue;
@@ -2382,17 +2382,44 @@ __global__ void k_install(float* S, int32_t* I, int N, const int32_t* env_ids, i
   const float* rf = rec_f + (size_t)j * SAG_REC_FLOATS;
   const int32_t* ri = rec_i + (size_t)j * SAG_REC_INTS;
   for (int k = 0; k < SAG_REC_FLOATS; k++) S[saddr(k, (size_t)N, (size_t)i)] = rf[k];
-  // derived word: which free bodies are awake = have a non-zero velocity component.  (SPECIFICATION, oracle
-  // world_forward "sleeping bodies": a resting body takes part in a forward evaluation only once something active
-  // touches it - also when it was installed overlapping another resting body, e.g. the HaulBox box spawned over a
-  // vase: the pair is resolved when the tether first pulls the box.)
-  uint32_t awake = 0;
+  // derived word: which free bodies are awake = have a non-zero velocity component (SPECIFICATION, oracle world_forward
+  // "sleeping bodies": a resting body takes part in a forward evaluation only once something active touches it), or are
+  // flagged in SAG_I_AWAKE.  An install of a NEW world (sag_set_layout) flags the bodies whose bounding circle overlaps
+  // another free body's, a pillar's or a button's: the HaulBox box is spawned at robot + .6 with no keep-out check
+  // (haul_box.py:17-18) and may sit inside a vase or a pillar - MuJoCo pushes such a pair apart in the first steps, and
+  // with the flag so does the first substep here (round 3 left them interpenetrated until the tether pulled: ADVICE r3).
+  // sag_set_state / sag_reset take the flags from the record.
+  uint32_t awake = init_task ? 0u : (uint32_t)ri[SAG_I_AWAKE] & TS_AWAKE_BITS;
   {
-    const int nV = ri[SAG_I_NV], bkind = ri[SAG_I_BOX_KIND];
+    const int nV = ri[SAG_I_NV], bkind = ri[SAG_I_BOX_KIND], nP = ri[SAG_I_NP], nB = ri[SAG_I_NB];
+    const float vsz = rf[SAG_F_VASE_SIZE], psz = rf[SAG_F_PILLAR_SIZE];
+    auto exists = [&](int a) { return a < SAG_MAX_VASES ? a < nV : bkind != SAG_BOX_NONE; };
+    auto rec = [&](int a) { return a < SAG_MAX_VASES ? rf + SAG_F_VASES + 6 * a : rf + SAG_F_BOX; };
+    auto bound = [&](int a) {
+      return a < SAG_MAX_VASES ? shape_bound(SH_VASE, vsz, 0.f)
+                               : shape_bound(bkind == SAG_BOX_ROD ? SH_ROD : (bkind == SAG_BOX_BALL ? SH_BALL : SH_BOX), vsz, 0.f);
+    };
     for (int a = 0; a < NBODY; a++) {
-      if (a < SAG_MAX_VASES ? a >= nV : bkind == SAG_BOX_NONE) continue;
-      const float* va = a < SAG_MAX_VASES ? rf + SAG_F_VASES + 6 * a : rf + SAG_F_BOX;
+      if (!exists(a)) continue;
+      const float* va = rec(a);
       if (va[3] != 0 || va[4] != 0 || va[5] != 0) awake |= 1u << a;
+      if (!init_task) continue;
+      const float ra = bound(a);
+      bool over = false;
+      for (int b = 0; b < NBODY; b++) {
+        if (b == a || !exists(b)) continue;
+        const float dx = rec(b)[0] - va[0], dy = rec(b)[1] - va[1], rs = ra + bound(b);
+        over |= dx * dx + dy * dy < rs * rs;
+      }
+      for (int q = 0; q < nP; q++) {
+        const float dx = rf[SAG_F_PILLARS + 2 * q] - va[0], dy = rf[SAG_F_PILLARS + 2 * q + 1] - va[1], rs = ra + psz;
+        over |= dx * dx + dy * dy < rs * rs;
+      }
+      for (int q = 0; q < nB; q++) {
+        const float dx = rf[SAG_F_BUTTONS + 2 * q] - va[0], dy = rf[SAG_F_BUTTONS + 2 * q + 1] - va[1], rs = ra + BUTTON_R;
+        over |= dx * dx + dy * dy < rs * rs;
+      }
+      if (over) awake |= 1u << a;
     }
   }
   I[iaddr(DI_META, (size_t)N, (size_t)i)] = (int32_t)pack_meta(ri);
@@ -2437,6 +2464,13 @@ __global__ void k_extract(const float* S, const int32_t* I, int N, const int32_t
   const uint32_t fw = (uint32_t)I[iaddr(DI_FLAGS, (size_t)N, (size_t)i)];
   ri[SAG_I_FLAGS] = (int32_t)(fw & 0xffu);
   ri[SAG_I_EPISODE] = (int32_t)(fw >> FLAG_EPISODE_SHIFT);
+  // SAG_I_AWAKE: the bodies that are awake although at rest (after a step: none - a moving body is awake by its velocity)
+  uint32_t at_rest = (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)i)] >> TS_AWAKE_SHIFT & TS_AWAKE_BITS;
+  for (int a = 0; a < NBODY; a++) {
+    const float* va = a < SAG_MAX_VASES ? rf + SAG_F_VASES + 6 * a : rf + SAG_F_BOX;
+    if (va[3] != 0 || va[4] != 0 || va[5] != 0) at_rest &= ~(1u << a);
+  }
+  ri[SAG_I_AWAKE] = (int32_t)at_rest;
 }
 
 // rows of an AoS record store by env id: dst[ids[j]] <- src[j] (scatter) or dst[j] <- src[ids[j]] (gather);

@@ -878,7 +878,7 @@ __device__ __attribute__((noinline)) void dc_pgs_wide(const int e, const int lan
       if (r < nrows_u) {
         int uu = lane, pp = parent;
         DC_OPAQUE(uu); DC_OPAQUE(pp);
-        const float hi = fmaf(mu_eff, fn_contact, hi0);
+        const float hi = fmaf(mu_eff, fmaxf(fn_contact, 0.f), hi0);   // (the running sum of increments may end a hair below zero when the normal force clamps to 0: the bound must not turn negative)
         const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
         const float df = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc - f), r));
         acc = fmaf(Ar[r], df, acc);
@@ -947,7 +947,7 @@ __device__ __attribute__((noinline)) void dc_pgs_fast(const int hf, const int u,
       if (r < nmax_u) {
         int uu = u, pp = parent;
         DC_OPAQUE(uu); DC_OPAQUE(pp);   // (keeps the two compares below inside the loop)
-        const float hi = fmaf(mu_eff, fn_contact, hi0);
+        const float hi = fmaf(mu_eff, fmaxf(fn_contact, 0.f), hi0);   // (the running sum of increments may end a hair below zero when the normal force clamps to 0: the bound must not turn negative)
         const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
         const float df = dc_bcastf(fc - f, r, half);
         acc = fmaf(Ar[r], df, acc);
@@ -1113,6 +1113,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
   DCC(DCY_LOAD);
 
   const int nsub = p.observe_only ? 0 : p.nstep;
+  const uint32_t awake0 = (uint32_t)p.I[iaddr(DI_TSTATE, N, i)] >> TS_AWAKE_SHIFT & TS_AWAKE_BITS;
   int cost_contacts = 0;
   uint32_t btn_mask = 0;
   double qacc_u = 0;
@@ -1122,6 +1123,7 @@ __global__ __launch_bounds__(32 * DC_EPW) void k_doggo_physics(StepArgs p, doubl
     // planar bodies that take part in this forward evaluation: the moving ones, + below those the robot touches
     // (specification: oracle world_forward, "sleeping bodies"); uniform in the half
     uint32_t act = (uint32_t)(__ballot(u < NBODY && (E.wfb[u][3] != 0 || E.wfb[u][4] != 0 || E.wfb[u][5] != 0)) >> (32 * half)) & ((1u << NBODY) - 1);
+    if (sub == 0) act |= awake0;   // SAG_I_AWAKE: bodies installed overlapping something take part in the first evaluation
     if (u == BOX_ID && W.has_box && W.bk.sh == SH_ROD) {
       float c, s; sincosf(E.wfb[BOX_ID][2], &s, &c);
       const float ix = 1.0f / (1.5f * W.bk.m), iy = 1.0f / W.bk.m;

@@ -299,19 +299,49 @@ int sag_task_desc_default(int32_t task_id, sag_task_desc* d) {
   return SAG_OK;
 }
 
+// what is wrong with a descriptor (the field's name and the rule), or nullptr
+const char* sag_task_desc_check(const sag_task_desc* dp) {
+  if (!dp) return "descriptor: null";
+  const sag_task_desc& d = *dp;
+  auto bad_rect = [](const double* r) {   // all zero = "the extents"; else finite with xmin < xmax, ymin < ymax
+    if (r[0] == 0 && r[1] == 0 && r[2] == 0 && r[3] == 0) return false;
+    for (int k = 0; k < 4; k++) if (!std::isfinite(r[k])) return true;
+    return !(r[0] < r[2] && r[1] < r[3]);
+  };
+  auto bad_keepout = [](double k) { return !std::isfinite(k) || k < 0; };
+  if (d.task_id < 0 || d.task_id >= SAG_NUM_TASKS) return "task_id: not one of the 14 tasks";
+  if (d.n_hazards < 0 || d.n_hazards > SAG_MAX_HAZARDS) return "n_hazards: outside 0..SAG_MAX_HAZARDS";
+  if (d.n_vases < 0 || d.n_vases > SAG_MAX_VASES) return "n_vases: outside 0..SAG_MAX_VASES";
+  if (d.n_pillars < 0 || d.n_pillars > SAG_MAX_PILLARS) return "n_pillars: outside 0..SAG_MAX_PILLARS";
+  if (d.n_buttons < 0 || d.n_buttons > SAG_MAX_BUTTONS) return "n_buttons: outside 0..SAG_MAX_BUTTONS";
+  if (d.box_kind < 0 || d.box_kind > SAG_BOX_BALL) return "box_kind: not an enum sag_box_kind";
+  for (int k = 0; k < 4; k++) if (!std::isfinite(d.extents[k])) return "extents: not finite";
+  if (!(d.extents[0] < d.extents[2]) || !(d.extents[1] < d.extents[3])) return "extents: need xmin < xmax and ymin < ymax";
+  if (d.button_reset < 0 || d.button_reset > 2) return "button_reset: 0 none, 1 choice + timer, 2 all active";
+  if (d.button_reset && !d.n_buttons) return "button_reset: set without buttons";
+  if (d.box_at_robot && !d.box_kind) return "box_at_robot: set without a task object";
+  // the device keeps the timer in 3 bits and re-arms it with its own constant (press_buttons.py:14 BUTTON_TICKING_DELAY = 5)
+  if (d.button_timer < 0 || d.button_timer > 5) return "button_timer: outside 0..5 (a 3-bit field on the device)";
+  if (d.button_reset == 1 && d.button_timer != 5) return "button_timer: the device re-arms the PressButtons timer with 5 (BUTTON_TICKING_DELAY)";
+  // the in-step goal resampling on the device (go_to_goal.py:59-80) tests hazards, vases, pillars and the task object, not buttons
+  if (d.has_goal && d.n_buttons) return "has_goal with n_buttons: the device-side goal resampling does not know button keep-outs";
+  if (bad_keepout(d.goal_keepout)) return "goal_keepout: negative or not finite";
+  if (bad_keepout(d.box_keepout)) return "box_keepout: negative or not finite";
+  if (bad_keepout(d.button_keepout)) return "button_keepout: negative or not finite";
+  if (!std::isfinite(d.box_offset)) return "box_offset: not finite";
+  if (bad_rect(d.box_rect)) return "box_rect: need finite xmin < xmax, ymin < ymax (or all zero for the extents)";
+  if (bad_rect(d.button_rect)) return "button_rect: need finite xmin < xmax, ymin < ymax (or all zero for the extents)";
+  if (!std::isfinite(d.gear) || !std::isfinite(d.damping) || d.gear < 0 || d.damping < 0) return "gear / damping: negative or not finite";
+  return nullptr;
+}
+
 int sag_sample_layouts_desc(int32_t robot, int32_t n, const uint32_t* seeds, const sag_task_desc* descs, int32_t n_descs,
                             const int32_t* desc_of_env, const sag_world_config* cfg, int32_t first_episode, int32_t env_id0,
                             float* rec_f, int32_t* rec_i, uint32_t* mt_key, int32_t* mt_pos, int32_t* mt_has_gauss,
                             double* mt_gauss, int32_t* status, int32_t nthreads) {
   if (robot < 0 || robot > 2 || n <= 0 || !seeds || !descs || n_descs <= 0 || !desc_of_env || !rec_f || !rec_i) return SAG_ERR_ARG;
-  for (int k = 0; k < n_descs; k++) {
-    const sag_task_desc& d = descs[k];
-    if (d.task_id < 0 || d.task_id >= SAG_NUM_TASKS || d.n_hazards < 0 || d.n_hazards > SAG_MAX_HAZARDS || d.n_vases < 0 ||
-        d.n_vases > SAG_MAX_VASES || d.n_pillars < 0 || d.n_pillars > SAG_MAX_PILLARS || d.n_buttons < 0 ||
-        d.n_buttons > SAG_MAX_BUTTONS || d.box_kind < 0 || d.box_kind > SAG_BOX_BALL || !(d.extents[0] < d.extents[2]) ||
-        !(d.extents[1] < d.extents[3]) || (d.button_reset && !d.n_buttons) || (d.box_at_robot && !d.box_kind))
-      return SAG_ERR_ARG;
-  }
+  for (int k = 0; k < n_descs; k++)
+    if (sag_task_desc_check(&descs[k])) return SAG_ERR_ARG;   // (sag_task_desc_check names the field)
   for (int i = 0; i < n; i++)
     if (desc_of_env[i] < 0 || desc_of_env[i] >= n_descs) return SAG_ERR_ARG;
   sag_world_config c;

@@ -131,4 +131,11 @@ class Task:
     order = [k for k in keys if k in ('goal', 'box')] + [k for k in keys if k.startswith('buttons')]
     if keys != order or ('goal' in keys and 'box' in keys and keys.index('goal') > keys.index('box')):
       raise NotImplementedError(f'{cls}.setup_placements(): order {keys} (the sampler draws goal, box, buttons in this order)')
+    # what the library itself would refuse (button_timer outside the device's 3-bit field or different from the constant it
+    # re-arms with, negative / non-finite keep-outs, degenerate rectangles, a goal together with buttons): here, with the
+    # class name, instead of a late "record exceeds capacities" - or silently different worlds after the first goal_met
+    from .. import _native
+    msg = _native.task_desc_check(d)
+    if msg:
+      raise ValueError(f'{cls}: {msg}')
     return d

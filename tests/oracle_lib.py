@@ -19,7 +19,7 @@ F_HAZARDS, F_PILLARS, F_BUTTONS, F_VASES = 47, 65, 69, 81
 F_ROBOT_EXT = 144
 F_BOUND = 141
 (I_TASK, I_NH, I_NV, I_NP, I_NB, I_BOX_KIND, I_GOAL_BUTTON, I_BTN_STATE,
- I_BTN_TIMER, I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS, I_EPISODE) = range(15)
+ I_BTN_TIMER, I_CATCH_TIMER, I_ACTIVE_MASK, I_STEP, I_ENV_ID, I_FLAGS, I_EPISODE, I_AWAKE) = range(16)
 
 
 def build(force=False):

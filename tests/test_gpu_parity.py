@@ -303,6 +303,7 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
   arr = oracle.make_batch(rf, ri)
   np.testing.assert_allclose(obs0, oracle.observe_batch(arr, rid, od), rtol=0, atol=OBS_TOL)
   n_met = n_cost = n_near = viol64 = viol32 = acc_bad = acc_e2e = 0
+  bad64_env, bad32_env = np.zeros(n, int), np.zeros(n, int)
   for t in range(T):
     rf, ri = ctx.get_state()
     arr, arr32 = oracle.make_batch(rf, ri), oracle32.make_batch(rf, ri)
@@ -337,6 +338,7 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
     bad32 = (np.abs(d_rf - o32_rf) > tol32 + tol32 * np.abs(o32_rf)).any(1)
     viol64 += int(bad64.sum())
     viol32 += int(bad32.sum())
+    bad64_env += bad64; bad32_env += bad32
     ok = ~bad64
     # discrete outputs
     np.testing.assert_array_equal(d_done, o_done)
@@ -374,17 +376,26 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
   assert n_met > (5 if ri[:, 5].any() else 20), 'the rollout should exercise goal-met events'
   assert n_cost > 20, 'the rollout should exercise cost events'
   assert n_near <= 0.001 * n * T
-  # (the ball's contact is stiff and underdamped - k h^2 = 1.4 - and amplifies rounding more)
-  # (the car has 8 geoms and a 2x longer step: proportionally more contact onsets per env-step)
-  # (car mix: one dribble_ball env in sustained stiff contact accounts for ~85 of its env-steps on its own)
-  # Budgets sit at ~2-3x the measured counts (profiles/r03_lockstep_counts.txt: Point tasks <= 3 of 30 720 env-steps, Car tasks <= 9,
-  # car/haul_box 29 against the fp32 build, the Point mix 54 of 245 760), except the two stiff cases that are near theirs
-  # (dribble_ball 105 of 30 720 against the fp32 build; the Car mix 3.4e-3, its dribble_ball envs).
-  if task == 'dribble_ball': frac = 0.005
-  elif task == MIXED: frac = 0.004 if robot == 'car' else 0.0005
-  elif robot == 'car': frac = 0.0015 if task == 'haul_box' else 0.0005
-  else: frac = 0.0002
-  budget = frac * n * T
+  # Budgets per TASK, at ~2-3x the measured counts (profiles/r04_lockstep_counts.txt; round 3: Point tasks <= 3 of 30 720
+  # env-steps, Car tasks <= 9, car/haul_box 29 against the fp32 build, dribble_ball 105 of 30 720 against the fp32 build):
+  #   dribble_ball   the ball's contact is stiff and underdamped (k h^2 = 1.4) and amplifies rounding: 1 %
+  #   car            8 geoms and a 2x longer step, proportionally more contact onsets per env-step: 0.05 %, haul_box 0.15 %
+  #   point          0.02 %
+  # A mixed batch is budgeted task by task - the sum over its envs of their task's rate (round 3 gave the Car mix one
+  # rate, 0.4 %, which its dribble_ball envs alone filled to 85 %: the verdict's "budgets at 2 - 3 x measured does not hold
+  # there") - and the counts of the mix's dribble_ball envs are logged beside the rest.
+  def task_frac(name):
+    if name == 'dribble_ball': return 0.01
+    if robot == 'car': return 0.0015 if name == 'haul_box' else 0.0005
+    return 0.0002
+  env_names = names if task == MIXED else [task] * n
+  budget = T * sum(task_frac(nm) for nm in env_names)
+  is_ball = np.array([nm == 'dribble_ball' for nm in env_names])
+  if task == MIXED:
+    rest = T * sum(task_frac(nm) for nm in env_names if nm != 'dribble_ball')
+    _log_lockstep(f'{robot}/{task}: of which its {int(is_ball.sum())} dribble_ball envs {int(bad64_env[is_ball].sum())} / {int(bad32_env[is_ball].sum())} (fp64 / fp32), '
+                  f'the other {int((~is_ball).sum())} envs {int(bad64_env[~is_ball].sum())} / {int(bad32_env[~is_ball].sum())} against a budget of {rest:.0f}')
+    assert bad64_env[~is_ball].sum() <= rest and bad32_env[~is_ball].sum() <= rest
   _log_lockstep(f'{robot}/{task}: {n} envs x {T} steps resynchronised every step | env-steps outside the stated tolerance vs fp64 oracle {viol64} '
                 f'({viol64 / (n * T):.2e}), vs fp32 oracle {viol32} ({viol32 / (n * T):.2e}), budget {budget / (n * T):.1e} | cost flags within 1e-5 of a '
                 f'threshold {n_near} | accelerometer off on identical state {acc_bad}, end to end {acc_e2e} | goal-met events {n_met}, cost events {n_cost}')
@@ -642,6 +653,72 @@ def test_state_roundtrip_reset_and_errors(nat):
     nat.Context('point', 4, device=99)
 
 
+def test_box_spawned_over_an_obstacle_is_flagged_and_pushed_clear(nat, oracle):
+  """HaulBox places its box at robot + .6 with no keep-out check (haul_box.py:17-18), so it can sit
+  inside a vase or a pillar.  sag_set_layout flags the overlapping free bodies awake (SAG_I_AWAKE, bounding circles), the
+  first substep pushes them apart as MuJoCo would, and device and oracle agree step by step from the installed state;
+  sag_reset restores the flags with the layout; sag_set_state takes them as given (0 = asleep: the body stays)."""
+  n = 6
+  rf, ri = bu.sample_records('point', 'haul_box', n, seed=11)
+  for e in range(n):
+    rf[e, 65:69] = 50.0; ri[e, 3] = 1   # one pillar (r .2) ...
+    ri[e, 2] = 1                        # ... and one vase
+    rf[e, 81:87] = 0
+    box = rf[e, 41:43]
+    if e < 3:
+      rf[e, 65:67] = box + [0.25, 0.0]    # the pillar 5 cm inside the box's main geom
+      rf[e, 81:83] = box + [50.0, 0.0]
+    else:
+      rf[e, 81:83] = box + [0.0, 0.28]    # the vase (half .1) 2 cm inside it
+  ctx = nat.Context('point', n, seed=3)
+  ctx.set_layout(rf, ri)
+  rf0, ri0 = ctx.get_state()
+  assert (ri0[:3, 15] == 1 << 10).all() and (ri0[3:, 15] == (1 << 10 | 1)).all(), ri0[:, 15]
+  zero = np.zeros((n, 2), np.float32)
+  tape = np.zeros((n, 64), np.uint32)
+  for t in range(12):
+    s_rf, s_ri = ctx.get_state()
+    arr = oracle.make_batch(s_rf, s_ri)
+    ctx.step(zero, zero, tape)
+    oracle.step_batch_full(arr, 0, zero, zero, tape)
+    d_rf, d_ri = ctx.get_state()
+    o_rf, o_ri = oracle.batch_records(arr)
+    np.testing.assert_allclose(d_rf, o_rf, rtol=STATE_TOL, atol=STATE_TOL, err_msg=f'step {t}')
+    np.testing.assert_array_equal(d_ri, o_ri)
+    assert (d_ri[:, 15] == 0).all(), 'the flags last for the first substep'
+  moved = np.hypot(*(d_rf[:3, 41:43] - rf0[:3, 41:43]).T)
+  assert (moved > 0.02).all(), f'a box is pushed off the pillar it was spawned in: {moved}'
+  moved = np.hypot(*(d_rf[3:, 81:83] - rf0[3:, 81:83]).T)
+  assert (moved > 0.004).all(), f'box and vase are pushed apart (the vase, 8 mg against 96, is the one that moves): {moved}'
+  ctx.reset()
+  assert (ctx.get_state()[1][:, 15] == ri0[:, 15]).all(), 'sag_reset restores the install-time flags'
+  asleep = ri0.copy(); asleep[:, 15] = 0
+  ctx.set_state(rf0, asleep)
+  for _ in range(5):
+    ctx.step(zero, zero, tape)
+  np.testing.assert_array_equal(ctx.get_state()[0][:, 41:44], rf0[:, 41:44])   # a record restored as asleep stays asleep
+  ctx.close()
+
+
+def test_ext_contacts_do_not_outlive_the_state_they_were_given_for(nat):
+  """contact results supplied with sag_set_ext_contacts are for the NEXT step of THAT state: sag_set_state,
+  sag_set_layout and sag_reset drop them."""
+  n = 4
+  rf, ri = bu.sample_records('point', 'go_to_goal', n, seed=5)
+  rf[:, 47:65] = 50.0   # hazards far away: no geometric cost
+  ctx = nat.Context('point', n, seed=3)
+  ctx.set_layout(rf, ri)
+  zero = np.zeros((n, 2), np.float32)
+  tape = np.zeros((n, 64), np.uint32)
+  ctx.set_ext_contacts([1] * n, [0] * n)
+  assert ctx.step(zero, zero, tape, nstep=0)[2].all(), 'the supplied contact count raises the cost'
+  for drop in (lambda: ctx.set_state(*ctx.get_state()), lambda: ctx.set_layout(rf, ri), lambda: ctx.reset()):
+    ctx.set_ext_contacts([1] * n, [0] * n)
+    drop()
+    assert not ctx.step(zero, zero, tape, nstep=0)[2].any()
+  ctx.close()
+
+
 def test_physics_error_is_data(nat):
   """Non-finite state -> (reward -10, done, cost 0) for that env only (safe_adaptation_gym.py:73-75)."""
   n = 70
@@ -797,7 +874,10 @@ def test_car_env_api(nat):
 DOGGO_TASKS = ['go_to_goal', 'push_box', 'press_buttons', 'haul_box', 'unsupervised', 'collect', MIXED]
 
 
-@pytest.mark.parametrize('task', DOGGO_TASKS)
+DOGGO_C4 = 'multitask-4096'   # BASELINE config 4 at one rank's size
+
+
+@pytest.mark.parametrize('task', DOGGO_TASKS + [DOGGO_C4])
 def test_doggo_lockstep_vs_oracle(nat, oracle, task):
   """Same protocol as test_step_lockstep_vs_oracle for the Doggo robot (BASELINE config 4 shape
   for 'multitask').  Stated tolerance after one step (12 substeps) from identical fp32 state:
@@ -805,10 +885,15 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task):
   robot in fp64 but stores fp32 and keeps the planar world in fp32; 12 substeps of stiff
   soft-contact dynamics amplify that rounding), free bodies within the planar STATE_TOL;
   threshold events (a sphere's penetration changing sign with the rounding) are counted and
-  bounded.  goal_met / done / task ints / RNG words exact on rows inside the tolerance."""
-  n, T = 64, 30
+  bounded.  goal_met / done / task ints / RNG words exact on rows inside the tolerance.
+  `multitask-4096` is BASELINE config 4 at its stated size per rank (4096 envs, ~290 per task, 14 steps: VERDICT r3
+  item 2), the oracle on every host core.  Cost flags that differ away from any threshold are counted over the WHOLE
+  run (round 3 allowed one per step) and budgeted at 2 - 3 x the measured count (profiles/r04_lockstep_counts.txt)."""
+  n, T = (4096, 14) if task == DOGGO_C4 else (64, 30)
   from safe_adaptation_gym_amd import benchmark
-  if task == MIXED:
+  if task == DOGGO_C4:
+    oracle.lib.sago_set_threads(os.cpu_count() or 1)
+  if task in (MIXED, DOGGO_C4):
     names = [nm for nm, _ in benchmark.make('multitask', batch_size=n, seed=666).train_tasks]
   else:
     names = task
@@ -822,7 +907,7 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task):
   E = 144
   pos_f = [0, 1, 2, E] + list(range(E + 1, E + 5)) + list(range(E + 9, E + 22))
   viol = n_rows = 0
-  touched = 0
+  touched = flag_mism = flag_near = overflow = 0
   for t in range(T):
     rf, ri = ctx.get_state()
     arr = oracle.make_batch(rf, ri)
@@ -849,8 +934,9 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task):
     np.testing.assert_array_equal(d_met[ok], o_met[ok])
     np.testing.assert_array_equal(d_used[ok], o_used[ok])
     np.testing.assert_array_equal(d_ri[ok], o_ri[ok])
-    mism = ok & (d_cost != o_cost) & (o_margin > 1e-5)
-    assert mism.sum() <= 1, f'cost flags differ away from a threshold at step {t}'
+    flag_mism += int((ok & (d_cost != o_cost) & (o_margin > 1e-5)).sum())
+    flag_near += int((ok & (d_cost != o_cost) & (o_margin <= 1e-5)).sum())
+    overflow += int((d_ri[:, 13] & 4 != 0).sum())
     # observation as a function of the device's own post-step state (lidar, kinematic sensors)
     f_obs = oracle.observe_batch(oracle.make_batch(d_rf, d_ri), 2, 104)
     np.testing.assert_allclose(d_obs[:, :48], f_obs[:, :48], rtol=0, atol=OBS_TOL, err_msg=f'lidar step {t}')
@@ -861,10 +947,18 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task):
     np.testing.assert_allclose(d_obs[ok, 60:68], o_obs[ok, 60:68], rtol=2e-2, atol=2e-3, err_msg=f'touch step {t}')
     np.testing.assert_allclose(d_rew[ok], o_rew[ok], rtol=0, atol=2e-4, err_msg=f'reward step {t}')
     touched += int((d_obs[:, 60:68] > 0).any(1).sum())
+  # cost flags differing away from any threshold, over the whole run: a contact whose penetration changes sign with the
+  # rounding (fp32 planar world on the device, fp64 in the oracle).  Budget: 0.15 % of the env-steps, at least 2
+  # (measured: see the log).
+  flag_budget = max(2, int(0.0015 * n_rows))
   _log_lockstep(f'doggo/{task}: {n} envs x {T} steps resynchronised every step | env-steps outside the stated tolerance vs fp64 oracle {viol} '
-                f'({viol / n_rows:.2e}), budget 5.0e-03 | env-steps with floor touch {touched}')
+                f'({viol / n_rows:.2e}), budget 5.0e-03 | cost flags differing away from a threshold {flag_mism} ({flag_mism / n_rows:.2e}; budget {flag_budget}), '
+                f'within 1e-5 of one {flag_near} | env-steps with floor touch {touched} | env-steps with a row overflow {overflow}')
   assert touched > 0.8 * n * (T - 3), 'the robots should stand on the floor'
-  assert viol <= 0.005 * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'   # measured: <= 1 of 1920 (profiles/r03_lockstep_counts.txt)
+  assert viol <= 0.005 * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'
+  assert flag_mism <= flag_budget, f'{flag_mism} cost flags differ away from a threshold'
+  if task == DOGGO_C4:
+    oracle.lib.sago_set_threads(1)
   ctx.close()
 
 

@@ -178,3 +178,42 @@ def test_task_surface_limits_raise():
 
   with pytest.raises(NotImplementedError, match='goal placement'):
     MovedGoal().descriptor()
+
+
+def test_descriptor_validation_names_the_field():
+  """what the device cannot serve is refused when the descriptor is BUILT, by name - button_timer outside its
+  3-bit field (or different from the constant the device re-arms with), negative / non-finite keep-outs, degenerate
+  rectangles, a goal together with buttons - at Task.descriptor() and again at the C ABI."""
+  from safe_adaptation_gym_amd.tasks.press_buttons import PressButtons
+  from safe_adaptation_gym_amd.tasks.push_box import PushBox
+
+  class SlowButtons(PressButtons):
+    BUTTON_TICKING_DELAY = 9
+
+  with pytest.raises(ValueError, match='SlowButtons: button_timer'):
+    SlowButtons().descriptor()
+
+  class NegativeKeepout(PushBox):
+    BOX_KEEPOUT = -0.1
+
+  with pytest.raises(ValueError, match='NegativeKeepout: box_keepout'):
+    NegativeKeepout().descriptor()
+
+  class BackwardsRect(PushBox):
+    def setup_placements(self):
+      p = super().setup_placements()
+      p['box'] = ([(1.0, -0.5, 0.5, 0.5)], self.BOX_KEEPOUT)
+      return p
+
+  with pytest.raises(ValueError, match='BackwardsRect: box_rect'):
+    BackwardsRect().descriptor()
+
+  good = PressButtons().descriptor()
+  assert nat.task_desc_check(good) is None
+  for field, value, word in [('button_timer', 7, 'button_timer'), ('button_keepout', float('nan'), 'button_keepout'),
+                             ('has_goal', 1, 'has_goal'), ('button_rect', [0.5, 0.0, 0.5, 1.0], 'button_rect'),
+                             ('extents', [0.0, 0.0, float('inf'), 1.0], 'extents'), ('n_buttons', 7, 'n_buttons')]:
+    bad = dict(good, **{field: value})
+    assert word in nat.task_desc_check(bad)
+    with pytest.raises(nat.SagError, match=word):
+      nat.sample_layouts('point', [1, 2], 0, descs=[bad])

@@ -221,6 +221,26 @@ def test_haul_tendon_limits_the_distance(oracle):
   assert f[F_BOX] < 0.55, 'box is hauled along'
 
 
+def test_box_spawned_over_a_pillar_is_pushed_clear_only_when_flagged_awake(oracle):
+  """HaulBox places its box at robot + .6 with no keep-out check (haul_box.py:17-18): it may sit inside a pillar.
+  With the install-time flag SAG_I_AWAKE (what sag_set_layout's overlap test sets: ADVICE r3) the box takes part in the
+  first forward evaluation and is pushed clear of the pillar, as MuJoCo separates such a pair; a box that came to rest
+  there WITHOUT the flag stays asleep until something active touches it (the sleeping-body rule)."""
+  from oracle_lib import I_AWAKE
+  rf, ri = box_world('haul_box', 1, (0.6, 0.0))
+  ri[I_NP] = 1
+  rf[F_PILLARS:F_PILLARS + 2] = [0.85, 0.0]        # pillar r .2: 5 cm inside the box's main geom (half .2)
+  ri[I_AWAKE] = 1 << 10
+  e, _ = run(oracle, rf, ri, [0.0, 0.0], 40)
+  f, i = oracle.record(e)
+  assert f[F_BOX] < 0.6 - 0.04, 'the box is pushed off the pillar'
+  assert np.hypot(f[F_BOX] - 0.85, f[F_BOX + 1]) >= 0.2 + 0.2 - 2e-3
+  assert i[I_AWAKE] == 0, 'the flag lasts for the first substep'
+  ri[I_AWAKE] = 0
+  e, _ = run(oracle, rf, ri, [0.0, 0.0], 40)
+  assert oracle.record(e)[0][F_BOX] == pytest.approx(0.6, abs=1e-7)
+
+
 # ---------------------------------------------------------------------------
 # Car robot: planar reduction of car.xml (specification)
 # ---------------------------------------------------------------------------
