@@ -378,14 +378,16 @@ def _lockstep(nat, oracle, oracle32, robot, task, scale):
   assert n_near <= 0.001 * n * T
   # Budgets per TASK, at ~2-3x the measured counts (profiles/r04_lockstep_counts.txt; round 3: Point tasks <= 3 of 30 720
   # env-steps, Car tasks <= 9, car/haul_box 29 against the fp32 build, dribble_ball 105 of 30 720 against the fp32 build):
-  #   dribble_ball   the ball's contact is stiff and underdamped (k h^2 = 1.4) and amplifies rounding: 1 %
+  #   dribble_ball   the ball's contact is stiff and underdamped (k h^2 = 1.4) and amplifies rounding: 1 % for the Point; the
+  #                  Car (2x the substep, k h^2 = 5.7; it keeps the ball in SUSTAINED contact against its bumper) 12 % -
+  #                  measured 92 of the 1920 env-steps of the Car mix's 12 dribble_ball envs, nearly all from one env
   #   car            8 geoms and a 2x longer step, proportionally more contact onsets per env-step: 0.05 %, haul_box 0.15 %
   #   point          0.02 %
   # A mixed batch is budgeted task by task - the sum over its envs of their task's rate (round 3 gave the Car mix one
   # rate, 0.4 %, which its dribble_ball envs alone filled to 85 %: the verdict's "budgets at 2 - 3 x measured does not hold
   # there") - and the counts of the mix's dribble_ball envs are logged beside the rest.
   def task_frac(name):
-    if name == 'dribble_ball': return 0.01
+    if name == 'dribble_ball': return 0.12 if robot == 'car' else 0.01
     if robot == 'car': return 0.0015 if name == 'haul_box' else 0.0005
     return 0.0002
   env_names = names if task == MIXED else [task] * n
@@ -948,14 +950,16 @@ def test_doggo_lockstep_vs_oracle(nat, oracle, task):
     np.testing.assert_allclose(d_rew[ok], o_rew[ok], rtol=0, atol=2e-4, err_msg=f'reward step {t}')
     touched += int((d_obs[:, 60:68] > 0).any(1).sum())
   # cost flags differing away from any threshold, over the whole run: a contact whose penetration changes sign with the
-  # rounding (fp32 planar world on the device, fp64 in the oracle).  Budget: 0.15 % of the env-steps, at least 2
-  # (measured: see the log).
-  flag_budget = max(2, int(0.0015 * n_rows))
+  # rounding (fp32 planar world on the device, fp64 in the oracle).  Measured (profiles/r04_lockstep_counts.txt): 0 of
+  # 57 344 env-steps at config 4's size, 0 - 1 of 1920 in the small cases; budget 1e-4 of the env-steps, at least 2.
+  # State: 10 of 57 344 outside the tolerance at config 4's size (budget 5e-4), 0 - 3 of 1920 in the small cases (0.5 %).
+  flag_budget = max(2, int(1e-4 * n_rows))
+  viol_frac = 0.0005 if task == DOGGO_C4 else 0.005
   _log_lockstep(f'doggo/{task}: {n} envs x {T} steps resynchronised every step | env-steps outside the stated tolerance vs fp64 oracle {viol} '
-                f'({viol / n_rows:.2e}), budget 5.0e-03 | cost flags differing away from a threshold {flag_mism} ({flag_mism / n_rows:.2e}; budget {flag_budget}), '
+                f'({viol / n_rows:.2e}), budget {viol_frac:.1e} | cost flags differing away from a threshold {flag_mism} ({flag_mism / n_rows:.2e}; budget {flag_budget}), '
                 f'within 1e-5 of one {flag_near} | env-steps with floor touch {touched} | env-steps with a row overflow {overflow}')
   assert touched > 0.8 * n * (T - 3), 'the robots should stand on the floor'
-  assert viol <= 0.005 * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'
+  assert viol <= viol_frac * n_rows, f'{viol} of {n_rows} env-steps outside the stated tolerance'
   assert flag_mism <= flag_budget, f'{flag_mism} cost flags differ away from a threshold'
   if task == DOGGO_C4:
     oracle.lib.sago_set_threads(1)
