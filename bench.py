@@ -67,6 +67,13 @@ def source_sha16():
   return h.hexdigest()[:16]
 
 
+def sampler_threads():
+  """Host threads one rank gives the native layout sampler: the box's cores divided among the ranks that share it (on an
+  8-GPU node every rank samples its own shard before the first barrier: 8 x 16 threads on one host was minutes of skew)."""
+  world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1')))
+  return max(1, min(16, len(os.sched_getaffinity(0)) // max(world, 1)))
+
+
 def build_records(task, envs_per_gpu, rank, seed=666, robot='point'):
   """Layouts with the reference sampler semantics (native sampler, exact numpy-legacy stream):
   global env g is drawn with RandomState(seed + g) exactly as make(robot, task, seed + g)
@@ -80,7 +87,7 @@ def build_records(task, envs_per_gpu, rank, seed=666, robot='point'):
     tids = np.array([benchmark.TASKS[nm].TASK_ID for nm in names], np.int32)
   else:
     tids = benchmark.TASKS[task].TASK_ID
-  rf, ri, status = nat.sample_layouts(robot, seed + g0 + np.arange(envs_per_gpu, dtype=np.int64), tids, env_id0=g0)
+  rf, ri, status = nat.sample_layouts(robot, seed + g0 + np.arange(envs_per_gpu, dtype=np.int64), tids, env_id0=g0, nthreads=sampler_threads())
   assert not status.any(), 'layout sampling failed'
   return rf, ri
 
@@ -154,7 +161,10 @@ class DeviceRun:
 
 
 def timed(run, steps, warmup, barrier):
-  """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides."""
+  """W untimed steps, then EXACTLY K steps bracketed by barrier + device sync on both sides.  Returns THIS rank's time
+  from the opening barrier to the end of its own K steps (device synchronised): the clock stops BEFORE the closing
+  barrier, so that what the caller max-reduces over the ranks is the slowest rank's work, not that plus the latency of
+  a gloo barrier - 1 ms of it would read as a 5 % scaling loss on the driver's 18-ms timed window."""
   run.run(warmup)
   run.wait()
   if hasattr(run, 'busy_fraction'):
@@ -163,8 +173,9 @@ def timed(run, steps, warmup, barrier):
   t0 = time.perf_counter()
   run.run(steps)
   run.wait()
+  t1 = time.perf_counter()
   barrier()
-  return time.perf_counter() - t0
+  return t1 - t0
 
 
 _PROFILE = None
@@ -241,37 +252,39 @@ def roofline_block(alg_bytes, envs, kernel_ms, kernels, key=None, launches=None)
                   'kernel_ms': kernel_ms, 'launches_timed': launches, 'alg_bytes_per_unit': alg_bytes, 'units_per_launch': envs}, kernels)
 
 
-def cpu_baseline(task, seconds=12.0):
+def cpu_baseline(task, seconds=12.0, robot='point', n=4096, single_core=True):
   """The CPU oracle (oracle/sag_oracle.c, fp64, OpenMP over envs) on this host: same
   layouts, same counter-based actions/noise.  A reported baseline, not the target."""
   from oracle_lib import Oracle
   o = Oracle()
-  n = 4096
-  rf, ri = build_records(task, n, 0)
+  rid, nu, od = {'point': (0, 2, 60), 'car': (1, 2, 72), 'doggo': (2, 12, 104)}[robot]
+  rf, ri = build_records(task, n, 0, robot=robot)
   arr = o.make_batch(rf, ri)
-  acts = np.stack([[o.actions((666, 0), int(ri[i, 12]), s, 2) for i in range(n)] for s in range(4)])
+  acts = np.stack([[o.actions((666, 0), int(ri[i, 12]), s, nu) for i in range(n)] for s in range(4)])
   cores = min(len(os.sched_getaffinity(0)), 16)  # a 1-GPU box is given 16 host cores
   out = {}
-  for label, nt in (('1', 1), ('all', cores)):
-    o.step_batch(arr, 0, acts[0], key=(666, 0), nthreads=nt)  # warm
+  for label, nt in ((('1', 1),) if single_core else ()) + (('all', cores),):
+    o.step_batch(arr, rid, acts[0], key=(666, 0), nthreads=nt, obs_dim=od)  # warm
     t0 = time.perf_counter()
     done_steps = 0
-    budget = seconds * (0.35 if nt == 1 else 0.65)
+    budget = seconds * ((0.35 if nt == 1 else 0.65) if single_core else 1.0)
     while time.perf_counter() - t0 < budget:
-      o.step_batch(arr, 0, acts[done_steps % 4], key=(666, 0), nthreads=nt)
+      o.step_batch(arr, rid, acts[done_steps % 4], key=(666, 0), nthreads=nt, obs_dim=od)
       done_steps += 1
     dt = time.perf_counter() - t0
     out[label] = (n * done_steps / dt, done_steps, dt)
   v, k, dt = out['all']
-  return {
+  res = {
       'value': v,
       'unit': 'env-steps/s',
       'cores': cores,
       'kind': 'port',
-      'sample': f'point/{task}, {n} envs x {k} steps in {dt:.1f}s, oracle/sag_oracle.c fp64 -O2 OpenMP '
-                f'{cores} threads (1 thread: {out["1"][0]:.0f} env-steps/s); CPU restatement, not MuJoCo',
-      'single_core_value': out['1'][0],
+      'sample': f'{robot}/{task}, {n} envs x {k} steps in {dt:.1f}s, oracle/sag_oracle.c fp64 -O2 OpenMP {cores} threads'
+                + (f' (1 thread: {out["1"][0]:.0f} env-steps/s)' if single_core else '') + '; CPU restatement, not MuJoCo',
   }
+  if single_core:
+    res['single_core_value'] = out['1'][0]
+  return res
 
 
 def main(argv=None, run_factory=None, emit=print):
@@ -485,6 +498,10 @@ def main(argv=None, run_factory=None, emit=print):
                          'roofline': roofline_block(ALG_BYTES['car'], n_c3, ms, step_kernels('car', n_c3),
                                                     'car' if n_c3 >= ROBOT_LINE['car']['split_min'] else None, cnt)}
         r3.close()
+      if not args.no_cpu_baseline:   # the oracle on the same batch: a few seconds each
+        c3['cpu_baseline'] = cpu_baseline('push_box', 3.0, robot='car', single_core=False)
+        if 'c4_doggo_multitask' in res:
+          res['c4_doggo_multitask']['cpu_baseline'] = cpu_baseline('multitask', 5.0, robot='doggo', n=args.c4_envs, single_core=False)
       res['c3_car_push_box'] = c3
       # BASELINE config 5 (stretch): Doggo / haul_box with rgb_observation: step + 64x64x3 render per env
       r5 = DeviceRun('haul_box', 4096, device, 0, robot='doggo')

@@ -48,6 +48,15 @@ class OracleRun:
     json.dump({'rank': self.rank, 'ids': [int(self.ids[0]), int(self.ids[-1])], 'steps': self.t, 'tasks': self.tasks},
               open(os.path.join(%(out)r, 'rank%%d_%%s.json' %% (self.rank, self.robot)), 'w'))
 
+# a slow rendezvous: every barrier of rank 1 arrives 300 ms late.  The reported time is each rank's own K steps (clock
+# stopped BEFORE the closing barrier), max-reduced - the barrier's latency must not be in it (VERDICT r3 item 9).
+import torch.distributed as _dist
+_barrier = _dist.barrier
+def _late_barrier(*a, **k):
+  if int(os.environ['RANK']) == 1: time.sleep(0.3)
+  return _barrier(*a, **k)
+_dist.barrier = _late_barrier
+
 lines = []
 bench.main(['--gpus', '2', '--steps', '6', '--warmup', '2', '--burn-in', '1', '--envs', '48',
             '--no-cpu-baseline', '--no-c2', '--c4-envs', '12', '--c4-steps', '2'], run_factory=OracleRun, emit=lines.append)
@@ -84,6 +93,9 @@ def test_two_rank_gloo_bench(tmp_path):
   assert abs(res['value'] - 96 * 6 / (res['ms_per_step'] * 6e-3)) < 1e-6 * res['value']
   # the slow rank sleeps 2 ms per step: the max over ranks cannot be below that
   assert res['ms_per_step'] >= 2.0
+  # ... and the 300 ms by which rank 1 is late at every barrier are NOT in the 6-step window (they would be 50 ms per step;
+  # a step of the stand-in takes ~3 ms)
+  assert res['ms_per_step'] < 40.0, res['ms_per_step']
   for k in ('roofline', 'config', 'metric', 'unit', 'dtype', 'data'):
     assert k in res
   assert set(res['roofline']) >= {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'}
@@ -97,6 +109,7 @@ def test_two_rank_gloo_bench(tmp_path):
   assert c4['n_gpus'] == 2 and c4['envs_per_gpu'] == 12 and c4['global_envs'] == 24 and c4['scaling'] == 'weak'
   assert c4['env_id_ranges_per_rank'] == [[0, 12], [12, 24]] and len(c4['kernel_ms_per_rank']) == 2
   assert abs(c4['value'] - 24 * 2 / (c4['ms_per_step'] * 2e-3)) < 1e-6 * c4['value'] and c4['ms_per_step'] >= 2.0
+  assert c4['ms_per_step'] < 100.0, 'a 300-ms barrier inside the 2-step window would be 150 ms per step (the stand-in takes ~30)'
   d0 = json.loads((tmp_path / 'rank0_doggo.json').read_text())
   d1 = json.loads((tmp_path / 'rank1_doggo.json').read_text())
   assert d0['ids'] == [0, 11] and d1['ids'] == [12, 23] and d0['steps'] == d1['steps'] == 20 + 5 + 2
