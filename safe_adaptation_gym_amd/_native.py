@@ -217,6 +217,42 @@ def _ptr(a, ctype):
   return None if a is None else a.ctypes.data_as(C.POINTER(ctype))
 
 
+class DeviceArray:
+  """A view of device memory owned by a Context (the outputs of a device-resident env.step, BatchedSafeAdaptationGym
+  with device_buffers=True): pointer, shape, dtype, strides.  `__cuda_array_interface__` (version 2; HIP pointers are
+  what PyTorch-ROCm and CuPy-ROCm expect there) lets a learner wrap it without a copy - torch.as_tensor(a, device='cuda')
+  -; `numpy()` downloads.  The memory is written on the context's stream: read it after env.wait() (or step(sync=True))."""
+
+  def __init__(self, ctx, ptr, shape, dtype, strides=None, base=None):
+    self.ctx, self.ptr, self.shape, self.dtype, self.strides = ctx, int(ptr), tuple(shape), np.dtype(dtype), strides
+    self._base = base   # (ptr, shape) of the contiguous buffer a strided view lives in
+
+  @property
+  def __cuda_array_interface__(self):
+    return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (self.ptr, False), 'version': 2,
+            'strides': self.strides}
+
+  def numpy(self):
+    if self.strides is None:
+      return self.ctx.dev_download(C.c_void_p(self.ptr), self.shape, self.dtype)
+    bptr, bshape = self._base
+    full = self.ctx.dev_download(C.c_void_p(bptr), bshape, self.dtype)
+    off = (self.ptr - bptr) // self.dtype.itemsize
+    return np.lib.stride_tricks.as_strided(full.reshape(-1)[off:], self.shape, self.strides).copy()
+
+
+def device_pointer(x):
+  """Device pointer of a DeviceArray or of anything that exports __cuda_array_interface__ (a torch / cupy array on the GPU)."""
+  if isinstance(x, DeviceArray):
+    return x.ptr
+  cai = getattr(x, '__cuda_array_interface__', None)
+  if cai is None:
+    raise TypeError(f'{type(x).__name__}: not a device array')
+  if cai.get('strides') not in (None,) and tuple(cai['strides']) != tuple(np.zeros(cai['shape'], np.dtype(cai['typestr'])).strides):
+    raise ValueError('device actions must be contiguous')
+  return int(cai['data'][0])
+
+
 class Context:
   """One GPU shard: owns the SoA world of n_envs environments on `device`."""
 

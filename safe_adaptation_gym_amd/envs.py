@@ -51,7 +51,8 @@ class BatchedSafeAdaptationGym:
   BASE_SENSORS = ['accelerometer', 'velocimeter', 'gyro', 'magnetometer']
 
   def __init__(self, robot_base, n_envs=1, rgb_observation=False, config=None, devices=None,
-               parity_rng=False, device_seed=None, render_lidars_and_collision=False, render_options=None):
+               parity_rng=False, device_seed=None, render_lidars_and_collision=False, render_options=None,
+               device_buffers=False):
     # rgb_observation: the observation is the robot camera's 64 x 64 x 3 uint8 image
     # (safe_adaptation_gym.py:122-126,148-149), ray-cast on the device
     self._rgb_observation = bool(rgb_observation)
@@ -63,6 +64,11 @@ class BatchedSafeAdaptationGym:
     self.n_envs = int(n_envs)
     self.base_config = config
     self.parity_rng = bool(parity_rng)
+    # device_buffers: step() / reset() leave their results in HBM and return _native.DeviceArray views of them (see
+    # step()); actions may be device arrays too.  The reference's API, without the PCIe round trip per step.
+    self.device_buffers = bool(device_buffers)
+    if self.device_buffers and self.parity_rng:
+      raise ValueError('device_buffers: the reference-order host generators of parity_rng draw on the host every step')
     self.devices = [0] if devices is None else list(devices)
     if self.n_envs < len(self.devices):
       self.devices = self.devices[:self.n_envs]
@@ -76,6 +82,7 @@ class BatchedSafeAdaptationGym:
         for (s, e), d in zip(self._ranges, self.devices)
     ]
     self._pool = ThreadPoolExecutor(len(self._ctx)) if len(self._ctx) > 1 else None
+    self._dev = None   # device_buffers: per-shard output / action buffers, allocated on first use
     self._tasks = None
     self._episode = 0
     self._base_seed = int(np.random.randint(2**31))
@@ -162,9 +169,19 @@ class BatchedSafeAdaptationGym:
     self._build_world(first_episode=False)
     return self._observe()
 
-  def step(self, action):
+  def step(self, action, sync=True):
     """-> (obs [N, obs_dim] f32, reward [N] (or [N, 2]) f32, done [N] bool,
-    info {'cost': [N] f32, 'bound': [N] f32, 'goal_met': [N] bool})"""
+    info {'cost': [N] f32, 'bound': [N] f32, 'goal_met': [N] bool})
+
+    With device_buffers=True the step is enqueued with sag_step_device and the same tuple comes back as
+    _native.DeviceArray views of HBM (obs f32, reward f32, done / cost / goal_met uint8 flags; `bound` stays a host
+    array): no copy in either direction.  `action` may be a host array (uploaded) or a device array - a DeviceArray or
+    anything with __cuda_array_interface__, e.g. a torch tensor on the GPU - of shape [N, nu] float32 (one per shard, in
+    a list, when the batch is sharded over several `devices`; the results are then lists, one entry per shard).
+    sync=False returns as soon as the launches are enqueued on the contexts' streams: call env.wait() before the
+    results are read on another stream.  The views are overwritten by the next step."""
+    if self.device_buffers:
+      return self._step_device(action, sync)
     a = np.asarray(action, np.float32).reshape(self.n_envs, self.robot.nu)
     noise = tapes = None
     if self.parity_rng:
@@ -190,6 +207,62 @@ class BatchedSafeAdaptationGym:
     info = {'cost': cost, 'bound': self._bounds, 'goal_met': met}
     return obs, reward, done, info
 
+  # -- device-resident path (device_buffers=True) ---------------------------------------------------
+  def _dev_bufs(self):
+    if self._dev is None:
+      self._dev = []
+      od, nu = self.robot.obs_dim, self.robot.nu
+      for c, (s, e) in zip(self._ctx, self._ranges):
+        n = e - s
+        b = {'act': c.dev_alloc(n * nu * 4), 'obs': c.dev_alloc(n * od * 4), 'rew': c.dev_alloc(n * 2 * 4),
+             'cost': c.dev_alloc(n), 'done': c.dev_alloc(n), 'met': c.dev_alloc(n)}
+        if self._rgb_observation:
+          b['img'] = c.dev_alloc(n * 64 * 64 * 3)
+        self._dev.append(b)
+    return self._dev
+
+  def _views(self, k):
+    c, (s, e), b = self._ctx[k], self._ranges[k], self._dev[k]
+    n = e - s
+    A = nat.DeviceArray
+    if self._rgb_observation:
+      obs = A(c, b['img'].value, (n, 64, 64, 3), np.uint8)
+    else:
+      obs = A(c, b['obs'].value, (n, self.robot.obs_dim), np.float32)
+    rew = (A(c, b['rew'].value, (n, 2), np.float32) if self._reward_dim == 2 else
+           A(c, b['rew'].value, (n,), np.float32, strides=(8,), base=(b['rew'].value, (n, 2))))
+    return obs, rew, A(c, b['done'].value, (n,), np.uint8), A(c, b['cost'].value, (n,), np.uint8), A(c, b['met'].value, (n,), np.uint8)
+
+  def _step_device(self, action, sync):
+    bufs = self._dev_bufs()
+    acts = action if isinstance(action, (list, tuple)) and len(self._ctx) > 1 else [action]
+    if len(acts) != len(self._ctx):
+      if len(acts) == 1 and not hasattr(acts[0], '__cuda_array_interface__') and not isinstance(acts[0], nat.DeviceArray):
+        a = np.asarray(acts[0], np.float32).reshape(self.n_envs, self.robot.nu)
+        acts = [a[s:e] for s, e in self._ranges]
+      else:
+        raise ValueError(f'{len(self._ctx)} shards: pass one device action array per shard')
+    for c, b, a in zip(self._ctx, bufs, acts):
+      if isinstance(a, nat.DeviceArray) or hasattr(a, '__cuda_array_interface__'):
+        d_act = nat.C.c_void_p(nat.device_pointer(a))
+      else:
+        c.dev_upload(b['act'], np.ascontiguousarray(a, np.float32))
+        d_act = b['act']
+      c.step_device(d_act, None, -1, b['obs'], b['rew'], b['cost'], b['done'], b['met'])
+      if self._rgb_observation:
+        c.render_rgb_device(b['img'])
+    if sync:
+      self.wait()
+    outs = [self._views(k) for k in range(len(self._ctx))]
+    one = len(outs) == 1
+    pick = (lambda j: outs[0][j]) if one else (lambda j: [o[j] for o in outs])
+    return pick(0), pick(1), pick(2), {'cost': pick(3), 'bound': self._bounds, 'goal_met': pick(4)}
+
+  def wait(self):
+    """Joins the contexts' streams (after step(sync=False))."""
+    for c in self._ctx:
+      c.wait()
+
   def _render_rgb(self):
     return np.concatenate(self._map(lambda c, s, e: c.render_rgb()))
 
@@ -206,6 +279,10 @@ class BatchedSafeAdaptationGym:
     return np.concatenate(self._map(lambda c, s, e: c.render(cam, w, h, overlays=self._render_lidars_and_collision)))
 
   def close(self):
+    for c, b in zip(self._ctx, self._dev or []):
+      for p in b.values():
+        c.dev_free(p)
+    self._dev = None
     for c in self._ctx:
       c.close()
     if self._pool:
@@ -276,6 +353,16 @@ class BatchedSafeAdaptationGym:
     }
 
   def _observe(self):
+    if self.device_buffers:   # reset is the cold path: the observation is formed as usual and parked in the obs buffer
+      bufs = self._dev_bufs()
+      for c, b in zip(self._ctx, bufs):
+        if self._rgb_observation:
+          c.render_rgb_device(b['img'])
+        else:
+          c.dev_upload(b['obs'], c.observe())
+      self.wait()
+      outs = [self._views(k)[0] for k in range(len(self._ctx))]
+      return outs[0] if len(outs) == 1 else outs
     if self._rgb_observation:
       return self._render_rgb()
     return np.concatenate(self._map(lambda c, s, e: c.observe()))

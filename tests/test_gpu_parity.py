@@ -853,6 +853,68 @@ def test_split_launch_equals_single_launch(nat, monkeypatch, robot, task):
     c.close()
 
 
+def test_device_buffers_env_api(nat):
+  """make(..., device_buffers=True) - the reference's make / reset / step surface with the results left
+  in HBM (DeviceArray views, __cuda_array_interface__) and actions taken from HBM: the same numbers as the NumPy path
+  bit for bit, sharded or not, and a step costs what its kernels cost (no PCIe round trip, no host synchronisation)."""
+  import time
+  import safe_adaptation_gym_amd as sag
+  n = 4096
+  host = sag.make('point', 'go_to_goal', seed=3, n_envs=n)
+  dev = sag.make('point', 'go_to_goal', seed=3, n_envs=n, device_buffers=True)
+  # (the host emulation of the device sources runs one kernel at a time: no shard threads there)
+  sh = sag.make('point', 'go_to_goal', seed=3, n_envs=n, device_buffers=True, devices=[0] if os.environ.get('SAG_HOSTEMU') else [0, 0, 0])
+  o_h, o_d, o_s = host.reset(), dev.reset(), sh.reset()
+  if not isinstance(o_s, list):
+    o_s = [o_s]
+  assert isinstance(o_d, nat.DeviceArray) and o_d.shape == (n, 60) and o_d.__cuda_array_interface__['data'][0] == o_d.ptr
+  np.testing.assert_array_equal(o_h, o_d.numpy())
+  np.testing.assert_array_equal(o_h, np.concatenate([x.numpy() for x in o_s]))
+  rng = np.random.RandomState(0)
+  c = dev._ctx[0]
+  d_act = c.dev_alloc(n * 2 * 4)
+  for t in range(12):
+    a = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    h = host.step(a)
+    if t % 2:   # actions from HBM (what a policy on the GPU hands over) ...
+      c.dev_upload(d_act, a)
+      d = dev.step(nat.DeviceArray(c, d_act.value, (n, 2), np.float32))
+    else:       # ... or from the host
+      d = dev.step(a)
+    s = sh.step(a)
+    if not isinstance(s[0], list):
+      s = ([s[0]], [s[1]], [s[2]], {k: ([v] if k != 'bound' else v) for k, v in s[3].items()})
+    for key, hv, dv, sv in [('obs', h[0], d[0], s[0]), ('reward', h[1], d[1], s[1]), ('done', h[2], d[2], s[2]),
+                            ('cost', h[3]['cost'], d[3]['cost'], s[3]['cost']), ('goal_met', h[3]['goal_met'], d[3]['goal_met'], s[3]['goal_met'])]:
+      np.testing.assert_array_equal(hv.astype(np.float32), dv.numpy().astype(np.float32), err_msg=f'{key} step {t}')
+      np.testing.assert_array_equal(hv.astype(np.float32), np.concatenate([x.numpy() for x in sv]).astype(np.float32), err_msg=f'{key} (shards) step {t}')
+    assert d[1].shape == (n,) and d[1].strides == (8,) and d[3]['bound'].shape == (n,)
+  # a step through the reference's API costs what its kernels cost
+  act = nat.DeviceArray(c, d_act.value, (n, 2), np.float32)
+  for _ in range(50):
+    dev.step(act, sync=False)
+  dev.wait()
+  c.enable_timing(True); c.kernel_time_ms(reset=True)
+  K = 400
+  t0 = time.perf_counter()
+  for _ in range(K):
+    dev.step(act, sync=False)
+  dev.wait()
+  wall_ms = (time.perf_counter() - t0) / K * 1e3
+  kernel_ms = c.kernel_time_ms(reset=True)[0]
+  c.enable_timing(False)
+  t0 = time.perf_counter()
+  for _ in range(100):
+    host.step(a)
+  host_ms = (time.perf_counter() - t0) / 100 * 1e3
+  print(f'env.step at {n} envs: device buffers {wall_ms:.4f} ms per step (kernels {kernel_ms:.4f} ms), NumPy path {host_ms:.4f} ms')
+  if not os.environ.get('SAG_HOSTEMU'):
+    assert wall_ms <= 1.2 * kernel_ms + 0.005, f'{wall_ms:.4f} ms per step against {kernel_ms:.4f} ms of kernels'
+  c.dev_free(d_act)
+  for e in (host, dev, sh):
+    e.close()
+
+
 def test_car_env_api(nat):
   """BASELINE config 3 through the front end: Car / push_box, obs 72 (48 lidar + 12 + 3 + 9)."""
   import safe_adaptation_gym_amd as sag
