@@ -756,6 +756,13 @@ namespace sag {
 #define LP(base, k) lds[((base) + (k)) * WAVE + lane]
 #define POOL(d, c) lds[(LS_POOL + (d) * 6 + (c)) * WAVE + lane]
 #define STG(j) lds[STG_BASE + lane * STG_STRIDE + (j)]  // STG_STRIDE: constexpr of the enclosing kernel
+// The 16 lidar bins of a chunk accumulate in a [bin][lane] tile over the same region (the bank is the lane: the
+// data-dependent bin of an atomic never conflicts; the [lane][17] rows did - SQ_LDS_BANK_CONFLICT was 1.4 x
+// SQ_ACTIVE_INST_LDS in k_step_quiet<0>, round 3).  SAG_LIDAR_TILE=0: the row layout (A/B).
+#ifndef SAG_LIDAR_TILE
+#define SAG_LIDAR_TILE 1
+#endif
+#define TILE(b) lds[STG_BASE + (b) * WAVE + lane]
 
 // tstate bits 17..27: body k has non-zero velocity or may overlap something (derived at
 // install); lets the kernel skip the loads, pair tests and write-back of sleeping bodies.
@@ -879,10 +886,17 @@ __device__ inline void lidar_point(float* lds, int lane, float rxf, float ryf, f
   const int bp = (bin + 1) & 15, bm = (bin + 15) & 15;
   // closeness values are >= +0, so their bit patterns order like the floats: LDS integer
   // atomic max (ds_max_i32, no return value) replaces read-max-write and its round trips
+#if SAG_LIDAR_TILE
+  int* o = reinterpret_cast<int*>(&TILE(0));
+  atomicMax(o + bin * WAVE, __float_as_int(sensor));
+  atomicMax(o + bp * WAVE, __float_as_int(alias * sensor));
+  atomicMax(o + bm * WAVE, __float_as_int((1.0f - alias) * sensor));
+#else
   int* o = reinterpret_cast<int*>(&STG(0));
   atomicMax(o + bin, __float_as_int(sensor));
   atomicMax(o + bp, __float_as_int(alias * sensor));
   atomicMax(o + bm, __float_as_int((1.0f - alias) * sensor));
+#endif
 }
 
 #ifndef SAG_STEP_MIN_WAVES
@@ -916,10 +930,17 @@ __device__ inline void lidar_point_tilted(float* lds, int lane, const double* po
   const double Dd = hypot(EX, EY);
   const float sensor = (float)((5.0 - Dd > 0 ? 5.0 - Dd : 0.0) / 5.0);
   const int bp = (bin + 1) & 15, bm = (bin + 15) & 15;
+#if SAG_LIDAR_TILE
+  int* o = reinterpret_cast<int*>(&TILE(0));
+  atomicMax(o + bin * WAVE, __float_as_int(sensor));
+  atomicMax(o + bp * WAVE, __float_as_int(alias * sensor));
+  atomicMax(o + bm * WAVE, __float_as_int((1.0f - alias) * sensor));
+#else
   int* o = reinterpret_cast<int*>(&STG(0));
   atomicMax(o + bin, __float_as_int(sensor));
   atomicMax(o + bp, __float_as_int(alias * sensor));
   atomicMax(o + bm, __float_as_int((1.0f - alias) * sensor));
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -2119,7 +2140,13 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     for (int chunk = 0; chunk < NCHUNK; chunk++) {
       if (chunk < 3) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) STG(k) = 0.0f;
+        for (int k = 0; k < 16; k++) {
+#if SAG_LIDAR_TILE
+          TILE(k) = 0.0f;
+#else
+          STG(k) = 0.0f;
+#endif
+        }
       }
       if (chunk == 0 && !ABL(ABL_NO_LIDAR)) {
 #pragma unroll 1
@@ -2181,15 +2208,21 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
           const int env = nq == 4 ? e >> 2 : (nq == 3 ? (int)(((uint32_t)e * 21846u) >> 16) : (nq == 6 ? (int)(((uint32_t)e * 10923u) >> 16)
                                                                                                     : (int)(((uint32_t)e * 9363u) >> 16)));
           const int c4 = e - env * nq;   // e / nq exact for e < 64 nq (nq = 3, 4, 6, 7)
-          const float* t = lds + STG_BASE + env * STG_STRIDE + 4 * c4;
-          const float4 v = make_float4(t[0], t[1], t[2], t[3]);
+          float4 v;
+          if (SAG_LIDAR_TILE && chunk < 3) {   // [bin][lane] tile: the env's four bins of this quarter are WAVE floats apart
+            const float* t = lds + STG_BASE + (4 * c4) * WAVE + env;
+            v = make_float4(t[0], t[WAVE], t[2 * WAVE], t[3 * WAVE]);
+          } else {
+            const float* t = lds + STG_BASE + env * STG_STRIDE + 4 * c4;
+            v = make_float4(t[0], t[1], t[2], t[3]);
+          }
           if (row_ok(env) && !ABL(ABL_NO_OBS_STORE)) o4[row_of(env) * Q + q0 + c4] = v;
         }
       } else if (chunk < 3) {
 #pragma unroll 4
         for (int j = 0; j < 16; j++) {
           const int e = j * WAVE + lane, env = e >> 4, col = e & 15;
-          const float v = lds[STG_BASE + env * STG_STRIDE + col];
+          const float v = SAG_LIDAR_TILE ? lds[STG_BASE + col * WAVE + env] : lds[STG_BASE + env * STG_STRIDE + col];
           if (row_ok(env) && !ABL(ABL_NO_OBS_STORE)) o[row_of(env) * OBS_DIM + chunk * 16 + col] = v;
         }
       } else {

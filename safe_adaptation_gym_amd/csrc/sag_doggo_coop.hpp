@@ -871,20 +871,21 @@ __device__ __attribute__((noinline)) void dc_pgs_wide(const int e, const int lan
   const float ninv = okA ? -inv : 0.f, c1 = okA ? 1.f - reg * inv : 1.f, c0 = okA ? aref * inv : 0.f;
   const float mu_eff = isfric ? mu : 0.f, hi0 = isfric ? 0.f : 3.0e38f;
   const int nrows_u = __builtin_amdgcn_readfirstlane(nrows);
+  int uu = lane, pp = parent;
 #pragma unroll 1
-  for (int it = 0; it < iters; it++)
+  for (int it = 0; it < iters; it++) {
+    DC_OPAQUE(uu); DC_OPAQUE(pp);
 #pragma unroll
     for (int r = 0; r < DC_ROWS; r++)
       if (r < nrows_u) {
-        int uu = lane, pp = parent;
-        DC_OPAQUE(uu); DC_OPAQUE(pp);
-        const float hi = fmaf(mu_eff, fmaxf(fn_contact, 0.f), hi0);   // (the running sum of increments may end a hair below zero when the normal force clamps to 0: the bound must not turn negative)
+        const float hi = fmaf(mu_eff, __builtin_amdgcn_fmed3f(fn_contact, 0.f, 3.0e38f), hi0);   // (as in dc_pgs_fast)
         const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
         const float df = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fc - f), r));
         acc = fmaf(Ar[r], df, acc);
         f = uu == r ? fc : f;
         fn_contact += pp == r ? df : 0.f;
       }
+  }
   if (mine) E.rF[lane] = (double)f;
 }
 
@@ -940,14 +941,16 @@ __device__ __attribute__((noinline)) void dc_pgs_fast(const int hf, const int u,
   const float ninv = okA ? -inv : 0.f, c1 = okA ? 1.f - reg * inv : 1.f, c0 = okA ? aref * inv : 0.f;
   const float mu_eff = isfric ? mu : 0.f, hi0 = isfric ? 0.f : 3.0e38f;   // bounds: [-mu fn, mu fn] / [0, inf)
   const int nmax_u = __builtin_amdgcn_readfirstlane(npass);              // (uniform: the row tests are scalar branches)
+  int uu = u, pp = parent;
 #pragma unroll 1
-  for (int it = 0; it < iters; it++)
+  for (int it = 0; it < iters; it++) {
+    DC_OPAQUE(uu); DC_OPAQUE(pp);   // (once per sweep, in place: keeps the row's two compares inside the sweep loop without a copy per row)
 #pragma unroll
     for (int r = 0; r < DC_PGS_LANES; r++)   // unrolled: lane index and register index of the row are constants
       if (r < nmax_u) {
-        int uu = u, pp = parent;
-        DC_OPAQUE(uu); DC_OPAQUE(pp);   // (keeps the two compares below inside the loop)
-        const float hi = fmaf(mu_eff, fmaxf(fn_contact, 0.f), hi0);   // (the running sum of increments may end a hair below zero when the normal force clamps to 0: the bound must not turn negative)
+        // (the running sum of increments may end a hair below zero when the normal force clamps to 0: the bound must not
+        //  turn negative; med3 instead of fmaxf: one instruction, no canonicalising copy in front of it)
+        const float hi = fmaf(mu_eff, __builtin_amdgcn_fmed3f(fn_contact, 0.f, 3.0e38f), hi0);
         const float fc = __builtin_amdgcn_fmed3f(fmaf(ninv, acc, fmaf(c1, f, c0)), isfric ? -hi : 0.f, hi);
         const float df = dc_bcastf(fc - f, r, half);
         acc = fmaf(Ar[r], df, acc);
@@ -955,6 +958,7 @@ __device__ __attribute__((noinline)) void dc_pgs_fast(const int hf, const int u,
         // a friction row tracks its contact's normal force by the same increments
         fn_contact += pp == r ? df : 0.f;
       }
+  }
   if (mine) E.rF[u] = (double)f;
 }
 
