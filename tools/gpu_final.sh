@@ -1,12 +1,12 @@
 #!/bin/bash
 # round-end measurement (run on the GPU box from the repo root, one gpurun call each for the two halves if time is short):
-#   1. the parity suite;  2. FULL profile of the default bench.py (kernel trace + PMC passes) -> profiles/r03_all_summary.txt
+#   1. the parity suite;  2. FULL profile of the default bench.py (kernel trace + PMC passes) -> profiles/r04_all_summary.txt
 #   + profiles/kernels.json;  3. steady-state traffic passes of the headline and the Car config -> profiles/traffic.json;
 #   4. the default bench line, now checked against 2.
 # STAGE=1: steps 1-2 and the headline's traffic; STAGE=2: the Car's traffic and step 4 (copy gpurun_out/${R}_kernels.json and
 # gpurun_out/traffic_${R}.json of stage 1 into profiles/ first: a gpurun call has 20 minutes and only gpurun_out/ comes back).
 export PYTHONPATH=$PWD:$PWD/tests
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 if [ "${STAGE:-1}" != 2 ]; then
 if [ -z "$SKIP_TESTS" ]; then
   timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${R}_gputest_final.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/${R}_gputest_final.log
