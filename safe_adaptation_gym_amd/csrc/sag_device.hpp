@@ -613,69 +613,6 @@ __device__ inline int collide_list_nb(BV& A, float ca, float sa, BV& B, int shB,
 #if defined(SAG_ABL_CL) && SAG_ABL_CL == 1   // timing-only: the bounding-circle pass alone
   mask = 0;
 #endif
-#ifdef SAG_CL_QUEUE   // (-DSAG_CL_QUEUE: contacts queued per lane and solved in one loop; bit-identical results, measured SLOWER: 3.04 vs 2.40 ms per Car step at 4 M envs)
-  if constexpr (SHA == SH_CAR) {
-    // Per lane over ITS circle hits, in the specification's pair order: box pairs an axis separates drop out
-    // (boxes_separated); the others QUEUE their contacts - one item per inside vertex, [pair:6][box pair:1][dir:1]
-    // [vertex:2], six to a 64-bit word - and the queue is solved afterwards in one loop.  Solved pair by pair, a
-    // wavefront ran the vertex tests and both solve loops once per pair index ANY lane still had (~8 a substep for
-    // a car pushing the 5-geom box, most lanes idle in each); now it runs the solve max-contacts-of-a-lane times
-    // (3 - 5).  Insideness depends on positions only, which the contact solves (accelerations) do not change.
-    constexpr int ITEM_BITS = 10, PER_WORD = 6, CAP = 2 * PER_WORD;
-    uint64_t q0 = 0, q1 = 0;
-    int cnt = 0;
-    auto pair_geoms = [&](int pbit, Geom& a, Geom& b, float& ax, float& ay, float& qx, float& qy) {
-      a = shape_geom(SHA, pbit >> 3, vsz, rstatic);
-      b = shape_geom(shB, NB > 1 ? pbit & 7 : 0, vsz, rstatic);
-      ax = A.x + ca * a.ox - sa * a.oy; ay = A.y + sa * a.ox + ca * a.oy;
-      qx = B.x + cb * b.ox - sb * b.oy; qy = B.y + sb * b.ox + cb * b.oy;
-    };
-    auto push = [&](uint32_t item) {
-      const bool lo = cnt < PER_WORD;
-      const uint64_t v = (uint64_t)item << (ITEM_BITS * (lo ? cnt : cnt - PER_WORD));
-      q0 |= lo ? v : 0ull; q1 |= lo ? 0ull : v;
-      cnt++;
-    };
-    auto drain = [&]() {
-      for (int it = 0; it < cnt; it++) {
-        const uint32_t item = (uint32_t)((it < PER_WORD ? q0 >> (ITEM_BITS * it) : q1 >> (ITEM_BITS * (it - PER_WORD))) & 1023ull);
-        Geom a, b; float ax, ay, qx, qy;
-        pair_geoms((int)(item & 63u), a, b, ax, ay, qx, qy);
-        if (item >> 6 & 1u) {
-          const int k = (int)(item >> 8 & 3u);
-          if (item >> 7 & 1u) vert_contact(A, B, k, qx, qy, cb, sb, b.a, b.b, ax, ay, ca, sa, a.a, a.b, true, sol);
-          else vert_contact(A, B, k, ax, ay, ca, sa, a.a, a.b, qx, qy, cb, sb, b.a, b.b, false, sol);
-          n++;
-        } else if (!a.box && !b.box) n += cc_contact(A, B, ax, ay, a.a, qx, qy, b.a, sol);
-        else if (!a.box) n += cb_contact(A, B, ax, ay, a.a, qx, qy, cb, sb, b.a, b.b, true, sol);
-        else n += cb_contact(B, A, qx, qy, b.a, ax, ay, ca, sa, a.a, a.b, false, sol);
-      }
-      q0 = 0; q1 = 0; cnt = 0;
-    };
-    for (mask_t mm = mask; mm; mm &= mm - 1) {
-      const int pbit = __ffsll((unsigned long long)mm) - 1;
-      Geom a, b; float ax, ay, qx, qy;
-      pair_geoms(pbit, a, b, ax, ay, qx, qy);
-      if (a.box && b.box) {
-        if (boxes_separated(ax, ay, ca, sa, a.a, a.b, qx, qy, cb, sb, b.a, b.b)) continue;
-        const uint32_t in_ab = verts_inside_mask(ax, ay, ca, sa, a.a, a.b, qx, qy, cb, sb, b.a, b.b);   // A's vertices in B
-        const uint32_t in_ba = verts_inside_mask(qx, qy, cb, sb, b.a, b.b, ax, ay, ca, sa, a.a, a.b);   // B's in A
-        if (cnt + __popc(in_ab) + __popc(in_ba) > CAP) drain();   // (a lane's own decision; never in practice)
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (in_ab >> k & 1u) push((uint32_t)pbit | 64u | (uint32_t)k << 8);
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          if (in_ba >> k & 1u) push((uint32_t)pbit | 64u | 128u | (uint32_t)k << 8);
-      } else {
-        if (cnt + 1 > CAP) drain();
-        push((uint32_t)pbit);
-      }
-    }
-    drain();
-    return n;
-  }
-#endif
   while (mask) {
     const int pbit = (NA > 4 ? __ffsll((unsigned long long)mask) : __ffs((unsigned int)mask)) - 1;
     mask &= mask - 1;
