@@ -1058,6 +1058,75 @@ def test_doggo_capsule_and_cylinder_contacts_on_device(nat, oracle):
   ctx.close()
 
 
+def test_doggo_random_contact_geometry_on_device(nat, oracle):
+  """The capsule / cylinder narrowphase on configurations no rollout visits: 2048 worlds of the multitask mix, the robot
+  in a random pose (height .12 - .30, tilted up to .5 rad, every joint anywhere inside its range) and the world's vases,
+  pillars, buttons and task object scattered over the metre around it, at any yaw - shafts against corners, cylinders
+  against faces, axes through boxes.  One forward evaluation (a step without substeps) on the device and in the oracle
+  from the same state: cost flags equal except where a penetration changes sign with the rounding (counted; the planar
+  narrowphase is fp32 on the device, fp64 in the oracle), accelerometer and touch within the solver's tolerance on the
+  envs whose rows fit the device's budget (the others are flagged, bit 2 of SAG_I_FLAGS, and counted)."""
+  from safe_adaptation_gym_amd import benchmark
+  n = 256 if os.environ.get('SAG_HOSTEMU') else 2048
+  names = [nm for nm, _ in benchmark.make('multitask', batch_size=n, seed=77).train_tasks]
+  rf, ri = bu.sample_records_native('doggo', names, n, seed=77)
+  rng = np.random.RandomState(3)
+  E = 144
+  lo = np.radians([-10, -75, -75, -10, -75, -75, -30, -10, 0, -75, -10, 0, -75])
+  hi = np.radians([30, 15, 0, 30, 15, 0, 30, 30, 135, 0, 30, 135, 0])
+  for e in range(n):
+    yaw, tilt, ax = rng.uniform(0, 2 * np.pi), rng.uniform(0, 0.5), rng.uniform(0, 2 * np.pi)
+    qy = np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)])
+    qt = np.array([np.cos(tilt / 2), np.sin(tilt / 2) * np.cos(ax), np.sin(tilt / 2) * np.sin(ax), 0])
+    w0, x0, y0, z0 = qy; w1, x1, y1, z1 = qt
+    q = np.array([w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1, w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1,
+                  w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1, w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1])
+    rf[e, 2] = yaw
+    rf[e, E] = rng.uniform(0.12, 0.30)
+    rf[e, E + 1:E + 5] = q
+    rf[e, E + 5:E + 9] = 0
+    rf[e, E + 9:E + 22] = rng.uniform(lo, hi)
+    rf[e, E + 22:E + 35] = 0
+    base = rf[e, 0:2]
+
+    def near(rmax):
+      a, r = rng.uniform(0, 2 * np.pi), rmax * np.sqrt(rng.uniform(0.0, 1.0))   # uniform over the disc
+      return base + r * np.array([np.cos(a), np.sin(a)])
+    for k in range(ri[e, 2]):
+      rf[e, 81 + 6 * k:81 + 6 * k + 2] = near(1.0); rf[e, 81 + 6 * k + 2] = rng.uniform(0, 2 * np.pi); rf[e, 81 + 6 * k + 3:81 + 6 * k + 6] = 0
+    for k in range(ri[e, 3]):
+      rf[e, 65 + 2 * k:67 + 2 * k] = near(1.2)
+    for k in range(ri[e, 4]):
+      rf[e, 69 + 2 * k:71 + 2 * k] = near(1.0)
+    if ri[e, 5]:
+      rf[e, 41:43] = near(1.0); rf[e, 43] = rng.uniform(0, 2 * np.pi); rf[e, 44:47] = 0
+  ctx = nat.Context('doggo', n, seed=9)
+  ctx.set_layout(rf, ri)
+  ctx.set_state(rf, ri)
+  s_rf, s_ri = ctx.get_state()
+  arr = oracle.make_batch(s_rf, s_ri)
+  zero = np.zeros((n, 12), np.float32)
+  tape = np.zeros((n, 64), np.uint32)
+  oracle.lib.sago_set_threads(os.cpu_count() or 1)
+  d_obs, _, d_cost, d_done, _, _ = ctx.step(zero, zero, tape, nstep=0)
+  o_obs, _, o_cost, o_done, _, _, _ = oracle.step_batch_full(arr, 2, zero, zero, tape, obs_dim=104, nstep=0)
+  oracle.lib.sago_set_threads(1)
+  overflow = (ctx.get_state()[1][:, 13] & 4) != 0
+  ok = ~overflow
+  flag_mism = int((d_cost[ok] != o_cost[ok]).sum())
+  acc_bad = (np.abs(d_obs[:, 48:51] - o_obs[:, 48:51]) > 0.05 + 0.02 * np.abs(o_obs[:, 48:51])).any(1) & ok
+  touch_bad = (np.abs(d_obs[:, 60:68] - o_obs[:, 60:68]) > 0.01 + 0.02 * np.abs(o_obs[:, 60:68])).any(1) & ok
+  _log_lockstep(f'doggo/random contact geometry: {n} states, one forward evaluation | cost rate device {d_cost.mean():.3f} oracle {o_cost.mean():.3f} | '
+                f'flags differing {flag_mism} | accelerometer outside 2 % {int(acc_bad.sum())}, touch outside 2 % {int(touch_bad.sum())} | '
+                f'states beyond the row budget (flagged, not compared) {int(overflow.sum())}')
+  assert 0.2 < o_cost.mean() < 0.9, 'the scatter should produce both touching and free robots'
+  np.testing.assert_array_equal(d_done, o_done)
+  assert flag_mism <= max(2, int(0.003 * n)), f'{flag_mism} cost flags differ'
+  assert acc_bad.sum() <= max(2, int(0.01 * n)) and touch_bad.sum() <= max(2, int(0.01 * n))
+  assert overflow.mean() < 0.25
+  ctx.close()
+
+
 def test_doggo_env_api(nat):
   """make('doggo', ...): obs 104, 12 actions; zero action lets the robot settle on its feet."""
   import safe_adaptation_gym_amd as sag
