@@ -235,15 +235,18 @@ class BatchedSafeAdaptationGym:
 
   def _step_device(self, action, sync):
     bufs = self._dev_bufs()
-    acts = action if isinstance(action, (list, tuple)) and len(self._ctx) > 1 else [action]
-    if len(acts) != len(self._ctx):
-      if len(acts) == 1 and not hasattr(acts[0], '__cuda_array_interface__') and not isinstance(acts[0], nat.DeviceArray):
-        a = np.asarray(acts[0], np.float32).reshape(self.n_envs, self.robot.nu)
-        acts = [a[s:e] for s, e in self._ranges]
-      else:
+    on_device = lambda x: isinstance(x, nat.DeviceArray) or hasattr(x, '__cuda_array_interface__')   # noqa: E731
+    if isinstance(action, (list, tuple)) and len(action) == len(self._ctx) and all(on_device(x) for x in action):
+      acts = list(action)          # one device array per shard
+    elif on_device(action):
+      if len(self._ctx) != 1:
         raise ValueError(f'{len(self._ctx)} shards: pass one device action array per shard')
+      acts = [action]
+    else:                          # host actions for the whole batch: split over the shards
+      a = np.asarray(action, np.float32).reshape(self.n_envs, self.robot.nu)
+      acts = [a[s:e] for s, e in self._ranges]
     for c, b, a in zip(self._ctx, bufs, acts):
-      if isinstance(a, nat.DeviceArray) or hasattr(a, '__cuda_array_interface__'):
+      if on_device(a):
         d_act = nat.C.c_void_p(nat.device_pointer(a))
       else:
         c.dev_upload(b['act'], np.ascontiguousarray(a, np.float32))
