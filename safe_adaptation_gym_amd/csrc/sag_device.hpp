@@ -660,6 +660,17 @@ constexpr int DPOOL = 3;
 enum { LS_X = 0, LS_Y = NBODY, LS_YAW = 2 * NBODY, LS_POOL = 3 * NBODY };
 constexpr int LDS_SLOTS = LS_POOL + 6 * DPOOL;
 constexpr int LDS_FLOATS = LDS_SLOTS * WAVE;
+// Car, kernels with contact code (BUSY / ALL): values that live across the contact phases of a substep but are touched
+// once or twice in it - the friction solve's warm-start forces and its share of the base acceleration, the spin
+// accelerations, the rear ball's quaternion - are parked in [slot][lane] LDS slots behind the body slots instead of
+// holding registers the pair walk needs (that instance spilled 73 VGPRs = 256 B of scratch per lane, and 2048 resident
+// wavefronts x 64 x 256 B is more than the chip's L2: the spills went to HBM).  SAG_CAR_PARK=0: in registers (A/B).
+#ifndef SAG_CAR_PARK
+#define SAG_CAR_PARK 1
+#endif
+constexpr int CAR_PARK_SLOTS = SAG_CAR_PARK ? 23 : 0;
+enum { CP_FL = 0, CP_F0 = 5, CP_PX = 8, CP_EACC = 11, CP_Q = 16, CP_TAIL = 20 };
+#define CPK(j) lds[(LDS_SLOTS + (j)) * WAVE + lane]
 constexpr int STG_BASE = LS_YAW * WAVE;
 
 // timing-only ablations (tools/ablate.py): -DSAG_ABLATE=<mask>; results are wrong by design
@@ -978,6 +989,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   static_assert(!DOGGO || MODE == MODE_ALL || MODE == MODE_POST, "Doggo runs the single-launch form");
   static_assert(DOGGO || MODE != MODE_POST, "MODE_POST is the Doggo post kernel");
   constexpr bool QUIET = MODE == MODE_QUIET;
+  constexpr bool PARK = CAR && !QUIET && CAR_PARK_SLOTS > 0;   // (CPK slots above)
   constexpr int SH_ME = CAR ? SH_CAR : SH_ROBOT;
   constexpr int OBS_DIM = DOGGO ? 104 : (CAR ? 72 : 60);
   // sensor columns per staged chunk: Doggo's 56 go out as two chunks of 28
@@ -1034,6 +1046,10 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     ext_tail = G4(DG_EXT + 2);
     ext[0] = e0.x; ext[1] = e0.y; ext[2] = e0.z; ext[3] = e0.w; ext[4] = e1.x; ext[5] = e1.y; ext[6] = e1.z; ext[7] = e1.w;
     ext[8] = ext_tail.x;
+    if constexpr (PARK) {   // the quaternion and the three pass-through floats of its group leave the registers until they are needed
+      CPK(CP_Q) = ext[5]; CPK(CP_Q + 1) = ext[6]; CPK(CP_Q + 2) = ext[7]; CPK(CP_Q + 3) = ext[8];
+      CPK(CP_TAIL) = ext_tail.y; CPK(CP_TAIL + 1) = ext_tail.z; CPK(CP_TAIL + 2) = ext_tail.w;
+    }
   }
   float goalx = gB.z, goaly = gB.w;
   float last0 = gC.x;
@@ -1294,7 +1310,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     const float rL = -bc * (vby - 0.13f * R.w + CRW * ext[0]), rT = -bc * (vbx - 0.1f * R.w), rR = -bc * (vby + 0.13f * R.w + CRW * ext[1]);
     const float rX = -bc * (vbx + 0.1f * R.w - CRW * ext[3]), rY = -bc * (vby + CRW * ext[2]);
     const float cL = rL - CRW * qL, cR = rR - CRW * qR, cX = rX - CRW * qX, cY = rY - CRW * qY;
-    float fL = car_fL, fT = car_fT, fR = car_fR, fX = car_fX, fY = car_fY;
+    float fL, fT, fR, fX, fY;
+    if constexpr (PARK) { fL = CPK(CP_FL); fT = CPK(CP_FL + 1); fR = CPK(CP_FL + 2); fX = CPK(CP_FL + 3); fY = CPK(CP_FL + 4); }
+    else { fL = car_fL; fT = car_fT; fR = car_fR; fX = car_fX; fY = car_fY; }
 #ifdef SAG_ABL_CARFRIC   // timing-only build: no floor friction at all
     car_warm = true;
 #endif
@@ -1337,11 +1355,18 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         fY = fn; g1 += M3 * df; sY += CRW * df * p.car.iIb;
       }
     }
-    car_f0 = g0; car_f1 = g1; car_f2 = g2;
-    car_fL = fL; car_fT = fT; car_fR = fR; car_fX = fX; car_fY = fY; car_warm = true;
+    car_warm = true;
+    if constexpr (PARK) {
+      CPK(CP_F0) = g0; CPK(CP_F0 + 1) = g1; CPK(CP_F0 + 2) = g2;
+      CPK(CP_FL) = fL; CPK(CP_FL + 1) = fT; CPK(CP_FL + 2) = fR; CPK(CP_FL + 3) = fX; CPK(CP_FL + 4) = fY;
+      CPK(CP_EACC) = sL; CPK(CP_EACC + 1) = sR; CPK(CP_EACC + 2) = sY; CPK(CP_EACC + 3) = -sX; CPK(CP_EACC + 4) = -CJD * ext[4] * p.car.iIb;
+    } else {
+      car_f0 = g0; car_f1 = g1; car_f2 = g2;
+      car_fL = fL; car_fT = fT; car_fR = fR; car_fX = fX; car_fY = fY;
+      eacc[0] = sL; eacc[1] = sR; eacc[2] = sY; eacc[3] = -sX; eacc[4] = -CJD * ext[4] * p.car.iIb;
+    }
     const float t0 = a0 + g0, t1 = a1 + g1;
     R.ax = cy * t0 - sy * t1; R.ay = sy * t0 + cy * t1; R.aw = a2 + g2;
-    eacc[0] = sL; eacc[1] = sR; eacc[2] = sY; eacc[3] = -sX; eacc[4] = -CJD * ext[4] * p.car.iIb;
   };
   // Point: what does not change over the substeps - the inverse inertia's determinant (a^2 + b^2 = mc^2 for any
   // heading), its yaw element, the yaw servo's denominator, the drive force - leaves the loop with its two divisions
@@ -1410,7 +1435,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 #endif
       if (sub == nsub) car_warm = false;      // the forward evaluation behind the observation solves cold: obs = f(state)
       car_floor(0.f, R.w * R.w * COY, 0.f);   // M^-1 (centrifugal force of the offset COM) in body axes
-      car_px = R.ax; car_py = R.ay; car_pw = R.aw;
+      if constexpr (PARK) { CPK(CP_PX) = R.ax; CPK(CP_PX + 1) = R.ay; CPK(CP_PX + 2) = R.aw; }
+      else { car_px = R.ax; car_py = R.ay; car_pw = R.aw; }
     }
     CYC(CY_ROBOT);
     cost_contacts = 0; btn_mask = 0;
@@ -1496,8 +1522,13 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     if constexpr (CAR) {
       // the floor friction once more when the contacts (or the tether) changed the base acceleration: what they
       // added now belongs to `everything else`
-      if (R.ax != car_px || R.ay != car_py || R.aw != car_pw)
-        car_floor(cy * R.ax + sy * R.ay - car_f0, cy * R.ay - sy * R.ax - car_f1, R.aw - car_f2);
+      if constexpr (PARK) {
+        if (R.ax != CPK(CP_PX) || R.ay != CPK(CP_PX + 1) || R.aw != CPK(CP_PX + 2))
+          car_floor(cy * R.ax + sy * R.ay - CPK(CP_F0), cy * R.ay - sy * R.ax - CPK(CP_F0 + 1), R.aw - CPK(CP_F0 + 2));
+      } else {
+        if (R.ax != car_px || R.ay != car_py || R.aw != car_pw)
+          car_floor(cy * R.ax + sy * R.ay - car_f0, cy * R.ay - sy * R.ax - car_f1, R.aw - car_f2);
+      }
     }
     CYC(CY_RV);
     if (sub == nsub) break;  // final forward: robot acceleration + contact flags only
@@ -1628,7 +1659,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     if constexpr (CAR) {
 #pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
 #pragma unroll
-      for (int k = 0; k < 5; k++) ext[k] += h * eacc[k];
+      for (int k = 0; k < 5; k++) ext[k] += h * (PARK ? CPK(CP_EACC + k) : eacc[k]);
+      if constexpr (PARK) { ext[5] = CPK(CP_Q); ext[6] = CPK(CP_Q + 1); ext[7] = CPK(CP_Q + 2); ext[8] = CPK(CP_Q + 3); }
       // ball quaternion: rate relative to the base, in base axes: q <- exp(h W / 2) q
       const float wx = ext[2], wy = ext[3], wz = ext[4];
       const float n2 = wx * wx + wy * wy + wz * wz;
@@ -1652,8 +1684,13 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         const float qz = dw * ext[8] + dx * ext[7] - dy_ * ext[6] + dz * ext[5];
         const float qn = 1.0f / sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
         ext[5] = qw * qn; ext[6] = qx * qn; ext[7] = qy * qn; ext[8] = qz * qn;
+        if constexpr (PARK) { CPK(CP_Q) = ext[5]; CPK(CP_Q + 1) = ext[6]; CPK(CP_Q + 2) = ext[7]; CPK(CP_Q + 3) = ext[8]; }
       }
     }
+  }
+  if constexpr (PARK) {   // back into the registers for the write-back and the sensors
+    ext[5] = CPK(CP_Q); ext[6] = CPK(CP_Q + 1); ext[7] = CPK(CP_Q + 2); ext[8] = CPK(CP_Q + 3);
+    ext_tail.y = CPK(CP_TAIL); ext_tail.z = CPK(CP_TAIL + 1); ext_tail.w = CPK(CP_TAIL + 2);
   }
 
   }  // !DOGGO
@@ -2196,7 +2233,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 // ---- the three launch forms ------------------------------------------------------------
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, SAG_STEP_MIN_WAVES) void k_step(StepArgs p) {
-  __shared__ float lds[LDS_FLOATS + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
+  __shared__ float lds[LDS_FLOATS + (ROBOT == SAG_ROBOT_CAR ? CAR_PARK_SLOTS * WAVE : 0) + SAG_LDS_PAD];  // PAD: occupancy probe (tools/ablate.py)
   static_assert(ROBOT != SAG_ROBOT_DOGGO, "Doggo: k_doggo_physics + k_step_doggo_post");
   // small batches: fewer envs per wavefront (p.envs_per_wave)
   // spread the batch over more CUs and shrink the divergence union; the idle lanes just mirror env N-1
@@ -2305,7 +2342,7 @@ __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_BUSY_MIN_WAV
 #ifndef SAG_BUSY_LDS_PAD
 #define SAG_BUSY_LDS_PAD 0
 #endif
-  __shared__ float lds[LDS_FLOATS + SAG_BUSY_LDS_PAD];  // PAD: occupancy probe
+  __shared__ float lds[LDS_FLOATS + (ROBOT == SAG_ROBOT_CAR ? CAR_PARK_SLOTS * WAVE : 0) + SAG_BUSY_LDS_PAD];  // PAD: occupancy probe
   __shared__ int rows[WAVE];
 #if SAG_BUSY_PRIO
   // the few long wavefronts of this kernel set the length of a step: they issue ahead of the quiet
