@@ -1,7 +1,7 @@
 """How far is the specification's constraint solve from the CONVERGED solution of the same constraint set?
   CPU only, oracle only: a study of the specification, not a device test.
 
-  python tests/study_sweeps.py [envs=512] [steps=120]  ->  table on stdout + profiles/r03_sweep_convergence.txt
+  python tests/study_sweeps.py [envs=512] [steps=120]  ->  table on stdout + profiles/r04_sweep_convergence.txt
 
 For each bench workload the SPECIFICATION free-runs (pursuit actions for Point / Car so that vases, the box and goals
 are hit; random torques for the Doggo).  At every step the SAME pre-step state is also advanced with N cold
@@ -101,5 +101,5 @@ f = o.record(e)[0]
 yaw = f[tp.F_ROBOT + 2]
 say(f'## car straight line, 250 steps at full throttle: heading drift {yaw - 0.3:+.4f} rad, speed {float(np.dot(f[tp.F_ROBOT + 3:tp.F_ROBOT + 5], [np.sin(yaw), -np.cos(yaw)])):.4f} m/s '
     '(round 2, one sweep of six elements: 0.06 rad, 0.77 m/s; 64 sweeps of them: 0.009 rad, 0.82 m/s)')
-out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r03_sweep_convergence.txt')
+out = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'profiles', 'r04_sweep_convergence.txt')
 open(out, 'w').write('\n'.join(lines) + '\n')

@@ -1127,6 +1127,31 @@ def test_doggo_random_contact_geometry_on_device(nat, oracle):
   ctx.close()
 
 
+def test_doggo_launch_order_does_not_change_results(nat, monkeypatch):
+  """k_doggo_physics takes the envs longest-first, pairing them differently from step to step (and, inside a cost class,
+  from run to run): an env's arithmetic depends on its own rows only (the PGS path is chosen per env), so the results
+  are those of the plain order bit for bit - including the haul_box envs whose rows exceed the 32-lane path."""
+  n, T = (96, 12) if os.environ.get('SAG_HOSTEMU') else (1024, 25)
+  rf, ri = bu.sample_records_native('doggo', 'haul_box', n, seed=666)
+  rng = np.random.RandomState(8)
+  acts = rng.uniform(-1, 1, (T, n, 12)).astype(np.float32)
+  out = {}
+  for sched in ('1', '0'):
+    monkeypatch.setenv('SAG_DOGGO_SCHED', sched)
+    ctx = nat.Context('doggo', n, seed=77, has_box=True)
+    ctx.set_layout(rf, ri)
+    obs = []
+    for t in range(T):
+      obs.append(ctx.step(acts[t], None, None)[0].copy())
+    out[sched] = (np.stack(obs), *ctx.get_state())
+    ctx.close()
+  heavy = int(((out['1'][2][:, 13] & 4) != 0).sum())
+  np.testing.assert_array_equal(out['1'][0], out['0'][0])
+  np.testing.assert_array_equal(out['1'][1], out['0'][1])
+  np.testing.assert_array_equal(out['1'][2], out['0'][2])
+  print(f'{n} haul_box envs x {T} steps: longest-first == plain order bit for bit ({heavy} envs beyond the row budget at the end)')
+
+
 def test_doggo_env_api(nat):
   """make('doggo', ...): obs 104, 12 actions; zero action lets the robot settle on its feet."""
   import safe_adaptation_gym_amd as sag
