@@ -1323,6 +1323,14 @@ void sago_doggo_debug(const OEnv* e, double* M, double* bias, double* sph, doubl
   if (dg_cholesky(D.L)) dg_solve(D.L, tau, qacc0);
 }
 
+/* dg_seg_box_t / dg_box_sd for the tests: the parameter of the segment a + t d (box frame) nearest to the box in signed
+ * distance, and that distance */
+double sago_seg_box_t(double ax, double ay, double dx, double dy, double hx, double hy, double t0, double t1, double* sd) {
+  const real t = dg_seg_box_t((real)ax, (real)ay, (real)dx, (real)dy, (real)hx, (real)hy, (real)t0, (real)t1);
+  if (sd) *sd = (double)dg_box_sd((real)(ax + (double)t * dx), (real)(ay + (double)t * dy), (real)hx, (real)hy);
+  return (double)t;
+}
+
 /* the contacts (normal rows) of ONE forward evaluation of a Doggo env at zero control: out[k] = key, point xyz,
  * normal xyz (into the robot), depth, solved normal force; returns their number, *cost_contacts = the count the
  * cost rule sees (robot geoms x vases / pillars).  Keys: sag_oracle_doggo.inc (floor 0x1000 + 4 point,
