@@ -422,10 +422,14 @@ class Context:
   def enable_timing(self, on=True):
     self._check(self.lib.sag_enable_timing(self.h, int(on)), 'sag_enable_timing')
 
-  def debug_cycles(self, reset=False):
-    out = (C.c_uint64 * 48)()
-    self._check(self.lib.sag_debug_cycles(self.h, int(reset), out, 48), 'sag_debug_cycles')
-    return np.array(out[:], np.uint64).reshape(3, 16)
+  def debug_cycles(self, reset=False, worst=False):
+    """[3 kernel forms, 15 sections + wavefront count] clock ticks summed over wavefronts (library built with -DSAG_CYCLES);
+    worst=True: the sections of the slowest wavefront since the last reset (last column: its total) and its block index per form."""
+    out = (C.c_uint64 * 291)()
+    self._check(self.lib.sag_debug_cycles(self.h, int(reset), out, 291), 'sag_debug_cycles')
+    a = np.array(out[:], np.uint64)
+    self.cycles_hist = a[99:291].reshape(3, 64)   # wavefronts by total ticks: bucket b = [2^((b + 40) / 4), 2^((b + 41) / 4))
+    return (a[48:96].reshape(3, 16), a[96:99]) if worst else a[:48].reshape(3, 16)
 
   def render_rgb(self):
     """[n_envs, 64, 64, 3] uint8: the robots' first-person camera images (rgb_observation)."""

@@ -66,7 +66,7 @@ struct sag_ctx {
   // list[phase] from the busy bits whenever state was installed from outside (list_valid = false)
   int32_t* d_rows = nullptr; int32_t* d_count = nullptr;
   bool list_valid = false;
-  int count_flip = 0;          // which of d_count[2], d_count[3] this step's compaction fills
+  int count_flip = 0;          // which of the counter sets 2 and 3 of d_count this step's compaction fills
   int32_t* last_count = nullptr;
   float* d_hot = nullptr;     // [N][HOT_FLOATS] hot records (split form), see sag_device.hpp
   bool hot_valid = false, use_hot = true;   // SAG_HOT=0 disables
@@ -101,6 +101,9 @@ struct sag_ctx {
   int32_t* d_dg_sched = nullptr; int dg_phase = 0;   // Doggo: longest-first launch order (sag_doggo_coop.hpp); SAG_DOGGO_SCHED=0 turns it off
   bool dg_sched_on = true;
   int epw_override = 0;  // SAG_EPW (read once at create): envs per wavefront of the single-launch form
+  int busy_e = 64;       // SAG_BUSY_E: envs per busy wavefront (0 = balanced over busy_slots: busy_wave_envs - measured slower, see there)
+  int busy_slots = 0;    // SAG_BUSY_SLOTS: busy wavefronts resident at once (0 = 8 per CU: two per SIMD)
+  int busy_kinds = 1;    // SAG_BUSY_KINDS=0: one busy list instead of one per kind (A/B)
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
@@ -279,7 +282,8 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   a.tape_used = d_used; a.max_vases = c->cfg.max_vases; a.max_hazards = c->cfg.max_hazards;
   a.max_pillars = c->cfg.max_pillars; a.max_buttons = c->cfg.max_buttons; a.observe_only = observe_only;
   a.has_box = c->cfg.has_box; a.G = c->G;
-  a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * c->N; a.count = c->d_count + c->phase;
+  // busy lists: [phase][BUSY_CLASSES][N] rows; counters [4][BUSY_CLASSES]: two for the in-kernel lists (by phase), two used alternately by k_compact
+  a.phase = c->phase; a.rows = c->d_rows + (size_t)c->phase * BUSY_CLASSES * c->N; a.count = c->d_count + c->phase * BUSY_CLASSES;
   a.rows_next = nullptr; a.count_next = nullptr; a.DR = nullptr; a.dg_sched = nullptr; a.dg_phase = -1;
   a.hot = nullptr; a.hot_haz = nullptr;
   // external contact results: for the one step with nstep == 0 that follows sag_set_ext_contacts
@@ -294,6 +298,8 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     while (epw > (dg ? 8 : 16) && (c->N + epw - 1) / epw < (dg ? 1 : 4) * c->n_cu) epw >>= 1;
     if (c->epw_override > 0) epw = c->epw_override;
     a.envs_per_wave = epw < 1 ? 1 : (epw > 64 ? 64 : epw);
+    a.busy_envs = c->busy_e; a.busy_kinds = c->busy_kinds;
+    a.busy_slots = c->busy_slots > 0 ? c->busy_slots : 8 * c->n_cu;
   }
   c->phase_used = c->phase;
   if (!observe_only) c->phase ^= 1;
@@ -310,7 +316,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   const bool split = c->split && !observe_only && c->cfg.robot != SAG_ROBOT_DOGGO;
   hipStream_t quiet_stream = c->stream;
   if (split) {
-    a.rows_next = c->d_rows + (size_t)(c->phase_used ^ 1) * c->N; a.count_next = c->d_count + (c->phase_used ^ 1);
+    a.rows_next = c->d_rows + (size_t)(c->phase_used ^ 1) * BUSY_CLASSES * c->N; a.count_next = c->d_count + (c->phase_used ^ 1) * BUSY_CLASSES;
     if (c->use_hot && c->d_hot) {
       a.hot = c->d_hot; a.hot_haz = c->d_hot + (size_t)c->N * HOT_FLOATS;
       if (!c->hot_valid) {
@@ -319,7 +325,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
       }
     }
     if (!c->inkernel_list) { a.rows_next = nullptr; a.count_next = nullptr; c->list_valid = false; }
-    else HIPCHK(c, hipMemsetAsync(a.count_next, 0, sizeof(int32_t), c->stream));
+    else HIPCHK(c, hipMemsetAsync(a.count_next, 0, BUSY_CLASSES * sizeof(int32_t), c->stream));
     // The quiet kernel needs no list (it reads the busy bits), so its stream forks off BEFORE the
     // compaction: k_compact only looks at this step's copy of the bit, which the quiet kernel never
     // changes (it rewrites tstate words of quiet envs with that bit still clear), so the two may overlap.
@@ -337,12 +343,12 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     }
     if (!c->inkernel_list) {
       // two counters used alternately: this step's compaction zeroes the one the next step will use
-      a.count = c->d_count + 2 + c->count_flip;
+      a.count = c->d_count + (2 + c->count_flip) * BUSY_CLASSES;
       hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->N, a.phase,
-                         a.rows, a.count, c->d_count + 2 + (c->count_flip ^ 1));
+                         a.rows, a.count, c->d_count + (2 + (c->count_flip ^ 1)) * BUSY_CLASSES);
       c->count_flip ^= 1;
     } else if (!c->list_valid) {
-      HIPCHK(c, hipMemsetAsync(a.count, 0, sizeof(int32_t), c->stream));
+      HIPCHK(c, hipMemsetAsync(a.count, 0, BUSY_CLASSES * sizeof(int32_t), c->stream));
       hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->N, a.phase,
                          a.rows, a.count, (int32_t*)nullptr);
     }
@@ -365,7 +371,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
 #define SAG_LAUNCH3(ROB, B_, X_)                                                                         \
   do {                                                                                                  \
     if (split) {                                                                                        \
-      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3((c->N + busy_envs(ROB) - 1) / busy_envs(ROB)), dim3(WAVE), 0, c->stream, a); \
+      hipLaunchKernelGGL((k_step_busy<ROB, B_, X_>), dim3(busy_grid(c->N, a.busy_envs, a.busy_slots)), dim3(WAVE), 0, c->stream, a); \
       hipLaunchKernelGGL((k_step_quiet<ROB, B_, X_>), dim3(blocks), dim3(WAVE), quiet_lds_extra, quiet_stream, a); \
     } else {                                                                                            \
       hipLaunchKernelGGL((k_step<ROB, B_, X_>), dim3((c->N + a.envs_per_wave - 1) / a.envs_per_wave), dim3(WAVE), 0, c->stream, a); \
@@ -502,6 +508,9 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   if (const char* e = getenv("SAG_INKERNEL_LIST")) c->inkernel_list = atoi(e) != 0;
   if (const char* e = getenv("SAG_HOT")) c->use_hot = atoi(e) != 0;
   if (const char* e = getenv("SAG_EPW")) c->epw_override = atoi(e);
+  if (const char* e = getenv("SAG_BUSY_E")) c->busy_e = atoi(e) > 64 ? 64 : atoi(e);
+  if (const char* e = getenv("SAG_BUSY_SLOTS")) c->busy_slots = atoi(e);
+  if (const char* e = getenv("SAG_BUSY_KINDS")) c->busy_kinds = atoi(e) != 0;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -509,9 +518,9 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->S, N * DEV_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->I, icount(N) * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
-  CREATE_CHK(hipMalloc(&c->d_rows, 2 * N * sizeof(int32_t)));
-  CREATE_CHK(hipMalloc(&c->d_count, 4 * sizeof(int32_t)));
-  CREATE_CHK(hipMemset(c->d_count, 0, 4 * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->d_rows, 2 * BUSY_CLASSES * N * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->d_count, 4 * BUSY_CLASSES * sizeof(int32_t)));
+  CREATE_CHK(hipMemset(c->d_count, 0, 4 * BUSY_CLASSES * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->L_f, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->L_i, N * SAG_REC_INTS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->st_f, N * SAG_REC_FLOATS * sizeof(float)));
@@ -880,15 +889,41 @@ int sag_kernel_time_ms(sag_ctx* c, int32_t reset, double* mean_ms, int64_t* laun
 
 int sag_debug_cycles(sag_ctx* c, int32_t reset, uint64_t* out, int32_t n) {
   if (!c || !out || n < 0) return SAG_ERR_ARG;
-#ifdef SAG_CYCLES
+#ifdef SAG_WAVE_TIMES   // (start, end) per busy wavefront of the last launch; reset: cleared
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  uint64_t host[3 * (CY_N + 1)];
-  HIPCHK(c, hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cyc), sizeof(host)));
-  for (int k = 0; k < n; k++) out[k] = k < 3 * (CY_N + 1) ? host[k] : 0;
+  if (c->stream2) HIPCHK(c, hipStreamSynchronize(c->stream2));
+  {
+    // out: [WT_MAX][2] times, then [WT_MAX][32] env ids (two per word), then [WT_MAX][64] work bytes (eight per word)
+    std::vector<uint64_t> host((size_t)(2 + 32 + 64 + 2) * WT_MAX);   // ... then [WT_MAX][8] wavefront passes (four per word)
+    HIPCHK(c, hipMemcpyFromSymbol(host.data() + (size_t)98 * WT_MAX, HIP_SYMBOL(g_wt_trips), (size_t)2 * WT_MAX * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(g_wt), (size_t)2 * WT_MAX * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpyFromSymbol(host.data() + (size_t)2 * WT_MAX, HIP_SYMBOL(g_wt_env), (size_t)32 * WT_MAX * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpyFromSymbol(host.data() + (size_t)34 * WT_MAX, HIP_SYMBOL(g_wt_work), (size_t)64 * WT_MAX * sizeof(uint64_t)));
+    for (int k = 0; k < n; k++) out[k] = (size_t)k < host.size() ? host[k] : 0;
+    if (reset) {
+      std::fill(host.begin(), host.end(), 0);
+      HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_wt), host.data(), (size_t)2 * WT_MAX * sizeof(uint64_t)));
+    }
+  }
+  return SAG_OK;
+#elif defined(SAG_CYCLES)
+  HIPCHK(c, hipSetDevice(c->cfg.device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // out[0 .. 48): sums per kernel form and section (+ wavefront count); out[48 .. 96): the sections of the slowest wavefront;
+  // out[96 .. 99): its block index; out[99 .. 291): wavefronts by total ticks, 3 x 64 buckets of a quarter octave from 2^10
+  constexpr int M = 3 * (CY_N + 1);
+  uint64_t host[2 * M + 3 + 192];
+  HIPCHK(c, hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cyc), M * sizeof(uint64_t)));
+  HIPCHK(c, hipMemcpyFromSymbol(host + M, HIP_SYMBOL(g_cyc_worst), M * sizeof(uint64_t)));
+  HIPCHK(c, hipMemcpyFromSymbol(host + 2 * M, HIP_SYMBOL(g_cyc_worst_block), 3 * sizeof(uint64_t)));
+  HIPCHK(c, hipMemcpyFromSymbol(host + 2 * M + 3, HIP_SYMBOL(g_cyc_hist), 192 * sizeof(uint64_t)));
+  for (int k = 0; k < n; k++) out[k] = k < 2 * M + 3 + 192 ? host[k] : 0;
   if (reset) {
     memset(host, 0, sizeof(host));
-    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_cyc), host, sizeof(host)));
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_cyc), host, M * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_cyc_worst), host, M * sizeof(uint64_t)));
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_cyc_hist), host, 192 * sizeof(uint64_t)));
   }
   return SAG_OK;
 #else
@@ -954,7 +989,10 @@ int sag_busy_count(sag_ctx* c, int32_t* count) {
   HIPCHK(c, hipSetDevice(c->cfg.device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (!c->last_count) { *count = 0; return SAG_OK; }
-  HIPCHK(c, hipMemcpy(count, c->last_count, sizeof(int32_t), hipMemcpyDeviceToHost));  // the list the last step consumed
+  int32_t per_kind[BUSY_CLASSES];   // the lists the last step consumed
+  HIPCHK(c, hipMemcpy(per_kind, c->last_count, sizeof(per_kind), hipMemcpyDeviceToHost));
+  *count = 0;
+  for (int k = 0; k < BUSY_CLASSES; k++) *count += per_kind[k];
   return SAG_OK;
 }
 

@@ -114,6 +114,9 @@ struct CarFricK {
 struct StepArgs {
   CarFricK car;
   int envs_per_wave;  // single-launch form (k_step): 8..64 envs per wavefront, by batch size
+  int busy_envs;      // split form (k_step_busy): envs per busy wavefront, or 0 = balanced over `busy_slots` (busy_wave_envs)
+  int busy_slots;     // busy wavefronts the chip holds at once
+  int busy_kinds;     // 1: the busy list is kept by kind (TS_KIND_SHIFT); 0: one list (SAG_BUSY_KINDS=0, A/B)
   float* S;          // [DEV_GROUPS][N] float4 (see didx)
   int32_t* I;        // tstate [N], then (meta, step, envid, flags) [N] int4 (see iaddr)
   int32_t N;
@@ -134,8 +137,8 @@ struct StepArgs {
   int32_t max_vases, max_hazards, max_pillars, max_buttons;  // context capacities (load bounds)
   int32_t has_box;
   int32_t phase;          // which copy of the busy bit this launch reads (0 / 1)
-  int32_t* rows;          // [N] env ids of the busy envs, compacted (k_compact)
-  int32_t* count;         // number of entries in rows
+  int32_t* rows;          // [BUSY_CLASSES][N] env ids of the busy envs by kind, compacted (k_compact)
+  int32_t* count;         // [BUSY_CLASSES] entries in each list
   int32_t* rows_next;     // split form: the busy list of the NEXT step, appended to by the classification
   int32_t* count_next;    //   (nullptr: not built; the host then runs k_compact)
   float* G;               // [3][NBODY][N] spill of body accelerations beyond the LDS pool
@@ -684,11 +687,43 @@ enum { ABL_NO_LIDAR = 1, ABL_NO_OBS_STORE = 2, ABL_NO_VV = 4, ABL_NO_VS = 8, ABL
 // section of step_body into g_cyc[mode][section]; off in the shipped library
 enum { CY_LOAD = 0, CY_ROBOT, CY_RS, CY_RV, CY_VS, CY_VV_BROAD, CY_VV_NARROW, CY_INTEG, CY_WRITEBACK,
        CY_REWARD, CY_RESAMPLE, CY_COST, CY_LIDAR, CY_OBS_STORE, CY_TAIL, CY_N };
+#ifdef SAG_WAVE_TIMES   // (tools/busy_timeline.py) per busy wavefront of the LAST launch: start / end (100-MHz wall clock), its env ids and, per
+// lane, how often each contact loop ran over the step - the raw material of a cost model of a busy wavefront
+constexpr int WT_MAX = 16384;
+static __device__ unsigned long long g_wt[WT_MAX][2];
+static __device__ int g_wt_env[WT_MAX][64];
+static __device__ unsigned char g_wt_work[WT_MAX][64][8];
+static __device__ unsigned short g_wt_trips[WT_MAX][8];   // loop passes the WAVEFRONT ran (sum over substeps of the max over its lanes)
+#define WTW(k) do { if (wt_work[k] < 255) wt_work[k]++; } while (0)
+__device__ inline int wt_wave_max(int v) { for (int off = 32; off; off >>= 1) v = max(v, __shfl_xor(v, off)); return v; }
+#define WTT(k, v) do { wt_trips[k] += (unsigned)wt_wave_max((int)(v)); } while (0)
+#else
+#define WTW(k) do {} while (0)
+#define WTT(k, v) do {} while (0)
+#endif
 #ifdef SAG_CYCLES
 static __device__ unsigned long long g_cyc[3][CY_N + 1];
+static __device__ unsigned long long g_cyc_worst[3][CY_N + 1];   // the sections of the wavefront with the largest total (last column)
+static __device__ unsigned long long g_cyc_worst_block[3];        // ... and its block index
+static __device__ unsigned long long g_cyc_hist[3][64];           // wavefronts by total ticks, four buckets per octave (bucket = floor(4 log2 ticks) - 40)
 #define CYC_DECL unsigned long long cyc_acc[CY_N] = {}; unsigned long long cyc_t = __builtin_readcyclecounter();
 #define CYC(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); cyc_acc[k] += t_ - cyc_t; cyc_t = t_; } while (0)
-#define CYC_FLUSH(mode) do { if (lane == 0) { for (int k_ = 0; k_ < CY_N; k_++) atomicAdd(&g_cyc[mode][k_], cyc_acc[k_]); atomicAdd(&g_cyc[mode][CY_N], 1ull); } } while (0)
+// the sections inside the active-body block run under a divergent branch: a lane outside it books the wavefront's time there on its next
+// marker (`robot`).  Per section the wavefront's figure is therefore the MAX over lanes, except `robot`: the MIN over the lanes that carry an env.
+__device__ inline unsigned long long cyc_wave_red(unsigned long long v, bool take_max) {
+  for (int off = 32; off; off >>= 1) {
+    const unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)(v >> 32), off) << 32) | (unsigned)__shfl_xor((int)(v & 0xffffffffu), off);
+    v = take_max ? (o > v ? o : v) : (o < v ? o : v);
+  }
+  return v;
+}
+#define CYC_FLUSH(mode) do { unsigned long long tot_ = 0, red_[CY_N]; \
+    for (int k_ = 0; k_ < CY_N; k_++) { red_[k_] = cyc_wave_red(k_ == CY_ROBOT && !live ? ~0ull : cyc_acc[k_], k_ != CY_ROBOT); tot_ += red_[k_]; } \
+    if (lane == 0) { for (int k_ = 0; k_ < CY_N; k_++) atomicAdd(&g_cyc[mode][k_], red_[k_]); \
+    atomicAdd(&g_cyc[mode][CY_N], 1ull); \
+    { const int lg_ = 63 - __clzll((long long)(tot_ | 1ull)); const int q_ = lg_ >= 2 ? (int)(tot_ >> (lg_ - 2) & 3ull) : 0; \
+      const int b_ = 4 * lg_ + q_ - 40; atomicAdd(&g_cyc_hist[mode][b_ < 0 ? 0 : (b_ > 63 ? 63 : b_)], 1ull); } \
+    if (atomicMax(&g_cyc_worst[mode][CY_N], tot_) < tot_) { for (int k_ = 0; k_ < CY_N; k_++) g_cyc_worst[mode][k_] = red_[k_]; g_cyc_worst_block[mode] = blockIdx.x; } } } while (0)
 #else
 #define CYC_DECL
 #define CYC(k) do {} while (0)
@@ -953,6 +988,15 @@ enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2, MODE_POST = 3 };
 // writes bit 28 + (phase ^ 1), so the QUIET launch cannot re-flag an env for the BUSY launch of
 // the same step
 constexpr uint32_t TS_BUSY_BIT = 1u << 28;
+// tstate bits 30..31: the KIND of a busy env = which walks of the contact code its robot is within reach of - bit 0 the task object,
+// bit 1 a static circle (pillar / button); neither: vases, or only bodies still moving.  A hint for the order of the busy list only
+// (busy_class_order): a busy wavefront executes every loop that ANY of its 64 lanes takes, in every substep, so wavefronts of one
+// kind each skip the other kinds' walks (Car / push_box, 4 M envs: mean busy wavefront 416 -> 275 us when the list is sorted by kind;
+// tools/busy_sort_probe.py).  One copy, written with the NEXT step's busy bit; results never depend on it.
+constexpr uint32_t TS_KIND_SHIFT = 30;
+constexpr int BUSY_CLASSES = 4;
+// launch order of the classes, most expensive walk first (the cheap wavefronts then fill the last round): both, object, static, neither
+__host__ __device__ constexpr int busy_class_order(int k) { return k == 0 ? 3 : (k == 1 ? 1 : (k == 2 ? 2 : 0)); }
 
 // Car: 1 / inertia of the spinning parts (joint damping implicit: I + h d); per floor-friction element (L / R the
 // wheels' rolling directions, T their merged lateral element, X / Y the caster's: oracle car_floor_friction) the
@@ -1224,6 +1268,11 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   int cost_contacts = 0;
   uint32_t btn_mask = 0;
   float cy = 1, sy = 0, yaw_turn = 0;
+#ifdef SAG_WAVE_TIMES
+  unsigned wt_work[8] = {};   // robot-static hits, robot-vase hits, robot-object hits, free-static hits, free-free pairs, integrated bodies, substeps with any, -
+  unsigned wt_trips[8] = {};  // the same loops, passes of the wavefront
+  unsigned wt_prev[8] = {};
+#endif
 
   CYC(CY_LOAD);
   // Doggo: the physics kernel has run; state in private memory for the sensors
@@ -1458,6 +1507,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
         St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
         const int n = collide_list<SH_ME, false>(R, cy, sy, St, SH_STATIC, 1.f, 0.f, vsz, sr, sol0);
+        WTW(0);
         if (is_p) cost_contacts += n;
         else if (n) btn_mask |= 1u << (k - SAG_MAX_PILLARS);
       }
@@ -1485,6 +1535,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       dy.ensure(k, false);
       BV V; float cv, sv; load_body(dy, k, V, cv, sv);
       const int n = collide_list<SH_ME, false>(R, cy, sy, V, SH_VASE, cv, sv, vsz, 0.f, sol0);
+      WTW(1);
       cost_contacts += n;
       if (n) { dy.set_acc(k, V.ax, V.ay, V.aw); active |= 1u << k; }
     }
@@ -1492,6 +1543,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       dy.ensure(BOX_ID, false);
       BV V; float cv, sv; load_body(dy, BOX_ID, V, cv, sv);
       const int n = collide_list<SH_ME, HAS_TBOX>(R, cy, sy, V, bk.sh, cv, sv, vsz, 0.f, solb);   // the task object is not an obstacle (consts.OBSTACLES)
+      WTW(2);
       if (n) { dy.set_acc(BOX_ID, V.ax, V.ay, V.aw); active |= 1u << BOX_ID; }
     }
     // HaulBox tether (haul_box.py:21-29): spatial tendon robot site (z .1) <-> box site (z .2),
@@ -1531,6 +1583,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       }
     }
     CYC(CY_RV);
+#ifdef SAG_WAVE_TIMES
+    if (sub == nsub) for (int k_ = 0; k_ < 6; k_++) { WTT(k_, wt_work[k_] - wt_prev[k_]); wt_prev[k_] = wt_work[k_]; }
+#endif
     if (sub == nsub) break;  // final forward: robot acceleration + contact flags only
     if (active && !ABL(ABL_NO_ACTIVE)) {
       // free bodies vs static circles (pillars then buttons), per active body
@@ -1557,6 +1612,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
           BV St; St.x = sx; St.y = syy; St.vx = St.vy = St.w = St.ax = St.ay = St.aw = 0;
           St.m0 = St.m1 = St.m2 = St.m3 = St.m4 = St.m5 = 0; St.dyn = 0;
           collide_shapes<!DOGGO>(V, isb ? bk.sh : SH_VASE, cv, sv, St, SH_STATIC, 1.f, 0.f, vsz, sr, isb ? solb : sol0);
+          WTW(3);
           dy.set_acc(k, V.ax, V.ay, V.aw);
         }
       }
@@ -1573,13 +1629,18 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         for (uint32_t m = active; m; m &= m - 1) {
           const int k = __ffs(m) - 1;
           const float kx = LP(LS_X, k), ky = LP(LS_Y, k), kr = is_box(k) ? box_r : vase_r;
+          // (all positions first, then the tests without branches: read one by one under the hit branch of the body before,
+          // every test waited out an LDS round trip - 2 k cycles per active body, the largest item of a small batch's slowest wavefront)
+          constexpr int NJ = HAS_TBOX ? NBODY : SAG_MAX_VASES;
+          float jx[NJ], jy[NJ];
 #pragma unroll
-          for (int j = 0; j < (HAS_TBOX ? NBODY : SAG_MAX_VASES); j++) {
-            const float dx = LP(LS_X, j) - kx, dyy = LP(LS_Y, j) - ky, rs = kr + (j == BOX_ID ? box_r : vase_r);
-            if ((fmask >> j & 1u) && j != k && dx * dx + dyy * dyy <= rs * rs) {
-              const int lo = min(j, k), hi = max(j, k);
-              pairs |= 1ull << (lo * (21 - lo) / 2 + hi - lo - 1);
-            }
+          for (int j = 0; j < NJ; j++) { jx[j] = LP(LS_X, j); jy[j] = LP(LS_Y, j); }
+#pragma unroll
+          for (int j = 0; j < NJ; j++) {
+            const float dx = jx[j] - kx, dyy = jy[j] - ky, rs = kr + (j == BOX_ID ? box_r : vase_r);
+            const bool hit = (fmask >> j & 1u) & (uint32_t)(j != k) & (uint32_t)(dx * dx + dyy * dyy <= rs * rs);
+            const int lo = min(j, k), hi = max(j, k);
+            pairs |= hit ? 1ull << (lo * (21 - lo) / 2 + hi - lo - 1) : 0ull;
           }
         }
       }
@@ -1594,6 +1655,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         load_body(dy, a, A, ca, sa);
         load_body(dy, b, B, cb, sb);
         const int n = collide_list<SH_VASE, HAS_TBOX>(A, ca, sa, B, isb ? bk.sh : SH_VASE, cb, sb, vsz, 0.f, isb ? solb : sol0);
+        WTW(4);
         if (n) {
           dy.set_acc(a, A.ax, A.ay, A.aw); dy.set_acc(b, B.ax, B.ay, B.aw);
           active |= 1u << a | 1u << b;
@@ -1606,6 +1668,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
 #pragma clang fp contract(on)   // a * b + c of ONE expression fuses (frontend decision: the same in every instance)
         const int k = __ffs(m) - 1;
         float vx_, vy_, w_, ax_, ay_, aw_;
+        WTW(5);
         dy.get(k, vx_, vy_, w_, ax_, ay_, aw_);
         const float bc = sol0.bcoef;
         if (!is_box(k) || bk.sh == SH_BOX) {
@@ -1654,6 +1717,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     } else {
       if (sub == nsub) break;
     }
+#ifdef SAG_WAVE_TIMES
+    for (int k_ = 0; k_ < 6; k_++) { WTT(k_, wt_work[k_] - wt_prev[k_]); wt_prev[k_] = wt_work[k_]; }
+#endif
     R.vx = __builtin_fmaf(h, R.ax, R.vx); R.vy = __builtin_fmaf(h, R.ay, R.vy); R.w = __builtin_fmaf(h, R.aw, R.w);
     R.x = __builtin_fmaf(h, R.vx, R.x); R.y = __builtin_fmaf(h, R.vy, R.y); yaw_turn = h * R.w; yaw += yaw_turn;
     if constexpr (CAR) {
@@ -1734,6 +1800,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     const float amax = CAR ? GRAV : 1.05f * gear * PT_FLIM / PT_MASS;
     const float reach = sqrtf(R.vx * R.vx + R.vy * R.vy) * T + amax * T * T + 0.005f;
     bool busy = awake != 0 || (HAS_TBOX && task == SAG_TASK_HAUL_BOX);
+    bool near_obj = false, near_static = false;   // (the kind, TS_KIND_SHIFT)
     const float rr = my_bound + reach;
     // Point: bounding circles first, then the footprint itself.  The robot is inside circle A (its sphere,
     // r .1) and circle B (around the arrow box at +.1 along the heading, r .05 sqrt 2); within the step
@@ -1763,7 +1830,7 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     }
     if (has_box) {
       const float dx = LP(LS_X, BOX_ID) - R.x, dyy = LP(LS_Y, BOX_ID) - R.y, rs = rr + box_r;
-      busy |= dx * dx + dyy * dyy <= rs * rs;
+      near_obj = dx * dx + dyy * dyy <= rs * rs;
     }
 #pragma unroll 1
     for (int k = 0; k < n_static; k++) {
@@ -1775,21 +1842,27 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
       const float dx = skx - R.x, dyy = sky - R.y, rs = rr + sr;
       if constexpr (FINE) {
         const float ex = skx - Bx, ey = sky - By;
-        busy |= on && (dx * dx + dyy * dyy <= (fa + sr) * (fa + sr) || ex * ex + ey * ey <= (fb + sr) * (fb + sr));
-      } else busy |= on && dx * dx + dyy * dyy <= rs * rs;
+        near_static |= on && (dx * dx + dyy * dyy <= (fa + sr) * (fa + sr) || ex * ex + ey * ey <= (fb + sr) * (fb + sr));
+      } else near_static |= on && dx * dx + dyy * dyy <= rs * rs;
     }
+    busy |= near_obj || near_static;
+    const uint32_t kind = p.busy_kinds ? (uint32_t)near_obj | (uint32_t)near_static << 1 : 0u;
     const uint32_t nbit = TS_BUSY_BIT << (p.phase ^ 1);
     tstate = busy ? (tstate | nbit) : (tstate & ~nbit);
+    tstate = (tstate & ~(3u << TS_KIND_SHIFT)) | (busy ? kind << TS_KIND_SHIFT : 0u);
     busy_next = busy;
     // next step's busy list, built here instead of by a separate compaction pass: one atomic per
     // wavefront claims a contiguous chunk (a chunk keeps the env neighbourhood of its wavefront)
     if (MODE != MODE_ALL && p.rows_next) {
-      const uint64_t bm = __ballot(busy && live);
-      if (bm) {
-        int chunk = 0;
-        if (lane == __ffsll((unsigned long long)bm) - 1) chunk = atomicAdd(p.count_next, __popcll(bm));
-        chunk = __shfl(chunk, __ffsll((unsigned long long)bm) - 1);
-        if (busy && live) p.rows_next[chunk + __popcll(bm & ((1ull << lane) - 1))] = i;
+      for (int c = 0; c < BUSY_CLASSES; c++) {   // (per kind: the list is [BUSY_CLASSES][N], k_compact)
+        const bool mine = busy && live && (int)kind == c;
+        const uint64_t bm = __ballot(mine);
+        if (bm) {
+          int chunk = 0;
+          if (lane == __ffsll((unsigned long long)bm) - 1) chunk = atomicAdd(p.count_next + c, __popcll(bm));
+          chunk = __shfl(chunk, __ffsll((unsigned long long)bm) - 1);
+          if (mine) p.rows_next[(size_t)c * p.N + chunk + __popcll(bm & ((1ull << lane) - 1))] = i;
+        }
       }
     }
   }
@@ -2228,6 +2301,13 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   }
   CYC(CY_TAIL);
   CYC_FLUSH(MODE);
+#ifdef SAG_WAVE_TIMES
+  if (MODE == MODE_BUSY && blockIdx.x < WT_MAX) {
+    g_wt_env[blockIdx.x][lane] = live ? i : -1;
+    for (int k = 0; k < 8; k++) g_wt_work[blockIdx.x][lane][k] = (unsigned char)wt_work[k];
+    if (lane == 0) for (int k = 0; k < 8; k++) g_wt_trips[blockIdx.x][k] = (unsigned short)wt_trips[k];
+  }
+#endif
 }
 
 // ---- the three launch forms ------------------------------------------------------------
@@ -2281,64 +2361,99 @@ __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_QUIET_MIN_WA
                                                    min(WAVE, p.N - base), skip, nullptr);
 }
 
-// busy envs -> dense list.  Each 256-thread block covers COMPACT_ENVS envs, orders its own busy ones by
-// index (ballot + prefix) and claims a contiguous segment with ONE atomic; segments of different blocks
-// land in arbitrary order, which only affects which wavefront processes an env.  (The atomics all hit
-// one counter and serialise at ~10 ns each: with 1024 envs per block the launch took 51 us at 4 M envs,
+// busy envs -> dense lists, one per kind (TS_KIND_SHIFT): rows [BUSY_CLASSES][N], count [BUSY_CLASSES].  Each 256-thread block covers
+// COMPACT_ENVS envs, orders its own busy ones of a kind by index (ballot + prefix) and claims a contiguous segment of that kind's list
+// with ONE atomic; segments of different blocks land in arbitrary order, which only affects which wavefront processes an env.  (The
+// atomics of a kind all hit one counter and serialise at ~10 ns each: with 1024 envs per block the launch took 51 us at 4 M envs,
 // 4096 atomics; 4096 envs per block quarters that.)
 constexpr int COMPACT_PER_LANE = 16, COMPACT_ENVS = 256 * COMPACT_PER_LANE;
 __global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int phase, int32_t* rows, int32_t* count,
                                                   int32_t* zero_for_next) {
-  // the counter the NEXT step's compaction will add to (saves a memset launch per step)
-  if (zero_for_next && blockIdx.x == 0 && threadIdx.x == 0) *zero_for_next = 0;
-  __shared__ int wave_tot[4][COMPACT_PER_LANE];
-  __shared__ int seg_base;
+  // the counters the NEXT step's compaction will add to (saves a memset launch per step)
+  if (zero_for_next && blockIdx.x == 0 && threadIdx.x < BUSY_CLASSES) zero_for_next[threadIdx.x] = 0;
+  __shared__ int wave_tot[4][COMPACT_PER_LANE][BUSY_CLASSES];
+  __shared__ int seg_base[BUSY_CLASSES];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e0 = blockIdx.x * COMPACT_ENVS + wv * (WAVE * COMPACT_PER_LANE);
   uint32_t bmask = 0;        // bit j: env e0 + j * 64 + lane is busy
+  uint32_t kinds = 0;        // two bits per j: its kind
   int pre[COMPACT_PER_LANE];
 #pragma unroll
   for (int j = 0; j < COMPACT_PER_LANE; j++) {
     const int e = e0 + j * WAVE + lane;
-    const bool b = e < N && ((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] & (TS_BUSY_BIT << phase));
-    const uint64_t m = __ballot(b);
+    const uint32_t w = e < N ? (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] : 0u;
+    const bool b = (w & (TS_BUSY_BIT << phase)) != 0;
+    const int k = (int)(w >> TS_KIND_SHIFT);
     bmask |= (uint32_t)b << j;
-    pre[j] = __popcll(m & ((1ull << lane) - 1));
-    if (lane == 0) wave_tot[wv][j] = __popcll(m);
+    kinds |= (uint32_t)k << (2 * j);
+    pre[j] = 0;
+#pragma unroll
+    for (int c = 0; c < BUSY_CLASSES; c++) {
+      const uint64_t m = __ballot(b && k == c);
+      if (b && k == c) pre[j] = __popcll(m & ((1ull << lane) - 1));
+      if (lane == 0) wave_tot[wv][j][c] = __popcll(m);
+    }
   }
   __syncthreads();
-  int before = 0, total = 0;
+  int before[BUSY_CLASSES] = {}, total[BUSY_CLASSES] = {};
   for (int w = 0; w < 4; w++)
-    for (int j = 0; j < COMPACT_PER_LANE; j++) {
-      const int t = wave_tot[w][j];
-      if (w < wv) before += t;
-      total += t;
-    }
-  if (threadIdx.x == 0) seg_base = total ? atomicAdd(count, total) : 0;
+    for (int j = 0; j < COMPACT_PER_LANE; j++)
+#pragma unroll
+      for (int c = 0; c < BUSY_CLASSES; c++) {
+        const int t = wave_tot[w][j][c];
+        if (w < wv) before[c] += t;
+        total[c] += t;
+      }
+  if (threadIdx.x < BUSY_CLASSES) {
+    int tot = 0;
+#pragma unroll
+    for (int c = 0; c < BUSY_CLASSES; c++) if (c == (int)threadIdx.x) tot = total[c];
+    seg_base[threadIdx.x] = tot ? atomicAdd(count + threadIdx.x, tot) : 0;
+  }
   __syncthreads();
-  int off = seg_base + before;
+  int off[BUSY_CLASSES];
+#pragma unroll
+  for (int c = 0; c < BUSY_CLASSES; c++) off[c] = seg_base[c] + before[c];
 #pragma unroll
   for (int j = 0; j < COMPACT_PER_LANE; j++) {
-    if (bmask >> j & 1u) rows[off + pre[j]] = e0 + j * WAVE + lane;
-    off += wave_tot[wv][j];
+    const int k = (int)(kinds >> (2 * j) & 3u);
+    int o = 0;
+#pragma unroll
+    for (int c = 0; c < BUSY_CLASSES; c++) { if (c == k) o = off[c]; off[c] += wave_tot[wv][j][c]; }
+    if (bmask >> j & 1u) rows[(size_t)k * N + o + pre[j]] = e0 + j * WAVE + lane;
   }
 }
 
 #ifndef SAG_BUSY_PRIO
 #define SAG_BUSY_PRIO 0
 #endif
-#ifndef SAG_BUSY_ENVS
-#define SAG_BUSY_ENVS 64  // envs per busy wavefront
-#endif
-#ifndef SAG_CAR_BUSY_ENVS
-#define SAG_CAR_BUSY_ENVS SAG_BUSY_ENVS
-#endif
-__host__ __device__ constexpr int busy_envs(int robot) { return robot == SAG_ROBOT_CAR ? SAG_CAR_BUSY_ENVS : SAG_BUSY_ENVS; }
+// Envs per busy wavefront.  A busy wavefront runs for 0.1 (Point) to 0.4 ms (Car) whatever its envs do (every loop of the contact
+// code is taken by some lane of 64), and the chip holds `slots` of them at once: a launch of W wavefronts takes ceil(W / slots)
+// rounds, and the last, part-filled round costs a whole one (Car, 4 M envs: 6300 wavefronts on ~1900 slots = 3.3 rounds took 1.83 ms
+// where the work / slots is 1.33 ms; tools/busy_timeline.py).  So the wavefronts take FEWER envs each, just enough to fill the
+// rounds that 64 per wavefront would need anyway: the divergence union of each shrinks and no round runs part-filled.
+constexpr int BUSY_MIN_ENVS = 32;
+__host__ __device__ inline int busy_wave_envs(int count, int slots) {
+  const long long full = 64LL * slots;
+  const long long rounds = (count + full - 1) / full;
+  const long long cap = rounds * slots;   // wavefronts of those rounds
+  const int e = cap > 0 ? (int)((count + cap - 1) / cap) : 64;
+  return e < BUSY_MIN_ENVS ? BUSY_MIN_ENVS : (e > 64 ? 64 : e);
+}
+// blocks a launch must provide for any busy count <= N
+inline int busy_grid(int N, int fixed, int slots) {
+  if (fixed > 0) return (N + fixed - 1) / fixed + BUSY_CLASSES;   // (one part-filled wavefront per kind)
+  const long long a = ((long long)N + BUSY_MIN_ENVS - 1) / BUSY_MIN_ENVS, b = ((long long)N + 63) / 64 + slots;
+  return (int)(a < b ? a : b) + BUSY_CLASSES;
+}
 #ifndef SAG_CAR_BUSY_MIN_WAVES
 #define SAG_CAR_BUSY_MIN_WAVES SAG_STEP_MIN_WAVES
 #endif
 template <int ROBOT, bool HAS_BTN, bool HAS_TBOX>
 __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_BUSY_MIN_WAVES : SAG_STEP_MIN_WAVES) void k_step_busy(StepArgs p) {
+#ifdef SAG_WAVE_TIMES
+  const unsigned long long wt0 = wall_clock64();
+#endif
 #ifndef SAG_BUSY_LDS_PAD
 #define SAG_BUSY_LDS_PAD 0
 #endif
@@ -2349,16 +2464,27 @@ __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_BUSY_MIN_WAV
   // kernel's wavefronts that share their SIMDs
   __builtin_amdgcn_s_setprio(SAG_BUSY_PRIO);
 #endif
-  constexpr int BE = busy_envs(ROBOT);
-  const int lane = threadIdx.x, c0 = blockIdx.x * BE;
-  const int count = *p.count;
-  if (c0 >= count) return;
+  // the lists of the kinds one after the other, the expensive kinds first (busy_class_order); a kind's last wavefront may be part-filled
+  int b = blockIdx.x, cls = -1, count = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < BUSY_CLASSES; k++) total += p.count[k];
+  const int BE = p.busy_envs > 0 ? p.busy_envs : busy_wave_envs(total, p.busy_slots);
+#pragma unroll
+  for (int k = 0; k < BUSY_CLASSES; k++) {
+    const int c = busy_class_order(k), n = p.count[c], w = (n + BE - 1) / BE;
+    if (cls < 0) { if (b < w) { cls = c; count = n; } else b -= w; }
+  }
+  if (cls < 0) return;
+  const int lane = threadIdx.x, c0 = b * BE;
   const int nval = min(BE, count - c0);
   const bool live = lane < nval;
-  const int i = p.rows[c0 + (live ? lane : 0)];
+  const int i = p.rows[(size_t)cls * p.N + c0 + (live ? lane : 0)];
   rows[lane] = i;
   __syncthreads();
   step_body<ROBOT, HAS_BTN, HAS_TBOX, MODE_BUSY>(p, lds, lane, i, live, 0, nval, 0ull, rows);
+#ifdef SAG_WAVE_TIMES
+  if (lane == 0 && blockIdx.x < WT_MAX) { g_wt[blockIdx.x][0] = wt0; g_wt[blockIdx.x][1] = wall_clock64(); }
+#endif
 }
 
 // hot records of every env from the group-major state (after an install: all envs start busy)
