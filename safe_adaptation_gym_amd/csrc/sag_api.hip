@@ -65,6 +65,7 @@ struct sag_ctx {
   // consumes list[phase] and its classification appends list[phase ^ 1]; k_compact rebuilds
   // list[phase] from the busy bits whenever state was installed from outside (list_valid = false)
   int32_t* d_rows = nullptr; int32_t* d_count = nullptr;
+  uint8_t* d_kind = nullptr;   // [N] kind of every busy env (BUSY_CLASSES)
   bool list_valid = false;
   int count_flip = 0;          // which of the counter sets 2 and 3 of d_count this step's compaction fills
   int32_t* last_count = nullptr;
@@ -104,6 +105,7 @@ struct sag_ctx {
   int busy_e = 64;       // SAG_BUSY_E: envs per busy wavefront (0 = balanced over busy_slots: busy_wave_envs - measured slower, see there)
   int busy_slots = 0;    // SAG_BUSY_SLOTS: busy wavefronts resident at once (0 = 8 per CU: two per SIMD)
   int busy_kinds = 1;    // SAG_BUSY_KINDS=0: one busy list instead of one per kind (A/B)
+  int kinds_min = -1;    // SAG_BUSY_KINDS_MIN: busy envs of the step before above which the kinds are used (default: 64 per resident slot; tests: 0)
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
 };
@@ -298,7 +300,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     while (epw > (dg ? 8 : 16) && (c->N + epw - 1) / epw < (dg ? 1 : 4) * c->n_cu) epw >>= 1;
     if (c->epw_override > 0) epw = c->epw_override;
     a.envs_per_wave = epw < 1 ? 1 : (epw > 64 ? 64 : epw);
-    a.busy_envs = c->busy_e; a.busy_kinds = c->busy_kinds;
+    a.busy_envs = c->busy_e; a.busy_kinds = c->busy_kinds; a.kind = c->d_kind; a.busy_total = c->d_count + 4 * BUSY_CLASSES;
     a.busy_slots = c->busy_slots > 0 ? c->busy_slots : 8 * c->n_cu;
   }
   c->phase_used = c->phase;
@@ -344,13 +346,13 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     if (!c->inkernel_list) {
       // two counters used alternately: this step's compaction zeroes the one the next step will use
       a.count = c->d_count + (2 + c->count_flip) * BUSY_CLASSES;
-      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->N, a.phase,
-                         a.rows, a.count, c->d_count + (2 + (c->count_flip ^ 1)) * BUSY_CLASSES);
+      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
+                         a.rows, a.count, c->d_count + (2 + (c->count_flip ^ 1)) * BUSY_CLASSES, a.busy_total, c->kinds_min >= 0 ? c->kinds_min : 64 * a.busy_slots);
       c->count_flip ^= 1;
     } else if (!c->list_valid) {
       HIPCHK(c, hipMemsetAsync(a.count, 0, BUSY_CLASSES * sizeof(int32_t), c->stream));
-      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->N, a.phase,
-                         a.rows, a.count, (int32_t*)nullptr);
+      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
+                         a.rows, a.count, (int32_t*)nullptr, a.busy_total, c->kinds_min >= 0 ? c->kinds_min : 64 * a.busy_slots);
     }
     c->last_count = a.count;
     c->list_valid = true;
@@ -511,6 +513,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   if (const char* e = getenv("SAG_BUSY_E")) c->busy_e = atoi(e) > 64 ? 64 : atoi(e);
   if (const char* e = getenv("SAG_BUSY_SLOTS")) c->busy_slots = atoi(e);
   if (const char* e = getenv("SAG_BUSY_KINDS")) c->busy_kinds = atoi(e) != 0;
+  if (const char* e = getenv("SAG_BUSY_KINDS_MIN")) c->kinds_min = atoi(e);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -519,8 +522,10 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   CREATE_CHK(hipMalloc(&c->I, icount(N) * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->G, N * 3 * NBODY * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->d_rows, 2 * BUSY_CLASSES * N * sizeof(int32_t)));
-  CREATE_CHK(hipMalloc(&c->d_count, 4 * BUSY_CLASSES * sizeof(int32_t)));
-  CREATE_CHK(hipMemset(c->d_count, 0, 4 * BUSY_CLASSES * sizeof(int32_t)));
+  CREATE_CHK(hipMalloc(&c->d_kind, N));
+  CREATE_CHK(hipMemset(c->d_kind, 0, N));
+  CREATE_CHK(hipMalloc(&c->d_count, (4 * BUSY_CLASSES + 1) * sizeof(int32_t)));   // (+ the env count of the last busy launch)
+  CREATE_CHK(hipMemset(c->d_count, 0, (4 * BUSY_CLASSES + 1) * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->L_f, N * SAG_REC_FLOATS * sizeof(float)));
   CREATE_CHK(hipMalloc(&c->L_i, N * SAG_REC_INTS * sizeof(int32_t)));
   CREATE_CHK(hipMalloc(&c->st_f, N * SAG_REC_FLOATS * sizeof(float)));
@@ -562,7 +567,7 @@ int sag_destroy(sag_ctx* c) {
   (void)hipSetDevice(c->cfg.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-  void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
+  void* bufs[] = {c->S, c->I, c->G, c->d_rows, c->d_count, c->d_kind, c->L_f, c->L_i, c->st_f, c->st_i, c->st_ids, c->d_act, c->d_noise,
                   c->d_tape, c->d_obs, c->d_rew, c->d_cost, c->d_done, c->d_met, c->d_used, c->scratch, c->d_rgb, c->d_dr, c->d_dg_sched, c->d_hot,
                   c->d_ext_cc, c->d_ext_btn};
   for (void* b : bufs) if (b) (void)hipFree(b);

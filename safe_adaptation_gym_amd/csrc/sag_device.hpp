@@ -116,7 +116,9 @@ struct StepArgs {
   int envs_per_wave;  // single-launch form (k_step): 8..64 envs per wavefront, by batch size
   int busy_envs;      // split form (k_step_busy): envs per busy wavefront, or 0 = balanced over `busy_slots` (busy_wave_envs)
   int busy_slots;     // busy wavefronts the chip holds at once
-  int busy_kinds;     // 1: the busy list is kept by kind (TS_KIND_SHIFT); 0: one list (SAG_BUSY_KINDS=0, A/B)
+  int busy_kinds;     // 1: the busy list is kept by kind (BUSY_CLASSES); 0: one list (SAG_BUSY_KINDS=0, A/B)
+  uint8_t* kind;      // [N] kind of every busy env, for the next step's compaction
+  int32_t* busy_total;  // the busy launch leaves its env count here
   float* S;          // [DEV_GROUPS][N] float4 (see didx)
   int32_t* I;        // tstate [N], then (meta, step, envid, flags) [N] int4 (see iaddr)
   int32_t N;
@@ -988,15 +990,18 @@ enum { MODE_ALL = 0, MODE_QUIET = 1, MODE_BUSY = 2, MODE_POST = 3 };
 // writes bit 28 + (phase ^ 1), so the QUIET launch cannot re-flag an env for the BUSY launch of
 // the same step
 constexpr uint32_t TS_BUSY_BIT = 1u << 28;
-// tstate bits 30..31: the KIND of a busy env = which walks of the contact code its robot is within reach of - bit 0 the task object,
-// bit 1 a static circle (pillar / button); neither: vases, or only bodies still moving.  A hint for the order of the busy list only
-// (busy_class_order): a busy wavefront executes every loop that ANY of its 64 lanes takes, in every substep, so wavefronts of one
-// kind each skip the other kinds' walks (Car / push_box, 4 M envs: mean busy wavefront 416 -> 275 us when the list is sorted by kind;
-// tools/busy_sort_probe.py).  One copy, written with the NEXT step's busy bit; results never depend on it.
-constexpr uint32_t TS_KIND_SHIFT = 30;
-constexpr int BUSY_CLASSES = 4;
-// launch order of the classes, most expensive walk first (the cheap wavefronts then fill the last round): both, object, static, neither
-__host__ __device__ constexpr int busy_class_order(int k) { return k == 0 ? 3 : (k == 1 ? 1 : (k == 2 ? 2 : 0)); }
+// The KIND of a busy env = which walks of the contact code its robot is within reach of - bit 0 the task object, bit 1 a static
+// circle (pillar / button), bit 2 a vase or any body still moving - as a byte per env (StepArgs::kind, written with the NEXT step's
+// busy bit).  A hint for the order of the busy list only: a busy wavefront executes every loop that ANY of its 64 lanes takes, in every
+// substep, so wavefronts of one kind each skip the other kinds' walks (Car / push_box, 4 M envs: mean busy wavefront 416 -> 275 us
+// when the list is sorted by bits 0 and 1, tools/busy_sort_probe.py).  The tests are the busy classification's own (reach bounds
+// that hold for the whole step), so a wavefront of a kind can never meet a walk its kind excludes; results never depend on the kind.
+constexpr int BUSY_CLASSES = 8;
+// launch order of the classes, most expensive walks first (the cheap wavefronts then fill the last round)
+__host__ __device__ constexpr int busy_class_order(int k) {
+  constexpr int order[BUSY_CLASSES] = {7, 5, 3, 1, 6, 4, 2, 0};
+  return order[k];
+}
 
 // Car: 1 / inertia of the spinning parts (joint damping implicit: I + h d); per floor-friction element (L / R the
 // wheels' rolling directions, T their merged lateral element, X / Y the caster's: oracle car_floor_friction) the
@@ -1800,7 +1805,8 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
     const float amax = CAR ? GRAV : 1.05f * gear * PT_FLIM / PT_MASS;
     const float reach = sqrtf(R.vx * R.vx + R.vy * R.vy) * T + amax * T * T + 0.005f;
     bool busy = awake != 0 || (HAS_TBOX && task == SAG_TASK_HAUL_BOX);
-    bool near_obj = false, near_static = false;   // (the kind, TS_KIND_SHIFT)
+    bool near_obj = false, near_static = false;   // (the kind: BUSY_CLASSES)
+    const bool moving = busy;
     const float rr = my_bound + reach;
     // Point: bounding circles first, then the footprint itself.  The robot is inside circle A (its sphere,
     // r .1) and circle B (around the arrow box at +.1 along the heading, r .05 sqrt 2); within the step
@@ -1845,11 +1851,12 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
         near_static |= on && (dx * dx + dyy * dyy <= (fa + sr) * (fa + sr) || ex * ex + ey * ey <= (fb + sr) * (fb + sr));
       } else near_static |= on && dx * dx + dyy * dyy <= rs * rs;
     }
+    const bool near_vase = busy && !moving;    // (only the vase loop above has raised `busy` since)
     busy |= near_obj || near_static;
-    const uint32_t kind = p.busy_kinds ? (uint32_t)near_obj | (uint32_t)near_static << 1 : 0u;
+    const uint32_t kind = p.busy_kinds ? (uint32_t)near_obj | (uint32_t)near_static << 1 | (uint32_t)(near_vase || moving) << 2 : 0u;
     const uint32_t nbit = TS_BUSY_BIT << (p.phase ^ 1);
     tstate = busy ? (tstate | nbit) : (tstate & ~nbit);
-    tstate = (tstate & ~(3u << TS_KIND_SHIFT)) | (busy ? kind << TS_KIND_SHIFT : 0u);
+    if (busy && live && p.kind) p.kind[i] = (uint8_t)kind;
     busy_next = busy;
     // next step's busy list, built here instead of by a separate compaction pass: one atomic per
     // wavefront claims a contiguous chunk (a chunk keeps the env neighbourhood of its wavefront)
@@ -2361,66 +2368,58 @@ __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_QUIET_MIN_WA
                                                    min(WAVE, p.N - base), skip, nullptr);
 }
 
-// busy envs -> dense lists, one per kind (TS_KIND_SHIFT): rows [BUSY_CLASSES][N], count [BUSY_CLASSES].  Each 256-thread block covers
-// COMPACT_ENVS envs, orders its own busy ones of a kind by index (ballot + prefix) and claims a contiguous segment of that kind's list
-// with ONE atomic; segments of different blocks land in arbitrary order, which only affects which wavefront processes an env.  (The
-// atomics of a kind all hit one counter and serialise at ~10 ns each: with 1024 envs per block the launch took 51 us at 4 M envs,
-// 4096 atomics; 4096 envs per block quarters that.)
+// busy envs -> dense lists, one per kind: rows [BUSY_CLASSES][N], count [BUSY_CLASSES].  Each 256-thread block covers COMPACT_ENVS
+// envs, orders its own busy ones of a kind (ballot + prefix) and claims a contiguous segment of that kind's list with ONE atomic;
+// segments of different blocks land in arbitrary order, which only affects which wavefront processes an env.  (The atomics of a
+// kind all hit one counter and serialise at ~10 ns each: with 1024 envs per block the launch took 51 us at 4 M envs, 4096 atomics;
+// 4096 envs per block quarters that.)
 constexpr int COMPACT_PER_LANE = 16, COMPACT_ENVS = 256 * COMPACT_PER_LANE;
-__global__ __launch_bounds__(256) void k_compact(const int32_t* I, int N, int phase, int32_t* rows, int32_t* count,
-                                                  int32_t* zero_for_next) {
+// The kinds are only used once the busy launch of the step before needed more than one round of resident wavefronts (prev_total >
+// kinds_min): below that a step is as long as its slowest busy wavefront, and a wavefront of 64 envs of the most expensive kind is
+// slower than a mixed one (Car / push_box, 1 M envs: 0.73 -> 0.78 ms with kinds; from 1.5 M envs on 0.98 -> 0.81, 4 M 1.95 -> 1.45).
+__global__ __launch_bounds__(256) void k_compact(const int32_t* I, const uint8_t* kind, int N, int phase, int32_t* rows, int32_t* count,
+                                                  int32_t* zero_for_next, const int32_t* prev_total, int kinds_min) {
+  const bool use_kinds = *prev_total > kinds_min;
   // the counters the NEXT step's compaction will add to (saves a memset launch per step)
   if (zero_for_next && blockIdx.x == 0 && threadIdx.x < BUSY_CLASSES) zero_for_next[threadIdx.x] = 0;
-  __shared__ int wave_tot[4][COMPACT_PER_LANE][BUSY_CLASSES];
-  __shared__ int seg_base[BUSY_CLASSES];
+  __shared__ int wave_tot[4][BUSY_CLASSES];
+  __shared__ int wave_base[4][BUSY_CLASSES];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int e0 = blockIdx.x * COMPACT_ENVS + wv * (WAVE * COMPACT_PER_LANE);
-  uint32_t bmask = 0;        // bit j: env e0 + j * 64 + lane is busy
-  uint32_t kinds = 0;        // two bits per j: its kind
-  int pre[COMPACT_PER_LANE];
+  uint32_t bmask = 0;          // bit j: env e0 + j * 64 + lane is busy
+  uint64_t kinds = 0;          // four bits per j: its kind
+  int pre[COMPACT_PER_LANE];   // its place among the wavefront's envs of that kind
+  int run[BUSY_CLASSES] = {};
 #pragma unroll
   for (int j = 0; j < COMPACT_PER_LANE; j++) {
     const int e = e0 + j * WAVE + lane;
-    const uint32_t w = e < N ? (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] : 0u;
-    const bool b = (w & (TS_BUSY_BIT << phase)) != 0;
-    const int k = (int)(w >> TS_KIND_SHIFT);
+    const bool b = e < N && ((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] & (TS_BUSY_BIT << phase)) != 0;
+    const int k = b && use_kinds ? (int)kind[e] & (BUSY_CLASSES - 1) : 0;
     bmask |= (uint32_t)b << j;
-    kinds |= (uint32_t)k << (2 * j);
+    kinds |= (uint64_t)k << (4 * j);
     pre[j] = 0;
 #pragma unroll
     for (int c = 0; c < BUSY_CLASSES; c++) {
       const uint64_t m = __ballot(b && k == c);
-      if (b && k == c) pre[j] = __popcll(m & ((1ull << lane) - 1));
-      if (lane == 0) wave_tot[wv][j][c] = __popcll(m);
+      if (b && k == c) pre[j] = run[c] + __popcll(m & ((1ull << lane) - 1));
+      run[c] += __popcll(m);
     }
   }
+  if (lane == 0)
+#pragma unroll
+    for (int c = 0; c < BUSY_CLASSES; c++) wave_tot[wv][c] = run[c];
   __syncthreads();
-  int before[BUSY_CLASSES] = {}, total[BUSY_CLASSES] = {};
-  for (int w = 0; w < 4; w++)
-    for (int j = 0; j < COMPACT_PER_LANE; j++)
-#pragma unroll
-      for (int c = 0; c < BUSY_CLASSES; c++) {
-        const int t = wave_tot[w][j][c];
-        if (w < wv) before[c] += t;
-        total[c] += t;
-      }
   if (threadIdx.x < BUSY_CLASSES) {
-    int tot = 0;
-#pragma unroll
-    for (int c = 0; c < BUSY_CLASSES; c++) if (c == (int)threadIdx.x) tot = total[c];
-    seg_base[threadIdx.x] = tot ? atomicAdd(count + threadIdx.x, tot) : 0;
+    const int c = threadIdx.x;
+    const int total = wave_tot[0][c] + wave_tot[1][c] + wave_tot[2][c] + wave_tot[3][c];
+    int base = total ? atomicAdd(count + c, total) : 0;
+    for (int w = 0; w < 4; w++) { wave_base[w][c] = base; base += wave_tot[w][c]; }
   }
   __syncthreads();
-  int off[BUSY_CLASSES];
-#pragma unroll
-  for (int c = 0; c < BUSY_CLASSES; c++) off[c] = seg_base[c] + before[c];
 #pragma unroll
   for (int j = 0; j < COMPACT_PER_LANE; j++) {
-    const int k = (int)(kinds >> (2 * j) & 3u);
-    int o = 0;
-#pragma unroll
-    for (int c = 0; c < BUSY_CLASSES; c++) { if (c == k) o = off[c]; off[c] += wave_tot[wv][j][c]; }
-    if (bmask >> j & 1u) rows[(size_t)k * N + o + pre[j]] = e0 + j * WAVE + lane;
+    const int k = (int)(kinds >> (4 * j) & 15u);
+    if (bmask >> j & 1u) rows[(size_t)k * N + wave_base[wv][k] + pre[j]] = e0 + j * WAVE + lane;
   }
 }
 
@@ -2469,6 +2468,7 @@ __global__ __launch_bounds__(WAVE, ROBOT == SAG_ROBOT_CAR ? SAG_CAR_BUSY_MIN_WAV
 #pragma unroll
   for (int k = 0; k < BUSY_CLASSES; k++) total += p.count[k];
   const int BE = p.busy_envs > 0 ? p.busy_envs : busy_wave_envs(total, p.busy_slots);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.busy_total = total;   // (for the next step's k_compact)
 #pragma unroll
   for (int k = 0; k < BUSY_CLASSES; k++) {
     const int c = busy_class_order(k), n = p.count[c], w = (n + BE - 1) / BE;

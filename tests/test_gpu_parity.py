@@ -821,22 +821,33 @@ def test_split_launch_equals_single_launch(nat, monkeypatch, robot, task):
     rf, ri = bu.sample_records_native(robot, task, n, seed=4000)
   rf = bu.goal_beyond_box(rf, ri) if task != 'haul_box' else rf
   ctxs = []
-  for flag in ('0', '1'):
+  # single launch; split with one busy list (what a batch this small gets); split with the busy list kept by KIND of contact (what
+  # batches get whose busy launch needs more than one round of resident wavefronts: k_compact) - the order of the list and the
+  # grouping of envs into wavefronts must not show in any result
+  for flag, kinds_min in (('0', None), ('1', None), ('1', '0')):
     monkeypatch.setenv('SAG_SPLIT', flag)
+    if kinds_min is None:
+      monkeypatch.delenv('SAG_BUSY_KINDS_MIN', raising=False)
+    else:
+      monkeypatch.setenv('SAG_BUSY_KINDS_MIN', kinds_min)
     c = nat.Context(robot, n, seed=77)
     c.set_layout(rf, ri)
     ctxs.append(c)
+  monkeypatch.delenv('SAG_BUSY_KINDS_MIN', raising=False)
   rng = np.random.RandomState(3)
   busy_share = []
   for t in range(T):
     s_rf, s_ri = ctxs[0].get_state()
     act = bu.pursuit_actions(s_rf, s_ri, rng, robot=robot)
     outs = [c.step(act) for c in ctxs]          # counter-based noise: same key, env id, step
-    for a, b in zip(outs[0][:5], outs[1][:5]):
-      np.testing.assert_array_equal(a, b, err_msg=f'step {t}')
-    sa, sb = ctxs[0].get_state(), ctxs[1].get_state()
-    np.testing.assert_array_equal(sa[0], sb[0], err_msg=f'state step {t}')
-    np.testing.assert_array_equal(sa[1], sb[1])
+    sa = ctxs[0].get_state()
+    for other, c in zip(outs[1:], ctxs[1:]):
+      for a, b in zip(outs[0][:5], other[:5]):
+        np.testing.assert_array_equal(a, b, err_msg=f'step {t}')
+      sb = c.get_state()
+      np.testing.assert_array_equal(sa[0], sb[0], err_msg=f'state step {t}')
+      np.testing.assert_array_equal(sa[1], sb[1])
+    assert ctxs[1].busy_count() == ctxs[2].busy_count()
     if t in (40, 41, 80):
       # state installed from outside between steps (partial reset to the installed layout, then a
       # set_state of a few envs): the busy lists and hot records of the split form must follow

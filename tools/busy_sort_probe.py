@@ -46,8 +46,10 @@ t, env, work, trips = report('as sampled')
 kind = np.full(envs, -1, np.int8)
 live = env >= 0
 k = (work[:, :, 2] > 0).astype(np.int8) + 2 * (work[:, :, 0] > 0).astype(np.int8)
+if os.environ.get('PROBE_FINE'):   # a third bit: the robot touched a vase or a free body moved
+  k = k + 4 * ((work[:, :, 1] > 0) | (work[:, :, 5] > 0)).astype(np.int8)
 kind[env[live]] = k[live]
-print('busy envs by kind (0 vases / other, 1 object, 2 static, 3 both):', np.bincount(kind[kind >= 0], minlength=4), flush=True)
+print('busy envs by kind (bit 0 object, bit 1 static, bit 2 vases / moving bodies):', np.bincount(kind[kind >= 0], minlength=4), flush=True)
 order = np.argsort(-kind.astype(np.int32), kind='stable').astype(np.int32)
 CH = 1 << 18
 for a in range(0, envs, CH):          # re-install in sorted order, a chunk at a time (host memory)
