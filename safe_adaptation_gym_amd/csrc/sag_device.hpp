@@ -2390,11 +2390,19 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, const uint8_t
   uint64_t kinds = 0;          // four bits per j: its kind
   int pre[COMPACT_PER_LANE];   // its place among the wavefront's envs of that kind
   int run[BUSY_CLASSES] = {};
+  // (both columns read for all 16 envs of the lane before anything is used: one memory round trip, not two per env)
+  uint32_t tw[COMPACT_PER_LANE];
+  uint8_t kb[COMPACT_PER_LANE];
 #pragma unroll
   for (int j = 0; j < COMPACT_PER_LANE; j++) {
     const int e = e0 + j * WAVE + lane;
-    const bool b = e < N && ((uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] & (TS_BUSY_BIT << phase)) != 0;
-    const int k = b && use_kinds ? (int)kind[e] & (BUSY_CLASSES - 1) : 0;
+    tw[j] = e < N ? (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] : 0u;
+    kb[j] = e < N && use_kinds ? kind[e] : (uint8_t)0;
+  }
+#pragma unroll
+  for (int j = 0; j < COMPACT_PER_LANE; j++) {
+    const bool b = (tw[j] & (TS_BUSY_BIT << phase)) != 0;
+    const int k = b ? (int)kb[j] & (BUSY_CLASSES - 1) : 0;
     bmask |= (uint32_t)b << j;
     kinds |= (uint64_t)k << (4 * j);
     pre[j] = 0;
