@@ -1,3 +1,4 @@
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_quick -o q -- python3 $GRAFT_REPO_ROOT/tools/busy_e_sweep.py one go_to_goal point 4194304 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT; f=$(ls gpurun_out/prof_quick/*/*kernel_stats.csv gpurun_out/prof_quick/*kernel_stats.csv 2>/dev/null | head -1); grep -E "k_compact|k_step_busy|k_step_quiet" $f
+for cfg in "push_box car 4194304" "go_to_goal point 4194304"; do
+  echo "$cfg default $(python tools/busy_e_sweep.py one $cfg)"
+  for q in 32 48 64 80 96 128; do echo "$cfg cu_split=$q $(SAG_CU_SPLIT=$q python tools/busy_e_sweep.py one $cfg)"; done
+done
