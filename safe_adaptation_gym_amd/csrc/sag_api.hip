@@ -104,7 +104,7 @@ struct sag_ctx {
   int epw_override = 0;  // SAG_EPW (read once at create): envs per wavefront of the single-launch form
   int busy_e = 64;       // SAG_BUSY_E: envs per busy wavefront (0 = balanced over busy_slots: busy_wave_envs - measured slower, see there)
   int busy_slots = 0;    // SAG_BUSY_SLOTS: busy wavefronts resident at once (0 = 8 per CU: two per SIMD)
-  int busy_kinds = 1;    // SAG_BUSY_KINDS=0: one busy list instead of one per kind (A/B)
+  int busy_kinds = -1;   // SAG_BUSY_KINDS: 1 = the busy list by kind of contact, 0 = one list; default: the Car (the Point's step is its quiet kernel: no gain)
   int kinds_min = -1;    // SAG_BUSY_KINDS_MIN: busy envs of the step before above which the kinds are used (default: 64 per resident slot; tests: 0)
   bool split = true;   // QUIET + BUSY launches; SAG_SPLIT=0/1 in the environment forces the form
   std::string err;
@@ -300,7 +300,7 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     while (epw > (dg ? 8 : 16) && (c->N + epw - 1) / epw < (dg ? 1 : 4) * c->n_cu) epw >>= 1;
     if (c->epw_override > 0) epw = c->epw_override;
     a.envs_per_wave = epw < 1 ? 1 : (epw > 64 ? 64 : epw);
-    a.busy_envs = c->busy_e; a.busy_kinds = c->busy_kinds; a.kind = c->d_kind; a.busy_total = c->d_count + 4 * BUSY_CLASSES;
+    a.busy_envs = c->busy_e; a.busy_kinds = c->busy_kinds < 0 ? c->cfg.robot == SAG_ROBOT_CAR : c->busy_kinds; a.kind = a.busy_kinds ? c->d_kind : nullptr; a.busy_total = c->d_count + 4 * BUSY_CLASSES;
     a.busy_slots = c->busy_slots > 0 ? c->busy_slots : 8 * c->n_cu;
   }
   c->phase_used = c->phase;
@@ -346,13 +346,21 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
     if (!c->inkernel_list) {
       // two counters used alternately: this step's compaction zeroes the one the next step will use
       a.count = c->d_count + (2 + c->count_flip) * BUSY_CLASSES;
-      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
-                         a.rows, a.count, c->d_count + (2 + (c->count_flip ^ 1)) * BUSY_CLASSES, a.busy_total, c->kinds_min >= 0 ? c->kinds_min : 64 * a.busy_slots);
+      if (a.busy_kinds)
+        hipLaunchKernelGGL(k_compact<true>, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
+                           a.rows, a.count, c->d_count + (2 + (c->count_flip ^ 1)) * BUSY_CLASSES, a.busy_total, c->kinds_min >= 0 ? c->kinds_min : 64 * a.busy_slots);
+      else
+        hipLaunchKernelGGL(k_compact<false>, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
+                           a.rows, a.count, c->d_count + (2 + (c->count_flip ^ 1)) * BUSY_CLASSES, a.busy_total, 0);
       c->count_flip ^= 1;
     } else if (!c->list_valid) {
       HIPCHK(c, hipMemsetAsync(a.count, 0, BUSY_CLASSES * sizeof(int32_t), c->stream));
-      hipLaunchKernelGGL(k_compact, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
-                         a.rows, a.count, (int32_t*)nullptr, a.busy_total, c->kinds_min >= 0 ? c->kinds_min : 64 * a.busy_slots);
+      if (a.busy_kinds)
+        hipLaunchKernelGGL(k_compact<true>, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
+                           a.rows, a.count, (int32_t*)nullptr, a.busy_total, c->kinds_min >= 0 ? c->kinds_min : 64 * a.busy_slots);
+      else
+        hipLaunchKernelGGL(k_compact<false>, dim3((c->N + COMPACT_ENVS - 1) / COMPACT_ENVS), dim3(256), 0, c->stream, c->I, c->d_kind, c->N, a.phase,
+                           a.rows, a.count, (int32_t*)nullptr, a.busy_total, 0);
     }
     c->last_count = a.count;
     c->list_valid = true;
@@ -512,7 +520,7 @@ int sag_create(const sag_config* cfg, sag_ctx** out) {
   if (const char* e = getenv("SAG_EPW")) c->epw_override = atoi(e);
   if (const char* e = getenv("SAG_BUSY_E")) c->busy_e = atoi(e) > 64 ? 64 : atoi(e);
   if (const char* e = getenv("SAG_BUSY_SLOTS")) c->busy_slots = atoi(e);
-  if (const char* e = getenv("SAG_BUSY_KINDS")) c->busy_kinds = atoi(e) != 0;
+  if (const char* e = getenv("SAG_BUSY_KINDS")) c->busy_kinds = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("SAG_BUSY_KINDS_MIN")) c->kinds_min = atoi(e);
   {
     hipDeviceProp_t prop;

@@ -2377,9 +2377,13 @@ constexpr int COMPACT_PER_LANE = 16, COMPACT_ENVS = 256 * COMPACT_PER_LANE;
 // The kinds are only used once the busy launch of the step before needed more than one round of resident wavefronts (prev_total >
 // kinds_min): below that a step is as long as its slowest busy wavefront, and a wavefront of 64 envs of the most expensive kind is
 // slower than a mixed one (Car / push_box, 1 M envs: 0.73 -> 0.78 ms with kinds; from 1.5 M envs on 0.98 -> 0.81, 4 M 1.95 -> 1.45).
+// KINDS = false (contexts that keep one list - the Point, whose step is its quiet kernel and gains nothing from the kinds): kind 0
+// for all, one ballot per env row instead of eight.
+template <bool KINDS>
 __global__ __launch_bounds__(256) void k_compact(const int32_t* I, const uint8_t* kind, int N, int phase, int32_t* rows, int32_t* count,
                                                   int32_t* zero_for_next, const int32_t* prev_total, int kinds_min) {
-  const bool use_kinds = *prev_total > kinds_min;
+  constexpr int NC = KINDS ? BUSY_CLASSES : 1;
+  const bool use_kinds = KINDS && *prev_total > kinds_min;
   // the counters the NEXT step's compaction will add to (saves a memset launch per step)
   if (zero_for_next && blockIdx.x == 0 && threadIdx.x < BUSY_CLASSES) zero_for_next[threadIdx.x] = 0;
   __shared__ int wave_tot[4][BUSY_CLASSES];
@@ -2397,7 +2401,7 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, const uint8_t
   for (int j = 0; j < COMPACT_PER_LANE; j++) {
     const int e = e0 + j * WAVE + lane;
     tw[j] = e < N ? (uint32_t)I[iaddr(DI_TSTATE, (size_t)N, (size_t)e)] : 0u;
-    kb[j] = e < N && use_kinds ? kind[e] : (uint8_t)0;
+    kb[j] = KINDS && e < N && use_kinds ? kind[e] : (uint8_t)0;
   }
 #pragma unroll
   for (int j = 0; j < COMPACT_PER_LANE; j++) {
@@ -2407,7 +2411,7 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, const uint8_t
     kinds |= (uint64_t)k << (4 * j);
     pre[j] = 0;
 #pragma unroll
-    for (int c = 0; c < BUSY_CLASSES; c++) {
+    for (int c = 0; c < NC; c++) {
       const uint64_t m = __ballot(b && k == c);
       if (b && k == c) pre[j] = run[c] + __popcll(m & ((1ull << lane) - 1));
       run[c] += __popcll(m);
@@ -2415,9 +2419,9 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, const uint8_t
   }
   if (lane == 0)
 #pragma unroll
-    for (int c = 0; c < BUSY_CLASSES; c++) wave_tot[wv][c] = run[c];
+    for (int c = 0; c < NC; c++) wave_tot[wv][c] = run[c];
   __syncthreads();
-  if (threadIdx.x < BUSY_CLASSES) {
+  if (threadIdx.x < NC) {
     const int c = threadIdx.x;
     const int total = wave_tot[0][c] + wave_tot[1][c] + wave_tot[2][c] + wave_tot[3][c];
     int base = total ? atomicAdd(count + c, total) : 0;

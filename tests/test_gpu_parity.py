@@ -828,12 +828,15 @@ def test_split_launch_equals_single_launch(nat, monkeypatch, robot, task):
     monkeypatch.setenv('SAG_SPLIT', flag)
     if kinds_min is None:
       monkeypatch.delenv('SAG_BUSY_KINDS_MIN', raising=False)
+      monkeypatch.delenv('SAG_BUSY_KINDS', raising=False)
     else:
       monkeypatch.setenv('SAG_BUSY_KINDS_MIN', kinds_min)
+      monkeypatch.setenv('SAG_BUSY_KINDS', '1')     # (the default keeps kinds for the Car only)
     c = nat.Context(robot, n, seed=77)
     c.set_layout(rf, ri)
     ctxs.append(c)
   monkeypatch.delenv('SAG_BUSY_KINDS_MIN', raising=False)
+  monkeypatch.delenv('SAG_BUSY_KINDS', raising=False)
   rng = np.random.RandomState(3)
   busy_share = []
   for t in range(T):
