@@ -867,6 +867,51 @@ def test_split_launch_equals_single_launch(nat, monkeypatch, robot, task):
     c.close()
 
 
+def test_busy_lists_by_kind_at_scale_equal_single_launch(nat, monkeypatch):
+  """The path large Car batches take (busy lists by kind of contact, hundreds of compaction blocks, thousands of busy wavefronts per
+  kind, the gate on the busy count of the step before) against the single launch, bit for bit: 600 000 Car / push_box envs, pursuit
+  actions for 24 steps.  The gate is lowered to 8192 busy envs (production: 64 per resident slot = 131 072, i.e. batches beyond ~1.5 M
+  envs) so that it opens during the rollout as it does in production: the first steps run on one list, the later ones on eight."""
+  if os.environ.get('SAG_HOSTEMU'):
+    pytest.skip('600 000 envs: a GPU-sized case (the host emulator runs the same lists at 1500 envs)')
+  n, T = 600_000, 24
+  from safe_adaptation_gym_amd import benchmark
+  tid = benchmark.TASKS['push_box'].TASK_ID
+  rf, ri, st = nat.sample_layouts('car', 7000 + np.arange(n, dtype=np.int64), tid, nthreads=min(16, len(os.sched_getaffinity(0))))
+  assert not st.any()
+  rf = bu.goal_beyond_box(rf, ri)
+  ctxs = []
+  for split, kmin in (('0', None), ('1', '8192')):
+    monkeypatch.setenv('SAG_SPLIT', split)
+    if kmin is None:
+      monkeypatch.delenv('SAG_BUSY_KINDS_MIN', raising=False)
+    else:
+      monkeypatch.setenv('SAG_BUSY_KINDS_MIN', kmin)
+    c = nat.Context('car', n, seed=71)
+    c.set_layout(rf, ri)
+    ctxs.append(c)
+  monkeypatch.delenv('SAG_BUSY_KINDS_MIN', raising=False)
+  rng = np.random.RandomState(5)
+  busy = []
+  for t in range(T):
+    s_rf, s_ri = ctxs[0].get_state()
+    act = bu.pursuit_actions(s_rf, s_ri, rng, robot='car')
+    outs = [c.step(act) for c in ctxs]
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+      np.testing.assert_array_equal(a, b, err_msg=f'step {t}')
+    busy.append(ctxs[1].busy_count())
+  sb = ctxs[1].get_state()
+  s_rf, s_ri = ctxs[0].get_state()
+  np.testing.assert_array_equal(s_rf, sb[0])
+  np.testing.assert_array_equal(s_ri, sb[1])
+  assert busy[0] == n, 'after an install every env is busy'
+  assert sum(b > 8192 for b in busy[1:]) >= 8 and sum(0 < b <= 8192 for b in busy[1:]) >= 3, \
+      f'the rollout must run on one list first and on the lists by kind later: busy envs per step {busy}'
+  assert outs[0][2].sum() > 0
+  for c in ctxs:
+    c.close()
+
+
 def test_device_buffers_env_api(nat):
   """make(..., device_buffers=True) - the reference's make / reset / step surface with the results left
   in HBM (DeviceArray views, __cuda_array_interface__) and actions taken from HBM: the same numbers as the NumPy path
