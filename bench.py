@@ -477,11 +477,10 @@ def main(argv=None, run_factory=None, emit=print):
         t_lc = (time.perf_counter() - t0) / reps
         ms, cnt = cx.kernel_time_ms(reset=True)
         lc[str(n_lc)] = {'value': n_lc / t_lc, 'unit': 'env-evaluations/s', 'ms_per_call': t_lc * 1e3,
-                         'roofline': roofline_block(ALG_BYTES['lidar_cost'], n_lc, ms, ['k_lidar_cost_team<16>' if n_lc <= 16384 else 'k_lidar_cost_reg'], 'lidar_cost', cnt)}
+                         'roofline': roofline_block(ALG_BYTES['lidar_cost'], n_lc, ms, ['k_lidar_cost_team<16>' if n_lc <= 16384 else 'k_lidar_cost_team<4>'], 'lidar_cost', cnt)}
         cx.close()
       lc['note'] = ('sag_lidar_cost_device on n poses x 21 points resident in HBM, kernel-only time; bit-exact bins and cost flags vs the reference fixtures. '
-                    '4096 poses: k_lidar_cost_team<16> (16 lanes share a pose; [bin][pose] ds_max tile); 4 M poses: k_lidar_cost_reg (a lane per pose; one '
-                    '12-KB LDS region as staging area, [bin][lane] ds_max tile and transpose buffer)')
+                    '4096 poses: k_lidar_cost_team<16> (16 lanes share a pose; [bin][pose] ds_max tile); 4 M poses: k_lidar_cost_team<4> (4 lanes share a pose; 3-KB tile, eight wavefronts per SIMD)')
       res['c2_lidar_cost_only'] = lc
       c2.close()
     if not args.no_c2:

@@ -428,16 +428,25 @@ int launch_step(sag_ctx* c, const float* d_act, const float* d_noise, const uint
   return 0;
 }
 
-// Small batches (the reference's own 4096 poses): a team of lanes per pose, so that the chip is full and a pose's points
-// are not one serial chain (k_lidar_cost_team).  Large ones, a lane per pose: K <= 21 (the reference's point count) the
-// register-resident kernel at 13 wavefronts per CU, more points per env the LDS-staged one.  SAG_LIDAR_TEAM = 0 / 4 / 16
-// forces the team size (tests run every kernel on the same inputs), SAG_LIDAR_REG=0 the LDS-staged kernel (A/B).
+// A team of lanes per pose (k_lidar_cost_team): lane s of a team takes the points s, s + LPP, ...  Few poses (the reference's own
+// 4096): 16 lanes, so that the chip is full and a pose's points are not one serial chain; more poses, smaller teams - 8 up to 262 144
+// poses, 4 beyond (4 M poses x 21 points, kernel only: teams of 4 0.474 ms, of 8 0.502, of 2 0.641, of 16 0.684; the lane-per-pose
+// kernel with its points in registers 0.537, LDS-staged 0.792 - its 12.8 KB of staging / tile per wavefront hold it at three
+// wavefronts per SIMD, a team's 3-KB tile does not; profiles/r04_lidar_forms.txt).  SAG_LIDAR_TEAM = 0 / 2 / 4 / 8 / 16 forces the
+// form (0: a lane per pose - K <= 21 the register-resident kernel, more points per env or SAG_LIDAR_REG=0 the LDS-staged one;
+// the tests run every form on the same inputs).
 void launch_lidar_cost(sag_ctx* c, int n, int K, const float* d_robot, const float* d_pts, const uint8_t* d_grp, float hazard_size,
                        float* d_lid, int32_t* d_bins, uint8_t* d_cost) {
   static const bool use_reg = [] { const char* e = getenv("SAG_LIDAR_REG"); return !e || atoi(e) != 0; }();
-  int team = n <= 16384 ? 16 : (n <= 131072 ? 4 : 0);
+  int team = n <= 16384 ? 16 : (n <= 262144 ? 8 : 4);
   if (const char* e = getenv("SAG_LIDAR_TEAM")) team = atoi(e);
-  if (team >= 16)
+  if (team == 2)
+    hipLaunchKernelGGL(k_lidar_cost_team<2>, dim3((n + 31) / 32), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts, d_grp, hazard_size,
+                       d_lid, d_bins, d_cost);
+  else if (team == 8)
+    hipLaunchKernelGGL(k_lidar_cost_team<8>, dim3((n + 7) / 8), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts, d_grp, hazard_size,
+                       d_lid, d_bins, d_cost);
+  else if (team >= 16)
     hipLaunchKernelGGL(k_lidar_cost_team<16>, dim3((n + 3) / 4), dim3(WAVE), 0, c->stream, n, K, d_robot, d_pts, d_grp, hazard_size,
                        d_lid, d_bins, d_cost);
   else if (team >= 4)

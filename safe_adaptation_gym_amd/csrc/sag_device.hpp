@@ -1995,7 +1995,9 @@ __device__ __forceinline__ void step_body(const StepArgs& p, float* lds, const i
   //      rectangle has grown 1.01^j, its four words sit at stream position pos + 4 j), so the 64
   //      lanes test candidates j = base + lane at once and the first accepted one wins.
   {
-    uint64_t need_mask = __ballot(need_goal && !ABL(ABL_NO_RESAMPLE));
+    // (only lanes that carry an env: the padding lanes of a small batch all mirror env N - 1 and would each repeat ITS resample -
+    // 48 of them at 16 envs per wavefront, a 0.2-ms spike in every wavefront of the step in which that one env meets its goal)
+    uint64_t need_mask = __ballot(need_goal && live && !ABL(ABL_NO_RESAMPLE));
     while (need_mask) {
       const int src = __ffsll((unsigned long long)need_mask) - 1;
       need_mask &= need_mask - 1;
@@ -2740,7 +2742,10 @@ __global__ __launch_bounds__(WAVE) void k_lidar_cost(int n, int K, const float* 
   int cst = 0;
   if (live) {
     const float rxf = robot[i * 3], ryf = robot[i * 3 + 1], yawf = robot[i * 3 + 2];
-    const double rx = rxf, ry = ryf, cd = cos((double)yawf), sd = sin((double)yawf);
+    // (heading in fp32: 1e-7 rad of rotation error against the 7.9e-6 rad = 2e-5 bins inside which lidar_exact redoes the point in
+    // fp64; two fp64 range reductions + polynomials per lane were a sixth of the lane-per-pose kernel and half of a team lane's work)
+    float sdf, cdf; sincosf(yawf, &sdf, &cdf);
+    const double rx = rxf, ry = ryf, cd = cdf, sd = sdf;
     const float t2 = hazard_size * hazard_size;
     int* acc = reinterpret_cast<int*>(tile_a) + lane;
 #pragma unroll 1
@@ -2853,7 +2858,10 @@ __global__ __launch_bounds__(WAVE, 3) void k_lidar_cost_reg(int n, int K, const 
   int cst = 0;
   if (live) {
     const float rxf = robot[i * 3], ryf = robot[i * 3 + 1], yawf = robot[i * 3 + 2];
-    const double rx = rxf, ry = ryf, cd = cos((double)yawf), sd = sin((double)yawf);
+    // (heading in fp32: 1e-7 rad of rotation error against the 7.9e-6 rad = 2e-5 bins inside which lidar_exact redoes the point in
+    // fp64; two fp64 range reductions + polynomials per lane were a sixth of the lane-per-pose kernel and half of a team lane's work)
+    float sdf, cdf; sincosf(yawf, &sdf, &cdf);
+    const double rx = rxf, ry = ryf, cd = cdf, sd = sdf;
     const float t2 = hazard_size * hazard_size;
     int* acc = reinterpret_cast<int*>(tile) + lane;   // (a lane only touches its own column: no barrier before the loop)
 #pragma unroll
@@ -2937,7 +2945,10 @@ __global__ __launch_bounds__(WAVE) void k_lidar_cost_team(int n, int K, const fl
   __syncthreads();
   if (live) {
     const float rxf = robot[i * 3], ryf = robot[i * 3 + 1], yawf = robot[i * 3 + 2];
-    const double rx = rxf, ry = ryf, cd = cos((double)yawf), sd = sin((double)yawf);
+    // (heading in fp32: 1e-7 rad of rotation error against the 7.9e-6 rad = 2e-5 bins inside which lidar_exact redoes the point in
+    // fp64; two fp64 range reductions + polynomials per lane were a sixth of the lane-per-pose kernel and half of a team lane's work)
+    float sdf, cdf; sincosf(yawf, &sdf, &cdf);
+    const double rx = rxf, ry = ryf, cd = cdf, sd = sdf;
     const float t2 = hazard_size * hazard_size;
     int* acc = tile + pose;
     int cst = 0;

@@ -154,7 +154,7 @@ def test_committed_profile_covers_every_kernel_bench_names():
     pytest.skip('profiles/kernels.json was measured on other device sources (re-run tools/gpu_final.sh before the round ends)')
   names = list(prof['kernels'])
   want = (bench.step_kernels('point', 1 << 22) + bench.step_kernels('point', 4096) + bench.step_kernels('car', 1 << 22) +
-          bench.step_kernels('car', 4096) + bench.step_kernels('doggo', 4096) + ['k_lidar_cost_team<16>', 'k_lidar_cost_reg', 'k_render_rgb'])
+          bench.step_kernels('car', 4096) + bench.step_kernels('doggo', 4096) + ['k_lidar_cost_team<16>', 'k_lidar_cost_team<4>', 'k_render_rgb'])
   missing = [k for k in want if not any(k in n for n in names)]
   assert not missing, missing
   assert prof.get('doggo_flops_per_env_step', {}).get('fp64', 0) > 1e6

@@ -51,12 +51,13 @@ def _lidar_inputs(n, K, seed):
   return robot, pts, grp
 
 
-@pytest.mark.parametrize('team', [None, 0, 4, 16])
+@pytest.mark.parametrize('team', [None, 0, 2, 4, 8, 16])
 @pytest.mark.parametrize('K', [21, 13, 30])
 def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle, K, team, monkeypatch):
-  """Every kernel behind sag_lidar_cost on the same inputs.  A lane per pose (team 0: the large-batch form): K <= 21 runs
-  the register-resident kernel (k_lidar_cost_reg), more points per env the LDS-staged one; teams of 4 / 16 lanes per
-  pose (k_lidar_cost_team) are what this batch size (BASELINE config 2's 4096) selects by itself (team None)."""
+  """Every kernel behind sag_lidar_cost on the same inputs.  A lane per pose (team 0): K <= 21 runs the register-resident
+  kernel (k_lidar_cost_reg), more points per env the LDS-staged one; teams of 2 / 4 / 8 / 16 lanes per pose
+  (k_lidar_cost_team): 16 is what this batch size (BASELINE config 2's 4096) selects by itself (team None), 8 and 4 what
+  larger batches get."""
   n = 4096
   robot, pts, grp = _lidar_inputs(n, K, 1)
   if team is not None:
@@ -71,7 +72,7 @@ def test_lidar_cost_kernel_bitexact_bins_and_flags(nat, oracle, K, team, monkeyp
   ctx.close()
 
 
-@pytest.mark.parametrize('team', [0, 4, 16])
+@pytest.mark.parametrize('team', [0, 2, 4, 8, 16])
 @pytest.mark.parametrize('K', [21, 30])
 def test_lidar_cost_device_entry_partial_block_and_unaligned_buffers(nat, K, team, monkeypatch):
   """sag_lidar_cost_device (the entry bench.py times): n not a multiple of the 64-env block (nor of a team kernel's 16 /

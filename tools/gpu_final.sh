@@ -13,7 +13,7 @@ if [ -z "$SKIP_TESTS" ]; then
 fi
 FULL=1 SUMMARY=profiles/${R}_all_summary.txt STEPS=30 timeout -k 10 1000 tools/prof.sh ${R}_all > gpurun_out/${R}_prof_all.log 2>&1
 cp gpurun_out/prof_${R}_all/summary.txt gpurun_out/${R}_all_summary.txt; cp profiles/kernels.json gpurun_out/${R}_kernels.json
-grep -E "k_lidar_cost_reg|k_doggo_physics|wrote" gpurun_out/${R}_all_summary.txt | head -8
+grep -E "k_lidar_cost_team<4>|k_doggo_physics|wrote" gpurun_out/${R}_all_summary.txt | head -8
 python tools/prof_steady.py gpurun_out/prof_${R}_all 30 4194304 point > gpurun_out/${R}_point_4M_steady.txt; grep -E "kernel trace|algorithmic|HBM traffic" gpurun_out/${R}_point_4M_steady.txt
 cp profiles/traffic.json gpurun_out/traffic_${R}.json
 fi
