@@ -2440,11 +2440,14 @@ __global__ __launch_bounds__(256) void k_compact(const int32_t* I, const uint8_t
 #ifndef SAG_BUSY_PRIO
 #define SAG_BUSY_PRIO 0
 #endif
-// Envs per busy wavefront.  A busy wavefront runs for 0.1 (Point) to 0.4 ms (Car) whatever its envs do (every loop of the contact
-// code is taken by some lane of 64), and the chip holds `slots` of them at once: a launch of W wavefronts takes ceil(W / slots)
-// rounds, and the last, part-filled round costs a whole one (Car, 4 M envs: 6300 wavefronts on ~1900 slots = 3.3 rounds took 1.83 ms
-// where the work / slots is 1.33 ms; tools/busy_timeline.py).  So the wavefronts take FEWER envs each, just enough to fill the
-// rounds that 64 per wavefront would need anyway: the divergence union of each shrinks and no round runs part-filled.
+// Envs per busy wavefront: 64 (StepArgs::busy_envs).  The alternative below - SAG_BUSY_E=0 - was built on the observation that a
+// launch of W busy wavefronts on `slots` resident ones takes ceil(W / slots) rounds and the last, part-filled round costs a whole
+// one (Car, 4 M envs, one busy list: 6300 wavefronts on ~1900 slots = 3.3 rounds took 1.83 ms where work / slots is 1.33 ms;
+// tools/busy_timeline.py): give every wavefront FEWER envs, just enough to fill the rounds that 64 per wavefront would need anyway.
+// Measured slower for every choice (56 / 48 / 40 envs per wavefront: 2.12 / 2.25 / 2.45 ms against 1.96; profiles/
+// r04_busy_envs_per_wavefront.txt): a busy wavefront's duration does not depend on how many envs it holds - some lane takes every
+// loop either way - so fewer envs per wavefront is simply more wavefronts.  What shortens a wavefront is holding envs of ONE kind
+// (BUSY_CLASSES).  Kept as a switch for measurements.
 constexpr int BUSY_MIN_ENVS = 32;
 __host__ __device__ inline int busy_wave_envs(int count, int slots) {
   const long long full = 64LL * slots;
