@@ -329,9 +329,16 @@ __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S,
   };
   uint8_t* img = out + i * (size_t)W * H * 3;
   const double aspect = (double)W / (double)H;
+  // Pixels in 8 x 8 tiles, a tile per wavefront pass: the 64 rays of a wavefront then span an eighth of the image's width instead of a
+  // whole row, and the wavefront runs the fp64 intersection of an object only when one of ITS rays passes the sphere test - with rows,
+  // some lane's ray reached nearly every object at that elevation.  Same rays, same arithmetic per pixel.
+  const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
 #pragma unroll 1
-  for (int px = threadIdx.x; px < W * H; px += 256) {
-    const int r = px / W, c = px - r * W;
+  for (int q = threadIdx.x; q < tiles_x * tiles_y * 64; q += 256) {
+    const int tile = q >> 6, w_ = q & 63, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int r = ty * 8 + (w_ >> 3), c = tx * 8 + (w_ & 7);
+    if (r >= H || c >= W) continue;
+    const int px = r * W + c;
     const double u = ((c + 0.5) / (0.5 * W) - 1.0) * cam.tanh_ * aspect, v = (1.0 - (r + 0.5) / (0.5 * H)) * cam.tanh_;
     double d[3];
     for (int k = 0; k < 3; k++) d[k] = u * cam.X[k] + v * cam.Y[k] - cam.Z[k];
@@ -339,10 +346,24 @@ __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S,
     const float fx = (float)d[0], fy = (float)d[1], fz = (float)d[2];
     double best = 1e30, col[3] = {0, 0, 0}, t;
     bool hit = false;
+    // ONE pass over the geoms (sphere test and intersection once each): an opaque hit moves the surface in; a translucent hit goes into
+    // the list of the nearest R_MAXLAYERS translucent hits, sorted by distance (equal distances keep geom order).  The layers that count
+    // are those in front of the FINAL opaque surface - a prefix of the sorted list, cut once the surface is known (below): the same set
+    // the former second pass collected with `t < best`.
+    double lt[R_MAXLAYERS];
+    int lk[R_MAXLAYERS], nl = 0;
 #pragma unroll 1
     for (int k = 0; k < nob; k++) {
       double n[3];
-      if (ob[k].alpha >= 1.0 && may_hit(k, fx, fy, fz) && r_hit(ob[k], cam.o, d, t, n) && t < best) { best = t; hit = true; r_shade(ob[k].rgb, n, d, col); }
+      if (!may_hit(k, fx, fy, fz) || !r_hit(ob[k], cam.o, d, t, n)) continue;
+      if (ob[k].alpha >= 1.0) {
+        if (t < best) { best = t; hit = true; r_shade(ob[k].rgb, n, d, col); }
+      } else {
+        int pos = nl < R_MAXLAYERS ? nl++ : (t < lt[R_MAXLAYERS - 1] ? R_MAXLAYERS - 1 : -1);
+        if (pos < 0) continue;
+        while (pos > 0 && lt[pos - 1] > t) { lt[pos] = lt[pos - 1]; lk[pos] = lk[pos - 1]; pos--; }
+        lt[pos] = t; lk[pos] = k;
+      }
     }
     if (d[2] < 0) {
       const double tf = -cam.o[2] / d[2], fx = cam.o[0] + tf * d[0], fy = cam.o[1] + tf * d[1];
@@ -356,19 +377,8 @@ __global__ __launch_bounds__(256) void k_render_rgb(const float* __restrict__ S,
       const double w = 0.5 * (d[2] + 1.0);
       col[0] = 0.1 + (0.527 - 0.1) * w; col[1] = 0.1 + (0.582 - 0.1) * w; col[2] = 0.35 + (0.906 - 0.35) * w;
     }
-    // translucent geoms in front of the opaque surface: the nearest R_MAXLAYERS of them, composited back to front
-    double lt[R_MAXLAYERS];
-    int lk[R_MAXLAYERS], nl = 0;
-#pragma unroll 1
-    for (int k = 0; k < nob; k++) {
-      double n[3];
-      if (ob[k].alpha < 1.0 && may_hit(k, fx, fy, fz) && r_hit(ob[k], cam.o, d, t, n) && t < best) {
-        int pos = nl < R_MAXLAYERS ? nl++ : (t < lt[R_MAXLAYERS - 1] ? R_MAXLAYERS - 1 : -1);
-        if (pos < 0) continue;
-        while (pos > 0 && lt[pos - 1] > t) { lt[pos] = lt[pos - 1]; lk[pos] = lk[pos - 1]; pos--; }
-        lt[pos] = t; lk[pos] = k;
-      }
-    }
+    // translucent geoms in front of the opaque surface, composited back to front
+    while (nl > 0 && !(lt[nl - 1] < best)) nl--;
     for (int q = nl - 1; q >= 0; q--) {
       double n[3], sc[3];
       r_hit(ob[lk[q]], cam.o, d, t, n);
